@@ -1,0 +1,221 @@
+"""Generate golden vectors from the REAL reference (build container only).
+
+Run:  python tests/golden/make_golden.py         (needs /root/reference; never runs on the GPU box)
+
+Imports the reference's own Python modules from /root/reference/src (read-only),
+feeds them seeded inputs and the name-seeded weight filler (oracle/filler.py) and
+stores inputs + expected outputs as small .npz fixtures next to this script.
+Nothing of the reference's source text is stored -- only data.
+
+Shims needed to import the reference here: stub modules for
+``librosa`` (only ``filters.mel`` is touched when constructing the label
+encoder), ``torchaudio.transforms``, ``torchvision``; ``np.float`` alias.
+"""
+import os
+import sys
+import types
+import copy
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/src"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from oracle.filler import fill_module_          # noqa: E402
+from oracle import features as ofeat            # noqa: E402
+
+
+def _install_shims():
+    if not hasattr(np, "float"):
+        np.float = float
+    lib = types.ModuleType("librosa")
+    lib.filters = types.SimpleNamespace(mel=lambda sr, n_fft, n_mels: ofeat.mel_filterbank(sr, n_fft, n_mels).T)
+    lib.core = types.SimpleNamespace()
+    sys.modules["librosa"] = lib
+    ta = types.ModuleType("torchaudio")
+    tat = types.ModuleType("torchaudio.transforms")
+    tat.TimeMasking = lambda **kw: (lambda x: x)
+    tat.FrequencyMasking = lambda **kw: (lambda x: x)
+    ta.transforms = tat
+    sys.modules["torchaudio"] = ta
+    sys.modules["torchaudio.transforms"] = tat
+
+
+def make_params(nb_classes=12, device="cpu"):
+    return {
+        "args": {"device": device, "encoder": "se-resnet34", "loss": "adyolo"},
+        "data_config": {"nb_classes": nb_classes, "sr": 24000, "hop_length_s": 0.025, "win_length_s": 0.05,
+                        "hop_length": 600, "win_length": 1200, "n_fft": 1200, "mel_bins": 64, "window": "han",
+                        "label_hop_len_s": 0.1, "data_pth": "/root/reference/data/DCASE2021_SELD/"},
+        "aug_config": {"rotation_augment": False, "spec_augment": False, "spec_augment_thresh": 0.5,
+                       "spec_augment_time_mask_param": 40, "spec_augment_freq_mask_param": 40},
+        "train_config": {"grid_size": [45, 45], "nb_anchors": 5, "conf_thresh": 0.5, "clss_thresh": 0.5,
+                         "unify_thresh": 15.0, "train_unify": [45.0, 25.0, 10.0], "g_overlap": 0.5,
+                         "nms": "conn-merge",
+                         "loss_gains": {"angular_gain": 5.0, "object_gain": 1.0, "nonobj_gain": 5.0,
+                                        "class_gain": 3.0}},
+    }
+
+
+EVENTS = {   # frame -> [[cls, src, az, el]]; covers az wrap (+-180), poles, duplicates in one cell, overlaps
+    0: [[3, 0, 10.0, 5.0]],
+    1: [[3, 0, 10.0, 5.0], [7, 1, -170.0, 40.0]],
+    2: [[0, 0, 180.0, -30.0], [0, 1, 175.0, -35.0]],
+    3: [[11, 0, -180.0, 89.0]],
+    4: [[5, 0, 44.9, -90.0], [5, 1, 50.0, -80.0], [2, 2, 47.0, -85.0]],
+    5: [[1, 0, 0.0, 90.0]],                 # el == 90 exactly -> no rows
+    6: [[9, 0, -135.0, 0.0]],               # exactly on a cell boundary
+    7: [[4, 0, 120.5, 60.25], [4, 1, 121.0, 59.0], [8, 2, -60.0, -45.0]],
+    9: [[6, 0, 20.0, 20.0]],                # frame >= nb_label_frames (8) -> dropped
+}
+
+
+def gen_labels():
+    from datasets import FeatureLabelProcessor, collate_fn
+    flp = FeatureLabelProcessor(make_params())
+    rows = flp.get_yolo_label(copy.deepcopy(EVENTS), 8)
+    rows = np.asarray(rows, dtype=np.float64)
+    # boundary sweep: every az on a 7.5 degree lattice (+ wrap points) x several elevations
+    sweep_in, sweep_rows = [], []
+    for az in list(np.arange(-180.0, 180.01, 7.5)) + [179.999, -179.999]:
+        for el in (-90.0, -89.9, -45.0, -22.5, 0.0, 22.5, 44.999, 45.0, 67.5, 89.999, 90.0):
+            r = flp.get_yolo_label({0: [[1, 0, float(az), float(el)]]}, 1)
+            sweep_in.append([az, el])
+            for x in r:
+                sweep_rows.append([len(sweep_in) - 1] + [float(v) for v in x])
+    # collate: sample 0 has events, sample 1 has none, sample 2 has events
+    feats = [torch.zeros(7, 8, 4), torch.ones(7, 8, 4), torch.full((7, 8, 4), 2.0)]
+    lab0 = flp.get_yolo_label(copy.deepcopy({k: v for k, v in EVENTS.items() if k < 3}), 8)
+    lab2 = flp.get_yolo_label(copy.deepcopy({k: v for k, v in EVENTS.items() if 3 <= k < 8}), 8)
+    feat_b, targ_b = collate_fn(list(zip(feats, [lab0, [], lab2])))
+    np.savez_compressed(os.path.join(HERE, "labels.npz"),
+                        rows=rows, sweep_in=np.asarray(sweep_in), sweep_rows=np.asarray(sweep_rows),
+                        collate_feat_shape=np.asarray(feat_b.shape), collate_target=targ_b.numpy(),
+                        grid_lb=flp.grid_lb, grid_ub=flp.grid_ub)
+    print("labels.npz rows", rows.shape, "sweep", len(sweep_in), len(sweep_rows), "collate", tuple(targ_b.shape))
+    return flp
+
+
+def gen_loss(flp):
+    from models.loss import ADYOLOloss
+    from datasets import collate_fn
+    out = {}
+    for tag, nb_classes, seed, scale in (("c12", 12, 11, 2.0), ("c13", 13, 12, 1.0), ("sat", 12, 13, 12.0)):
+        params = make_params(nb_classes)
+        loss_fn = ADYOLOloss(params)
+        g = torch.Generator().manual_seed(seed)
+        b, t = 2, 8
+        logit = (torch.randn(b, t, 8 * 4 * 5 * (nb_classes + 3), generator=g) * scale).requires_grad_(True)
+        ev0 = copy.deepcopy(EVENTS)
+        ev1 = {0: [[2, 0, -100.0, 10.0]], 3: [[2, 0, 33.0, -70.0], [10, 1, 34.0, -69.0]], 7: [[0, 0, 179.5, 0.5]]}
+        lab0 = flp.get_yolo_label(ev0, t)
+        lab1 = flp.get_yolo_label(ev1, t)
+        _, target = collate_fn(list(zip([torch.zeros(1), torch.zeros(1)], [lab0, lab1])))
+        loss = loss_fn(logit, target)
+        loss.backward()
+        out[tag + "_logit"] = logit.detach().numpy()
+        out[tag + "_target"] = target.numpy()
+        out[tag + "_loss"] = loss.detach().numpy()
+        out[tag + "_dlogit"] = logit.grad.numpy()
+        print("loss", tag, float(loss), "M", target.shape[0], "dlogit absmax", float(logit.grad.abs().max()))
+    np.savez_compressed(os.path.join(HERE, "adyolo_loss.npz"), **out)
+
+
+def gen_encoder():
+    from models.backbones.resnet import SEResnet34
+    from models.linearheads import ADYOLOhead
+    params = make_params()
+    enc = SEResnet34((1, 7, 64, 64), (), params)
+    head = ADYOLOhead(256, 256, 12, [45, 45], 5)
+    fill_module_(_Wrap(enc, head))      # keys 'encoder.*' / 'head.*' exactly as in the reference WrapperModel
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 7, 64, 64, generator=g)
+    probe = torch.randn(2, 16, 256, generator=g)
+    out = {"x": x.numpy(), "probe": probe.numpy()}
+
+    enc.eval()
+    with torch.no_grad():
+        taps = {}
+        h = enc.conv1(x); h = enc.relu(h); h = enc.bn1(h); taps["stem"] = h
+        h = enc.layer1(h); taps["layer1"] = h
+        h = enc.layer2(h); taps["layer2"] = h
+        h = enc.layer3(h); taps["layer3"] = h
+        h = enc.layer4(h); taps["layer4"] = h
+        y_eval = enc(x)
+        y1_eval = enc(x[:1])
+    out["y_eval"] = y_eval.numpy()
+    out["y_eval_b1"] = y1_eval.numpy()
+    for k in ("stem", "layer1", "layer4"):
+        out["tap_eval_" + k] = taps[k].numpy()[:, :4]          # first 4 channels only (size)
+    with torch.no_grad():
+        out["head_eval"] = head(y_eval).numpy()
+
+    # train mode, dropout disabled so the result is deterministic; grads of <out, probe>
+    enc.train()
+    enc.lstm.dropout = 0.0
+    xg = x.clone().requires_grad_(True)
+    y_tr = enc(xg)
+    (y_tr * probe).sum().backward()
+    out["y_train"] = y_tr.detach().numpy()
+    out["dx_train"] = xg.grad.numpy()
+    sd = enc.state_dict()
+    for k in ("bn1.running_mean", "bn1.running_var", "layer3.0.downsample.1.running_var",
+              "layer4.2.bn2.running_mean"):
+        out["stat_" + k] = sd[k].numpy()
+    out["stat_bn1.num_batches_tracked"] = sd["bn1.num_batches_tracked"].numpy()
+    named = dict(enc.named_parameters())
+    for k in ("conv1.weight", "conv1.bias", "bn1.weight", "bn1.bias", "layer1.0.conv1.weight",
+              "layer1.2.se.fc.0.weight", "layer2.0.downsample.0.weight", "layer2.0.downsample.1.weight",
+              "layer3.5.conv2.weight", "layer4.0.conv1.weight", "layer4.2.se.fc.2.bias", "attention.W.weight",
+              "attention.W.bias", "lstm.weight_ih_l0", "lstm.weight_hh_l0_reverse", "lstm.bias_hh_l1",
+              "lstm.weight_ih_l1_reverse", "norm.weight", "norm.bias"):
+        gk = named[k].grad.numpy()
+        out["grad_" + k] = gk if gk.size <= 40000 else gk.reshape(-1)[:40000]
+    np.savez_compressed(os.path.join(HERE, "encoder.npz"), **out)
+    print("encoder.npz y_eval", y_eval.shape, float(y_eval.abs().mean()), "y_train", float(y_tr.abs().mean()),
+          "dx absmax", float(xg.grad.abs().max()))
+
+    # head alone, incl. grads
+    g = torch.Generator().manual_seed(22)
+    hx = torch.randn(2, 16, 256, generator=g).requires_grad_(True)
+    hp = torch.randn(2, 16, 2400, generator=g)
+    hy = head(hx)
+    (hy * hp).sum().backward()
+    hn = dict(head.named_parameters())
+    np.savez_compressed(os.path.join(HERE, "head.npz"), x=hx.detach().numpy(), probe=hp.numpy(),
+                        y=hy.detach().numpy(), dx=hx.grad.numpy(),
+                        **{"grad_" + k: v.grad.numpy() if v.grad.numel() < 70000 else v.grad.numpy().reshape(-1)[:70000]
+                           for k, v in hn.items()})
+    print("head.npz", tuple(hy.shape))
+
+
+class _Wrap(torch.nn.Module):
+    """Same key prefixes ('encoder.', 'head.') as the reference WrapperModel (wrapper.py:26-47)."""
+
+    def __init__(self, encoder, head):
+        super().__init__()
+        self.encoder = encoder
+        self.head = head
+
+
+def gen_scaler():
+    import pickle
+    for d in ("DCASE2021", "DCASE2022"):
+        with open("/root/reference/data/%s_SELD/scaler_wts.pkl" % d, "rb") as f:
+            s = pickle.load(f)
+        np.savez_compressed(os.path.join(HERE, "scaler_%s.npz" % d),
+                            mel_mean=s["MEL"]["mean"], mel_std=s["MEL"]["std"],
+                            iv_mean=s["IV"]["mean"], iv_std=s["IV"]["std"])
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    _install_shims()
+    flp = gen_labels()
+    gen_loss(flp)
+    gen_encoder()
+    gen_scaler()
