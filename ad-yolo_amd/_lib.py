@@ -1,0 +1,95 @@
+"""ctypes binding of libadyolo_hip.so (C ABI declared in include/adyolo_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent, importing
+the ops raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` (hipcc, gfx950).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libadyolo_hip.so")
+
+P = ctypes.c_void_p
+I = ctypes.c_int
+L = ctypes.c_long
+F = ctypes.c_float
+U64 = ctypes.c_uint64
+
+# name -> (restype, argtypes); mirrors include/adyolo_hip.h one to one
+SIGNATURES = {
+    "adyolo_abi_version": (I, []),
+    "adyolo_last_error": (ctypes.c_char_p, []),
+    "adyolo_feat_stft_mel": (I, [P] * 11 + [I, I, I, P]),
+    "adyolo_feat_finish": (I, [P] * 4 + [I, I, I, P]),
+    "adyolo_nchw_to_nhwc8": (I, [P, P, I, I, I, I, P]),
+    "adyolo_pack_w3x3": (I, [P, P, P, I, I, I, P]),
+    "adyolo_conv3x3_fwd": (I, [P] * 5 + [I] * 6 + [P]),
+    "adyolo_conv3x3_wgrad_slabs": (I, [I] * 5),
+    "adyolo_conv3x3_wgrad": (I, [P] * 4 + [I] * 6 + [P]),
+    "adyolo_gemm": (I, [P] * 5 + [I] * 10 + [P]),
+    "adyolo_colsum": (I, [P, P, P, I, I, I, I, P]),
+    "adyolo_bn_stats": (I, [P] * 7 + [I, I, I, F, F, P]),
+    "adyolo_bn_eval_stats": (I, [P] * 4 + [I, F, P]),
+    "adyolo_bn_scale_shift": (I, [P] * 6 + [I, P]),
+    "adyolo_affine_nhwc": (I, [P] * 4 + [L, I, P]),
+    "adyolo_bn_bwd_reduce": (I, [P] * 7 + [L, I, P]),
+    "adyolo_bn_bwd_apply": (I, [P] * 10 + [L, I, I, P]),
+    "adyolo_se_fc_fwd": (I, [P] * 10 + [I, I, I, I, P]),
+    "adyolo_se_tail_fwd": (I, [P] * 6 + [I, I, I, P]),
+    "adyolo_se_tail_bwd_reduce": (I, [P] * 8 + [I, I, I, P]),
+    "adyolo_se_fc_bwd": (I, [P] * 21 + [I, I, I, I, P]),
+    "adyolo_se_tail_bwd_apply": (I, [P] * 12 + [I, I, I, P]),
+    "adyolo_avgpool2_fwd": (I, [P, P, I, I, I, I, P]),
+    "adyolo_avgpool2_bwd": (I, [P, P, I, I, I, I, P]),
+    "adyolo_add": (I, [P, P, P, L, P]),
+    "adyolo_mul": (I, [P, P, P, L, P]),
+    "adyolo_scale_dev": (I, [P, P, P, L, P]),
+    "adyolo_sap_fwd": (I, [P] * 5 + [I, I, I, P]),
+    "adyolo_sap_bwd": (I, [P] * 8 + [I, I, I, P]),
+    "adyolo_gru_fwd": (I, [P] * 6 + [I, I, P]),
+    "adyolo_gru_bwd": (I, [P] * 6 + [I, I, P]),
+    "adyolo_ln_tanh_fwd": (I, [P] * 4 + [L, I, F, P]),
+    "adyolo_ln_tanh_bwd": (I, [P] * 8 + [L, I, F, P]),
+    "adyolo_dropout_mask": (I, [P, L, F, U64, U64, P]),
+    "adyolo_loss_workspace_words": (L, [I, I, I, I]),
+    "adyolo_loss_fwd_bwd": (I, [P] * 6 + [I] * 7 + [P, P, F, F, F, F, P]),
+    "adyolo_adam_step": (I, [P] * 4 + [L, F, F, F, F, F, I, F, P]),
+}
+
+_lib = None
+
+
+class AdyoloHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raise loudly if it is not built (no CPU / eager fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AdyoloHipError(
+            "libadyolo_hip.so is not built (%s). Run `python -c \"import __graft_entry__ as g; g.build()\"` "
+            "(hipcc --offload-arch=gfx950). There is no fallback path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise AdyoloHipError("libadyolo_hip.so does not export %s" % name)
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.adyolo_abi_version()
+    if ver != 1:
+        raise AdyoloHipError("libadyolo_hip.so ABI version %d != 1" % ver)
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.adyolo_last_error()
+        raise AdyoloHipError("%s failed (rc=%d): %s" % (name, rc, msg.decode() if msg else "?"))
+    return rc

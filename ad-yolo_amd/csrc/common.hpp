@@ -1,0 +1,56 @@
+// Shared helpers for the gfx950 kernels of libadyolo_hip.so (CDNA4 only, wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/adyolo_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace adyolo {
+
+void set_error(const char *fmt, ...);
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+#define ADYOLO_REQUIRE(cond, code, ...)      \
+    do {                                     \
+        if (!(cond)) {                       \
+            adyolo::set_error(__VA_ARGS__);  \
+            return (code);                   \
+        }                                    \
+    } while (0)
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// v_mfma_f32_32x32x2_f32: D(32x32) += A(32x2) * B(2x32); lane l holds A[l&31][l>>5], B[l>>5][l&31];
+// D register r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+}  // namespace adyolo

@@ -1,0 +1,400 @@
+// K2: 3x3 convolution (stride 1, pad 1), channels-last, as an implicit GEMM on the exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32).  Replaces the cuDNN/MIOpen/oneDNN calls behind nn.Conv2d at
+// /root/reference/src/models/backbones/resnet.py:16,18,142 (forward, data-gradient, weight-gradient).
+//
+// Forward / data-gradient (same kernel, different weight packing):
+//   GEMM view  M = pixels, N = Cout, K = 9*Cin ordered (tap, cin).  One workgroup (4 waves) owns a
+//   TH x TW = 256-pixel patch and BN output channels.  Per 32-channel input chunk the patch plus its
+//   1-pixel halo is staged ONCE in LDS ([(TH+2)(TW+2)][KC+4] floats, 144-B rows: ds_read_b128 hits 16
+//   distinct 16-B slots per lane group) and all 9 taps read it at shifted addresses; the per-tap weight
+//   slice [BN][KC] is double-buffered in LDS and prefetched through registers under the previous tap's
+//   MFMAs.  LDS = 48.9 KB + 2 x 9.2 KB = 67 KB -> two workgroups per CU overlap one's staging with the
+//   other's matrix work.  K is walked 8 at a time: lane half h holds k = 4h..4h+3 of both operands (one
+//   ds_read_b128 each), feeding 4 MFMAs -- the sum over k is order-free so A and B only need to agree.
+// Weight-gradient:
+//   GEMM view  M = Cout, N = (tap, Cin), K = pixels.  One workgroup owns a (32 cout x 32 cin) block of
+//   every tap (9 accumulator tiles per wave) and walks pixel patches; the 4 waves split each patch's
+//   rows and are summed through LDS at the end; each workgroup writes one slab, slabs are reduced
+//   deterministically into the reference layout [Cout][Cin][3][3].
+#include "common.hpp"
+
+namespace adyolo {
+
+template <int KC, int BN, int TW>
+struct ConvCfg {
+    static constexpr int TH = 256 / TW;
+    static constexpr int HW_ = TW + 2;
+    static constexpr int HH_ = TH + 2;
+    static constexpr int NPIX = HW_ * HH_;
+    static constexpr int AS = KC + 4;
+    static constexpr int NT = BN / 32;
+    static constexpr int Q = KC / 4;
+    static constexpr int A_FLOATS = NPIX * AS;
+    static constexpr int W_FLOATS = BN * AS;
+    static constexpr int WPT = (BN * Q + 255) / 256;
+};
+
+template <int KC, int BN, int TW>
+__global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(
+    const float *__restrict__ x, const float *__restrict__ wpk, const float *__restrict__ bias,
+    const float *__restrict__ addend, float *__restrict__ y, int H, int W, int Cin, int Cout,
+    int tilesW, int tilesH, int relu) {
+    using Cfg = ConvCfg<KC, BN, TW>;
+    constexpr int TH = Cfg::TH, HW_ = Cfg::HW_, NPIX = Cfg::NPIX, AS = Cfg::AS, NT = Cfg::NT, Q = Cfg::Q;
+    constexpr int WPT = Cfg::WPT;
+    __shared__ __attribute__((aligned(16))) float As[Cfg::A_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Ws[2][Cfg::W_FLOATS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    int bid = blockIdx.x;
+    const int tw = bid % tilesW;
+    bid /= tilesW;
+    const int th = bid % tilesH;
+    const int n = bid / tilesH;
+    const int co0 = blockIdx.y * BN;
+    const int ty0 = th * TH, tx0 = tw * TW;
+
+    int prow[2], pcol[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        if (TW == 32) {
+            prow[mt] = wave * 2 + mt;
+            pcol[mt] = li;
+        } else {
+            prow[mt] = (wave * 2 + mt) * 2 + (li >> 4);
+            pcol[mt] = li & 15;
+        }
+    }
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    const int nchunks = Cin / KC;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int c0 = ch * KC;
+        __syncthreads();
+        for (int idx = tid; idx < NPIX * Q; idx += 256) {
+            const int pix = idx / Q, q = idx - pix * Q;
+            const int hy = pix / HW_, hx = pix - hy * HW_;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const float4 *>(x + (((size_t)n * H + gy) * W + gx) * Cin + c0 + q * 4);
+            *reinterpret_cast<float4 *>(&As[pix * AS + q * 4]) = v;
+        }
+        for (int idx = tid; idx < BN * Q; idx += 256) {
+            const int co = idx / Q, q = idx - co * Q;
+            *reinterpret_cast<float4 *>(&Ws[0][co * AS + q * 4]) =
+                *reinterpret_cast<const float4 *>(wpk + ((size_t)(co0 + co) * 9 + 0) * Cin + c0 + q * 4);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int cur = tap & 1;
+            float4 wn[WPT];
+            if (tap < 8) {
+#pragma unroll
+                for (int i = 0; i < WPT; ++i) {
+                    const int idx = tid + i * 256;
+                    if (idx < BN * Q) {
+                        const int co = idx / Q, q = idx - co * Q;
+                        wn[i] = *reinterpret_cast<const float4 *>(
+                            wpk + ((size_t)(co0 + co) * 9 + tap + 1) * Cin + c0 + q * 4);
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < KC / 8; ++s) {
+                float4 a[2], b[NT];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    a[mt] = *reinterpret_cast<const float4 *>(
+                        &As[((prow[mt] + ky) * HW_ + pcol[mt] + kx) * AS + s * 8 + lh * 4]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    b[nt] = *reinterpret_cast<const float4 *>(&Ws[cur][(nt * 32 + li) * AS + s * 8 + lh * 4]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[mt][nt] = mfma32(a[mt].x, b[nt].x, acc[mt][nt]);
+                        acc[mt][nt] = mfma32(a[mt].y, b[nt].y, acc[mt][nt]);
+                        acc[mt][nt] = mfma32(a[mt].z, b[nt].z, acc[mt][nt]);
+                        acc[mt][nt] = mfma32(a[mt].w, b[nt].w, acc[mt][nt]);
+                    }
+            }
+            if (tap < 8) {
+#pragma unroll
+                for (int i = 0; i < WPT; ++i) {
+                    const int idx = tid + i * 256;
+                    if (idx < BN * Q) {
+                        const int co = idx / Q, q = idx - co * Q;
+                        *reinterpret_cast<float4 *>(&Ws[cur ^ 1][co * AS + q * 4]) = wn[i];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pr = mfma_row(r, lane);
+            int row, col;
+            if (TW == 32) {
+                row = wave * 2 + mt;
+                col = pr;
+            } else {
+                row = (wave * 2 + mt) * 2 + (pr >> 4);
+                col = pr & 15;
+            }
+            const int gy = ty0 + row, gx = tx0 + col;
+            if (gy < H && gx < W) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int co = co0 + nt * 32 + li;
+                    const size_t o = (((size_t)n * H + gy) * W + gx) * Cout + co;
+                    float v = acc[mt][nt][r];
+                    if (bias) v += bias[co];
+                    if (addend) v += addend[o];
+                    if (relu) v = fmaxf(v, 0.f);
+                    y[o] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int TW>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(
+    const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ slabs, int H, int W,
+    int Cin, int Cout, int tilesW, int tilesH, int ntiles, int nsplit, int cinBlocks) {
+    constexpr int TH = 256 / TW, HW_ = TW + 2, HH_ = TH + 2, NPIX = HW_ * HH_;
+    constexpr int XS = 32, DS = 32;
+    __shared__ __attribute__((aligned(16))) float Xs[NPIX * XS];   // 43.5 KB, reused for the cross-wave sum
+    __shared__ __attribute__((aligned(16))) float Ds[256 * DS];    // 32 KB
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int split = blockIdx.x;
+    const int cb = blockIdx.y / cinBlocks, ib = blockIdx.y - cb * cinBlocks;
+    const int co0 = cb * 32, c0 = ib * 32;
+    const int cvalid = min(32, Cin - c0);       // 8 for the stem (activations padded 7 -> 8)
+    const int CinP = cinBlocks * 32;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int tile = split; tile < ntiles; tile += nsplit) {
+        int b = tile;
+        const int tw = b % tilesW;
+        b /= tilesW;
+        const int th = b % tilesH;
+        const int n = b / tilesH;
+        const int ty0 = th * TH, tx0 = tw * TW;
+        __syncthreads();
+#pragma unroll 2
+        for (int idx = tid; idx < NPIX * 8; idx += 256) {
+            const int pix = idx >> 3, q = idx & 7;
+            const int hy = pix / HW_, hx = pix - hy * HW_;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q * 4 < cvalid && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const float4 *>(x + (((size_t)n * H + gy) * W + gx) * Cin + c0 + q * 4);
+            *reinterpret_cast<float4 *>(&Xs[pix * XS + q * 4]) = v;
+        }
+#pragma unroll 2
+        for (int idx = tid; idx < 256 * 8; idx += 256) {
+            const int pix = idx >> 3, q = idx & 7;
+            const int py = pix / TW, px = pix - py * TW;
+            const int gy = ty0 + py, gx = tx0 + px;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy < H && gx < W)
+                v = *reinterpret_cast<const float4 *>(dy + (((size_t)n * H + gy) * W + gx) * Cout + co0 + q * 4);
+            *reinterpret_cast<float4 *>(&Ds[pix * DS + q * 4]) = v;
+        }
+        __syncthreads();
+        constexpr int ROWS_PER_WAVE = TH / 4;     // 2 (TW=32) or 4 (TW=16)
+        constexpr int KSTEPS = TW / 8;            // 4 or 2
+#pragma unroll 1
+        for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+            const int row = wave * ROWS_PER_WAVE + rr;
+#pragma unroll 1
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const int cbase = ks * 8 + lh * 4;
+                float a[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[q] = Ds[(row * TW + cbase + q) * DS + li];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float bq = Xs[((row + ky) * HW_ + cbase + q + kx) * XS + li];
+                        acc[tap] = mfma32(a[q], bq, acc[tap]);
+                    }
+                }
+            }
+        }
+    }
+    // cross-wave sum through LDS (Xs has 10880 >= 9216 floats), then one slab per workgroup
+    float *red = Xs;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(tap * 16 + r) * 64 + lane] = acc[tap][r];
+    }
+#pragma unroll 1
+    for (int w = 1; w < 3; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(tap * 16 + r) * 64 + lane] += acc[tap][r];
+                asm volatile("" ::: "memory");      // one tap's LDS traffic in flight at a time
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 3) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + mfma_row(r, lane);
+                slabs[(((size_t)split * Cout + co) * 9 + tap) * CinP + c0 + li] =
+                    acc[tap][r] + red[(tap * 16 + r) * 64 + lane];
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+}
+
+__global__ void conv3x3_wgrad_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ dw,
+                                            int nslab, int Cout, int CinP, int Cin_real) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // over [Cout][9][CinP]
+    const int total = Cout * 9 * CinP;
+    if (idx >= total) return;
+    const int ci = idx % CinP;
+    const int tap = (idx / CinP) % 9;
+    const int co = idx / (CinP * 9);
+    if (ci >= Cin_real) return;
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += slabs[(size_t)k * total + idx];
+    dw[((size_t)co * Cin_real + ci) * 9 + tap] = s;
+}
+
+__global__ void pack_w3x3_kernel(const float *__restrict__ w, float *__restrict__ wf,
+                                 float *__restrict__ wd, int Cout, int Cin_real, int Cin) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // over [Cout][9][Cin]
+    if (idx >= Cout * 9 * Cin) return;
+    const int ci = idx % Cin;
+    const int tap = (idx / Cin) % 9;
+    const int co = idx / (Cin * 9);
+    const float v = ci < Cin_real ? w[((size_t)co * Cin_real + ci) * 9 + tap] : 0.f;
+    wf[idx] = v;
+    if (wd) wd[((size_t)ci * 9 + (8 - tap)) * Cout + co] = v;
+}
+
+template <int KC, int BN, int TW>
+static int launch_fwd(const float *x, const float *wpk, const float *bias, const float *addend, float *y,
+                      int N, int H, int W, int Cin, int Cout, int relu, hipStream_t st) {
+    constexpr int TH = 256 / TW;
+    const int tilesW = cdiv(W, TW), tilesH = cdiv(H, TH);
+    dim3 grid((unsigned)(N * tilesH * tilesW), (unsigned)(Cout / BN));
+    hipLaunchKernelGGL((conv3x3_fwd_kernel<KC, BN, TW>), grid, dim3(256), 0, st, x, wpk, bias, addend, y, H, W,
+                       Cin, Cout, tilesW, tilesH, relu);
+    return check_launch("conv3x3_fwd");
+}
+
+static int wgrad_splits(int N, int H, int W, int Cin, int Cout, int *TWo) {
+    const int TW = W >= 32 ? 32 : 16, TH = 256 / TW;
+    const int ntiles = N * cdiv(H, TH) * cdiv(W, TW);
+    const int blocks = (Cout / 32) * cdiv(Cin, 32);
+    int nsplit = 1024 / blocks;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > ntiles) nsplit = ntiles;
+    if (TWo) *TWo = TW;
+    return nsplit;
+}
+
+}  // namespace adyolo
+
+using namespace adyolo;
+
+extern "C" int adyolo_pack_w3x3(const float *w, float *wpk_fwd, float *wpk_dgrad, int Cout, int Cin_real,
+                                int Cin, void *stream) {
+    ADYOLO_REQUIRE(w && wpk_fwd && Cout > 0 && Cin_real > 0 && Cin >= Cin_real, ADYOLO_EINVAL,
+                   "pack_w3x3: bad arguments");
+    const int total = Cout * 9 * Cin;
+    hipLaunchKernelGGL(pack_w3x3_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w, wpk_fwd,
+                       wpk_dgrad, Cout, Cin_real, Cin);
+    return check_launch("pack_w3x3");
+}
+
+extern "C" int adyolo_conv3x3_fwd(const float *x, const float *wpk, const float *bias, const float *addend,
+                                  float *y, int N, int H, int W, int Cin, int Cout, int relu, void *stream) {
+    ADYOLO_REQUIRE(x && wpk && y && N > 0 && H > 0 && W > 0, ADYOLO_EINVAL, "conv3x3_fwd: bad arguments");
+    ADYOLO_REQUIRE((Cin == 8 || Cin % 32 == 0) && Cout % 32 == 0, ADYOLO_ENOSUP,
+                   "conv3x3_fwd: Cin=%d must be 8 or a multiple of 32, Cout=%d a multiple of 32", Cin, Cout);
+    hipStream_t st = as_stream(stream);
+    const bool wide = W >= 32;
+    if (Cin == 8) {
+        return wide ? launch_fwd<8, 32, 32>(x, wpk, bias, addend, y, N, H, W, Cin, Cout, relu, st)
+                    : launch_fwd<8, 32, 16>(x, wpk, bias, addend, y, N, H, W, Cin, Cout, relu, st);
+    }
+    if (Cout % 64 == 0) {
+        return wide ? launch_fwd<32, 64, 32>(x, wpk, bias, addend, y, N, H, W, Cin, Cout, relu, st)
+                    : launch_fwd<32, 64, 16>(x, wpk, bias, addend, y, N, H, W, Cin, Cout, relu, st);
+    }
+    return wide ? launch_fwd<32, 32, 32>(x, wpk, bias, addend, y, N, H, W, Cin, Cout, relu, st)
+                : launch_fwd<32, 32, 16>(x, wpk, bias, addend, y, N, H, W, Cin, Cout, relu, st);
+}
+
+extern "C" int adyolo_conv3x3_wgrad_slabs(int N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cout % 32) return ADYOLO_EINVAL;
+    return wgrad_splits(N, H, W, Cin, Cout, nullptr);
+}
+
+extern "C" int adyolo_conv3x3_wgrad(const float *x, const float *dy, float *slabs, float *dw, int N, int H,
+                                    int W, int Cin, int Cin_real, int Cout, void *stream) {
+    ADYOLO_REQUIRE(x && dy && slabs && dw && N > 0 && H > 0 && W > 0, ADYOLO_EINVAL, "conv3x3_wgrad: bad arguments");
+    ADYOLO_REQUIRE((Cin == 8 || Cin % 32 == 0) && Cout % 32 == 0 && Cin_real <= Cin, ADYOLO_ENOSUP,
+                   "conv3x3_wgrad: unsupported channels Cin=%d Cout=%d", Cin, Cout);
+    hipStream_t st = as_stream(stream);
+    int TW;
+    const int nsplit = wgrad_splits(N, H, W, Cin, Cout, &TW);
+    const int TH = 256 / TW;
+    const int tilesW = cdiv(W, TW), tilesH = cdiv(H, TH);
+    const int ntiles = N * tilesW * tilesH;
+    const int cinBlocks = cdiv(Cin, 32);
+    dim3 grid((unsigned)nsplit, (unsigned)((Cout / 32) * cinBlocks));
+    if (TW == 32)
+        hipLaunchKernelGGL((conv3x3_wgrad_kernel<32>), grid, dim3(256), 0, st, x, dy, slabs, H, W, Cin, Cout,
+                           tilesW, tilesH, ntiles, nsplit, cinBlocks);
+    else
+        hipLaunchKernelGGL((conv3x3_wgrad_kernel<16>), grid, dim3(256), 0, st, x, dy, slabs, H, W, Cin, Cout,
+                           tilesW, tilesH, ntiles, nsplit, cinBlocks);
+    int rc = check_launch("conv3x3_wgrad");
+    if (rc) return rc;
+    const int CinP = cinBlocks * 32;
+    const int total = Cout * 9 * CinP;
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, slabs, dw, nsplit,
+                       Cout, CinP, Cin_real);
+    return check_launch("conv3x3_wgrad_reduce");
+}

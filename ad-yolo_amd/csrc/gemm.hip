@@ -1,0 +1,257 @@
+// K7: dense GEMM on the exact-fp32 MFMA, C[m][n] = sum_k opA(m,k) opB(n,k) (+bias[n]).
+// Replaces nn.Linear (linearheads.py:95-98; SE FCs resnet.py:96-98), the 1x1 downsample convolution
+// (resnet.py:160-162), the GRU input projections (resnet.py:153) and all of their backward GEMMs.
+// 128x64 output tile per workgroup (one 32-row strip per wave, two 32x32 accumulators), K tile 32.
+// k-major operands are staged as [row][36] and read with one ds_read_b128 per 4 k; m-major
+// (transposed) operands are staged as [k][rows+4] and read with four conflict-free ds_read_b32.
+#include "common.hpp"
+
+namespace adyolo {
+
+constexpr int GBM = 128, GBN = 64, GBK = 32;
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                      const float *__restrict__ bias, float *__restrict__ C,
+                                                      int M, int N, int K, int lda, int ldb, int ldc, int klen,
+                                                      size_t slab_stride, int slab_ld, int accumulate) {
+    constexpr int A_LD = TA ? (GBM + 4) : (GBK + 4);
+    constexpr int B_LD = TB ? (GBN + 4) : (GBK + 4);
+    __shared__ __attribute__((aligned(16))) float As[TA ? GBK * (GBM + 4) : GBM * (GBK + 4)];
+    __shared__ __attribute__((aligned(16))) float Bs[TB ? GBK * (GBN + 4) : GBN * (GBK + 4)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const int z = blockIdx.z;
+    const int kbeg = z * klen;
+    const int kend = min(K, kbeg + klen);
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+        __syncthreads();
+        if (!TA) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + i * 256;
+                const int row = idx >> 3, q = idx & 7;
+                const int m = m0 + row, k = k0 + q * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < M && k < kend) v = *reinterpret_cast<const float4 *>(A + (size_t)m * lda + k);
+                *reinterpret_cast<float4 *>(&As[row * A_LD + q * 4]) = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + i * 256;
+                const int kk = idx >> 5, q = idx & 31;
+                const int k = k0 + kk, m = m0 + q * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < kend && m < M) v = *reinterpret_cast<const float4 *>(A + (size_t)k * lda + m);
+                *reinterpret_cast<float4 *>(&As[kk * A_LD + q * 4]) = v;
+            }
+        }
+        if (!TB) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + i * 256;
+                const int row = idx >> 3, q = idx & 7;
+                const int nn = n0 + row, k = k0 + q * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (nn < N && k < kend) v = *reinterpret_cast<const float4 *>(B + (size_t)nn * ldb + k);
+                *reinterpret_cast<float4 *>(&Bs[row * B_LD + q * 4]) = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + i * 256;
+                const int kk = idx >> 4, q = idx & 15;
+                const int k = k0 + kk, nn = n0 + q * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < kend && nn < N) v = *reinterpret_cast<const float4 *>(B + (size_t)k * ldb + nn);
+                *reinterpret_cast<float4 *>(&Bs[kk * B_LD + q * 4]) = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < GBK / 8; ++s) {
+            float a[4], b[2][4];
+            const int kk = s * 8 + lh * 4;
+            if (!TA) {
+                const float4 v = *reinterpret_cast<const float4 *>(&As[(wave * 32 + li) * A_LD + kk]);
+                a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[q] = As[(kk + q) * A_LD + wave * 32 + li];
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                if (!TB) {
+                    const float4 v = *reinterpret_cast<const float4 *>(&Bs[(nt * 32 + li) * B_LD + kk]);
+                    b[nt][0] = v.x; b[nt][1] = v.y; b[nt][2] = v.z; b[nt][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b[nt][q] = Bs[(kk + q) * B_LD + nt * 32 + li];
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[nt] = mfma32(a[q], b[nt][q], acc[nt]);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int nn = n0 + nt * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wave * 32 + mfma_row(r, lane);
+            if (m < M && nn < N) {
+                if (slab_stride) {
+                    C[(size_t)z * slab_stride + (size_t)m * slab_ld + nn] = acc[nt][r];
+                } else {
+                    float v = acc[nt][r];
+                    if (bias) v += bias[nn];
+                    const size_t o = (size_t)m * ldc + nn;
+                    if (accumulate) v += C[o];
+                    C[o] = v;
+                }
+            }
+        }
+    }
+}
+
+__global__ void gemm_slab_reduce_kernel(const float *__restrict__ slabs, const float *__restrict__ bias,
+                                        float *__restrict__ C, int M, int N, int ldc, int splits, int accumulate) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)M * N;
+    if (idx >= total) return;
+    const int m = (int)(idx / N), nn = (int)(idx - (size_t)m * N);
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slabs[(size_t)z * total + idx];
+    if (bias) s += bias[nn];
+    const size_t o = (size_t)m * ldc + nn;
+    if (accumulate) s += C[o];
+    C[o] = s;
+}
+
+// column sums: stage 1 partial[blk][c] over a strip of rows, stage 2 sums the partials in double.
+__global__ void colsum_partial_kernel(const float *__restrict__ A, float *__restrict__ partial, long R, int C,
+                                      int lda) {
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (long r = blockIdx.x; r < R; r += gridDim.x) s += A[(size_t)r * lda + c];
+    partial[(size_t)blockIdx.x * C + c] = s;
+}
+__global__ void colsum_final_kernel(const float *__restrict__ partial, float *__restrict__ out, int nblk, int C,
+                                    int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * C + c];
+    out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+}
+
+__global__ void add_kernel(const float4 *__restrict__ a, const float4 *__restrict__ b, float4 *__restrict__ y,
+                           long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 u = a[i], v = b[i];
+        y[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    }
+}
+__global__ void mul_kernel(const float4 *__restrict__ a, const float4 *__restrict__ b, float4 *__restrict__ y,
+                           long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 u = a[i], v = b[i];
+        y[i] = make_float4(u.x * v.x, u.y * v.y, u.z * v.z, u.w * v.w);
+    }
+}
+
+__global__ void scale_dev_kernel(const float4 *__restrict__ a, const float *__restrict__ s, float4 *__restrict__ y,
+                                 long n4) {
+    const float f = s[0];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 u = a[i];
+        y[i] = make_float4(u.x * f, u.y * f, u.z * f, u.w * f);
+    }
+}
+
+}  // namespace adyolo
+
+using namespace adyolo;
+
+extern "C" int adyolo_scale_dev(const float *a, const float *scalar_dev, float *y, long n, void *stream) {
+    ADYOLO_REQUIRE(a && scalar_dev && y && n > 0 && n % 4 == 0, ADYOLO_EINVAL, "scale_dev: n must be a positive multiple of 4");
+    const long n4 = n / 4;
+    const int grid = (int)(n4 / 256 + 1 > 4096 ? 4096 : n4 / 256 + 1);
+    hipLaunchKernelGGL(scale_dev_kernel, dim3(grid), dim3(256), 0, as_stream(stream), (const float4 *)a, scalar_dev,
+                       (float4 *)y, n4);
+    return check_launch("scale_dev");
+}
+
+extern "C" int adyolo_gemm(const float *A, const float *B, const float *bias, float *C, float *slabs, int M,
+                           int N, int K, int lda, int ldb, int ldc, int transA, int transB, int splits,
+                           int accumulate, void *stream) {
+    ADYOLO_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, ADYOLO_EINVAL, "gemm: bad arguments");
+    ADYOLO_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0, ADYOLO_ENOSUP,
+                   "gemm: K=%d lda=%d ldb=%d must be multiples of 4", K, lda, ldb);
+    ADYOLO_REQUIRE((!transA || M % 4 == 0) && (!transB || N % 4 == 0), ADYOLO_ENOSUP,
+                   "gemm: transposed operands need M (N) %% 4 == 0 (M=%d N=%d)", M, N);
+    if (splits < 1) splits = 1;
+    ADYOLO_REQUIRE(splits == 1 || slabs, ADYOLO_EINVAL, "gemm: splits > 1 needs a slab workspace");
+    hipStream_t st = as_stream(stream);
+    int klen = cdiv(cdiv(K, splits), GBK) * GBK;
+    splits = cdiv(K, klen);
+    dim3 grid((unsigned)cdiv(N, GBN), (unsigned)cdiv(M, GBM), (unsigned)splits);
+    const size_t slab_stride = splits > 1 ? (size_t)M * N : 0;
+    float *out = splits > 1 ? slabs : C;
+#define LAUNCH(TA_, TB_)                                                                                       \
+    hipLaunchKernelGGL((gemm_kernel<TA_, TB_>), grid, dim3(256), 0, st, A, B, bias, out, M, N, K, lda, ldb, ldc, \
+                       klen, slab_stride, N, accumulate)
+    if (transA && transB) LAUNCH(true, true);
+    else if (transA) LAUNCH(true, false);
+    else if (transB) LAUNCH(false, true);
+    else LAUNCH(false, false);
+#undef LAUNCH
+    int rc = check_launch("gemm");
+    if (rc || splits == 1) return rc;
+    const size_t total = (size_t)M * N;
+    hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3(cdiv((long)total, 256)), dim3(256), 0, st, slabs, bias, C, M,
+                       N, ldc, splits, accumulate);
+    return check_launch("gemm_slab_reduce");
+}
+
+extern "C" int adyolo_colsum(const float *A, float *out, float *partial, int R, int C, int lda, int accumulate,
+                             void *stream) {
+    ADYOLO_REQUIRE(A && out && partial && R > 0 && C > 0, ADYOLO_EINVAL, "colsum: bad arguments");
+    hipStream_t st = as_stream(stream);
+    const int nblk = R < 256 ? R : 256;
+    const int tx = C >= 256 ? 256 : 64;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, cdiv(C, tx)), dim3(tx), 0, st, A, partial, (long)R, C, lda);
+    int rc = check_launch("colsum_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, partial, out, nblk, C, accumulate);
+    return check_launch("colsum_final");
+}
+
+extern "C" int adyolo_add(const float *a, const float *b, float *y, long n, void *stream) {
+    ADYOLO_REQUIRE(a && b && y && n > 0 && n % 4 == 0, ADYOLO_EINVAL, "add: n must be a positive multiple of 4");
+    const long n4 = n / 4;
+    const int grid = (int)(n4 / 256 + 1 > 4096 ? 4096 : n4 / 256 + 1);
+    hipLaunchKernelGGL(add_kernel, dim3(grid), dim3(256), 0, as_stream(stream), (const float4 *)a, (const float4 *)b,
+                       (float4 *)y, n4);
+    return check_launch("add");
+}
+extern "C" int adyolo_mul(const float *a, const float *b, float *y, long n, void *stream) {
+    ADYOLO_REQUIRE(a && b && y && n > 0 && n % 4 == 0, ADYOLO_EINVAL, "mul: n must be a positive multiple of 4");
+    const long n4 = n / 4;
+    const int grid = (int)(n4 / 256 + 1 > 4096 ? 4096 : n4 / 256 + 1);
+    hipLaunchKernelGGL(mul_kernel, dim3(grid), dim3(256), 0, as_stream(stream), (const float4 *)a, (const float4 *)b,
+                       (float4 *)y, n4);
+    return check_launch("mul");
+}

@@ -1,0 +1,272 @@
+// K8: AD-YOLO angular-distance responsibility-assignment loss, forward + backward, no host syncs.
+// Replaces ADYOLOloss.__call__ (/root/reference/src/models/loss.py:189-251): ~40 ATen kernels, three
+// CPU-resident label tensors and six .item() syncs per call become three launches:
+//   1. assign : one lane per target row -> decode its cell's anchors, great-circle distance D[m][a],
+//               arg-min, threshold masks; marks anchors (bit sets), counts distinct positives per
+//               threshold with the value returned by atomicOr, accumulates the angular term and its
+//               (un-normalised) gradient on the u,v logits.
+//   2. main   : ONE pass over the logits, one lane per logit (coalesced): BCE terms of the three
+//               thresholds and dlogit written in the same pass (HBM traffic = read logits + write dlogits
+//               + 6 words per anchor of assignment state).
+//   3. final  : combines the per-workgroup partial sums in double into the (1,) loss.
+#include "common.hpp"
+
+namespace adyolo {
+
+constexpr int LOSS_HDR = 64;        // counters: [0..2] Npos_i, [3] Npairs, [4] n_partials_assign
+
+struct LossGeom {
+    int B, T, Gaz, Gel, A, C, M;
+    float thr[3];
+    float gain_ang, gain_obj, gain_nonobj, gain_cls;
+    float grid_az, grid_el, span;          // span = 0.5 + g_overlap
+};
+
+__device__ __forceinline__ float deg2rad_(float d) { return d * 0.017453292519943295f; }
+__device__ __forceinline__ float rad2deg_(float r) { return r * 57.29577951308232f; }
+
+__global__ __launch_bounds__(256) void loss_assign_kernel(const float *__restrict__ logit,
+                                                          const float *__restrict__ target, LossGeom g,
+                                                          unsigned *__restrict__ hdr, unsigned *__restrict__ pos_bits,
+                                                          unsigned *__restrict__ cls_bits, float *__restrict__ ang_grad,
+                                                          float *__restrict__ ang_partial, float *__restrict__ dist,
+                                                          long NA) {
+    __shared__ float red_sum[4];
+    __shared__ int red_cnt[4];
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float my_sum = 0.f;
+    int my_pairs = 0;
+    if (m < g.M) {
+        const float *tr = target + (size_t)m * 7;
+        const int b = (int)tr[0], t = (int)tr[1], gi = (int)tr[2], gj = (int)tr[3], cl = (int)tr[4];
+        const float U = tr[5], V = tr[6];
+        if (b >= 0 && b < g.B && t >= 0 && t < g.T && gi >= 0 && gi < g.Gaz && gj >= 0 && gj < g.Gel && cl >= 0 &&
+            cl < g.C) {
+            const long cell = (((long)b * g.T + t) * g.Gaz + gi) * g.Gel + gj;
+            const int CH = g.C + 3;
+            const float off_u = gi * g.grid_az - 180.f + 0.5f * g.grid_az;
+            const float off_v = gj * g.grid_el - 90.f + 0.5f * g.grid_el;
+            const float u2 = deg2rad_(U), v2 = deg2rad_(V);
+            const float sv2 = sinf(v2), cv2 = cosf(v2);
+            float D[8], gu[8], gv[8];
+            int amin = 0;
+            for (int a = 0; a < g.A; ++a) {
+                const float *lp = logit + ((size_t)cell * g.A + a) * CH + g.C + 1;
+                const float tu = tanhf(lp[0]), tv = tanhf(lp[1]);
+                float ud = tu * g.span * g.grid_az + off_u;
+                const float vraw = tv * g.span * g.grid_el + off_v;
+                const float vd = fminf(fmaxf(vraw, -90.f), 90.f);
+                if (ud >= 180.f) ud -= 360.f;
+                if (ud < -180.f) ud += 360.f;
+                const float u1 = deg2rad_(ud), v1 = deg2rad_(vd);
+                const float sv1 = sinf(v1), cv1 = cosf(v1);
+                const float du = u1 - u2, adu = fabsf(du);
+                const float cs = sv1 * sv2 + cv1 * cv2 * cosf(adu);
+                const float lo = -1.f + 1e-7f, hi = 1.f - 1e-7f;
+                const float cc = fminf(fmaxf(cs, lo), hi);
+                D[a] = rad2deg_(acosf(cc));
+                float dD_dcs = 0.f;
+                if (cs >= lo && cs <= hi) dD_dcs = -57.29577951308232f / sqrtf(1.f - cc * cc);
+                const float sgn = du > 0.f ? 1.f : (du < 0.f ? -1.f : 0.f);
+                const float dcs_du1 = -cv1 * cv2 * sinf(adu) * sgn;
+                const float dcs_dv1 = cv1 * sv2 - sv1 * cv2 * cosf(adu);
+                const float dU_dl = (1.f - tu * tu) * g.span * g.grid_az;
+                const float dV_dl = (vraw >= -90.f && vraw <= 90.f) ? (1.f - tv * tv) * g.span * g.grid_el : 0.f;
+                gu[a] = dD_dcs * dcs_du1 * 0.017453292519943295f * dU_dl;
+                gv[a] = dD_dcs * dcs_dv1 * 0.017453292519943295f * dV_dl;
+                if (D[a] < D[amin]) amin = a;
+                if (dist) dist[(size_t)m * g.A + a] = D[a];
+            }
+            for (int a = 0; a < g.A; ++a) {
+                unsigned bits = 0;
+                for (int i = 0; i < 3; ++i)
+                    if (D[a] < g.thr[i] || a == amin) bits |= 1u << i;
+                if (!bits) continue;
+                const long anchor = cell * g.A + a;
+                const unsigned old = atomicOr(&pos_bits[anchor], bits);
+                const unsigned fresh = bits & ~old;
+                for (int i = 0; i < 3; ++i) {
+                    if (fresh & (1u << i)) atomicAdd(&hdr[i], 1u);
+                    if (bits & (1u << i)) atomicOr(&cls_bits[(size_t)i * NA + anchor], 1u << cl);
+                }
+                if (bits & 1u) {          // angular term uses the first threshold only (loss.py:241-243)
+                    my_sum += D[a] / 180.f;
+                    my_pairs += 1;
+                    atomicAdd(&ang_grad[anchor * 2 + 0], gu[a] / 180.f);
+                    atomicAdd(&ang_grad[anchor * 2 + 1], gv[a] / 180.f);
+                }
+            }
+        }
+    }
+    my_sum = wave_sum(my_sum);
+    for (int o = 32; o > 0; o >>= 1) my_pairs += __shfl_xor(my_pairs, o, 64);
+    if (lane == 0) {
+        red_sum[wave] = my_sum;
+        red_cnt[wave] = my_pairs;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ang_partial[blockIdx.x] = red_sum[0] + red_sum[1] + red_sum[2] + red_sum[3];
+        atomicAdd(&hdr[3], (unsigned)(red_cnt[0] + red_cnt[1] + red_cnt[2] + red_cnt[3]));
+    }
+}
+
+__device__ __forceinline__ float bce_grad_logit(float s, float y) {
+    // nn.BCELoss backward (s - y) / max(s (1 - s), 1e-12), chained with sigmoid' = s (1 - s)
+    const float q = s * (1.f - s);
+    return (s - y) / fmaxf(q, 1e-12f) * q;
+}
+
+__global__ __launch_bounds__(256) void loss_main_kernel(const float *__restrict__ logit, LossGeom g,
+                                                        const unsigned *__restrict__ hdr,
+                                                        const unsigned *__restrict__ pos_bits,
+                                                        const unsigned *__restrict__ cls_bits,
+                                                        const float *__restrict__ ang_grad, float *__restrict__ dlogit,
+                                                        float *__restrict__ partial, long NA, float grad_scale) {
+    __shared__ float red[4][9];
+    const int CH = g.C + 3;
+    const long total = NA * CH;
+    float npos[3], nneg[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        npos[i] = (float)hdr[i];
+        nneg[i] = (float)(NA - (long)hdr[i]);
+    }
+    const float npairs = (float)hdr[3];
+    float wpos[3], wneg[3], wcls[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        wpos[i] = g.gain_obj / (3.f * npos[i]);
+        wneg[i] = g.gain_nonobj / (3.f * nneg[i]);
+        wcls[i] = g.gain_cls / (3.f * npos[i] * (float)g.C);
+    }
+    const float wang = g.gain_ang / npairs;
+    float acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long anchor = e / CH;
+        const int ch = (int)(e - anchor * CH);
+        const float xl = logit[e];
+        float grad = 0.f;
+        if (ch <= g.C) {
+            const unsigned pb = pos_bits[anchor];
+            const float s = sigmoidf_(xl);
+            const float lp = -fmaxf(logf(s), -100.f);           // -log(s), clamped like nn.BCELoss
+            const float lq = -fmaxf(logf(1.f - s), -100.f);     // -log(1-s)
+            if (ch == 0) {
+                const float g1 = bce_grad_logit(s, 1.f), g0 = bce_grad_logit(s, 0.f);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    if (pb & (1u << i)) {
+                        acc[i] += lp;
+                        grad += wpos[i] * g1;
+                    } else {
+                        acc[3 + i] += lq;
+                        grad += wneg[i] * g0;
+                    }
+                }
+            } else if (pb) {
+                const float g1 = bce_grad_logit(s, 1.f), g0 = bce_grad_logit(s, 0.f);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    if (pb & (1u << i)) {
+                        const unsigned yb = (cls_bits[(size_t)i * NA + anchor] >> (ch - 1)) & 1u;
+                        acc[6 + i] += yb ? lp : lq;
+                        grad += wcls[i] * (yb ? g1 : g0);
+                    }
+                }
+            }
+        } else {
+            grad = wang * ang_grad[anchor * 2 + (ch - g.C - 1)];
+        }
+        if (dlogit) dlogit[e] = grad * grad_scale;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const float v = wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9)
+        partial[(size_t)blockIdx.x * 9 + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void loss_final_kernel(const float *__restrict__ partial, int nblk, const float *__restrict__ ang_partial,
+                                  int nang, const unsigned *__restrict__ hdr, LossGeom g, long NA,
+                                  float *__restrict__ loss) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s[9];
+    for (int i = 0; i < 9; ++i) s[i] = 0.0;
+    for (int b = 0; b < nblk; ++b)
+        for (int i = 0; i < 9; ++i) s[i] += (double)partial[(size_t)b * 9 + i];
+    double ang = 0.0;
+    for (int b = 0; b < nang; ++b) ang += (double)ang_partial[b];
+    double total = (double)g.gain_ang * ang / (double)hdr[3];
+    for (int i = 0; i < 3; ++i) {
+        const double np_ = (double)hdr[i], nn_ = (double)(NA - (long)hdr[i]);
+        total += ((double)g.gain_obj * s[i] / np_ + (double)g.gain_nonobj * s[3 + i] / nn_ +
+                  (double)g.gain_cls * s[6 + i] / (np_ * (double)g.C)) / 3.0;
+    }
+    loss[0] = (float)total;
+}
+
+constexpr int LOSS_MAIN_BLOCKS = 2048;
+
+}  // namespace adyolo
+
+using namespace adyolo;
+
+// workspace (32-bit words): [hdr 64][pos_bits NA][cls_bits 3*NA][ang_grad 2*NA][ang_partial ceil(M/256)][partial 9*2048]
+extern "C" long adyolo_loss_workspace_words(int BT, int G, int A, int M) {
+    const long NA = (long)BT * G * A;
+    return LOSS_HDR + 6 * NA + (long)cdiv(M > 0 ? M : 1, 256) + 9L * LOSS_MAIN_BLOCKS + 64;
+}
+
+extern "C" int adyolo_loss_fwd_bwd(const float *logit, const float *target, float *ws, float *loss, float *dlogit,
+                                   float *dist, int B, int T, int Gaz, int Gel, int A, int C, int M,
+                                   const float *thr_host, const float *gains_host, float grid_az, float grid_el,
+                                   float g_overlap, float grad_scale, void *stream) {
+    ADYOLO_REQUIRE(logit && target && ws && loss && thr_host && gains_host, ADYOLO_EINVAL, "loss: null pointer");
+    ADYOLO_REQUIRE(B > 0 && T > 0 && Gaz > 0 && Gel > 0 && A > 0 && A <= 8 && C > 0 && C <= 32, ADYOLO_ENOSUP,
+                   "loss: unsupported geometry A=%d (<=8) C=%d (<=32)", A, C);
+    ADYOLO_REQUIRE(M > 0, ADYOLO_EINVAL, "loss: M == 0 (the reference fails on an empty target too, loss.py:224)");
+    hipStream_t st = as_stream(stream);
+    const long NA = (long)B * T * Gaz * Gel * A;
+    LossGeom g;
+    g.B = B; g.T = T; g.Gaz = Gaz; g.Gel = Gel; g.A = A; g.C = C; g.M = M;
+    for (int i = 0; i < 3; ++i) g.thr[i] = thr_host[i];
+    g.gain_ang = gains_host[0]; g.gain_obj = gains_host[1]; g.gain_nonobj = gains_host[2]; g.gain_cls = gains_host[3];
+    g.grid_az = grid_az; g.grid_el = grid_el; g.span = 0.5f + g_overlap;
+
+    unsigned *hdr = reinterpret_cast<unsigned *>(ws);
+    unsigned *pos_bits = hdr + LOSS_HDR;
+    unsigned *cls_bits = pos_bits + NA;
+    float *ang_grad = reinterpret_cast<float *>(cls_bits + 3 * NA);
+    float *ang_partial = ang_grad + 2 * NA;
+    const int nang = cdiv(M, 256);
+    float *partial = ang_partial + nang;
+
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)(LOSS_HDR + 6 * NA) * 4, st);
+    if (e != hipSuccess) {
+        set_error("loss: memset failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    hipLaunchKernelGGL(loss_assign_kernel, dim3(nang), dim3(256), 0, st, logit, target, g, hdr, pos_bits, cls_bits,
+                       ang_grad, ang_partial, dist, NA);
+    int rc = check_launch("loss_assign");
+    if (rc) return rc;
+    const long total = NA * (C + 3);
+    long nb = (total + 255) / 256;
+    if (nb > LOSS_MAIN_BLOCKS) nb = LOSS_MAIN_BLOCKS;
+    hipLaunchKernelGGL(loss_main_kernel, dim3((unsigned)nb), dim3(256), 0, st, logit, g, hdr, pos_bits, cls_bits,
+                       ang_grad, dlogit, partial, NA, grad_scale);
+    rc = check_launch("loss_main");
+    if (rc) return rc;
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, partial, (int)nb, ang_partial, nang, hdr, g, NA,
+                       loss);
+    return check_launch("loss_final");
+}

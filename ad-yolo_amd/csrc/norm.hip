@@ -1,0 +1,582 @@
+// K3 / K3b / K4: BatchNorm2d (train + eval), the squeeze-excite + residual tail of SEBasicBlock, and
+// AvgPool2d(2,2) -- all HBM-bound, channels-last, float4 per lane.  Replaces nn.BatchNorm2d
+// (/root/reference/src/models/backbones/resnet.py:17,19,144,163), SELayer (:91-106), the residual
+// add + ReLU (:45-46) and nn.AvgPool2d (:13,27-29).
+// Reductions are two-stage and deterministic: per-workgroup fp32 partials (a thread sums <= a few hundred
+// values), combined in double by a single small finishing kernel.  No atomics.
+#include "common.hpp"
+
+namespace adyolo {
+
+// ---- generic two-value column reduction over rows of a [N][HW][C] tensor ---------------------------------
+// grid (G, N); partial layout [2][N*G][C]
+template <class F>
+__global__ __launch_bounds__(256) void reduce2_partial_kernel(F f, float *__restrict__ partial, int HW, int C,
+                                                              int G) {
+    __shared__ float red[2][256 * 4];
+    const int c4n = C >> 2;
+    const int ry_n = 256 / c4n;
+    const int tid = threadIdx.x;
+    const int cx = tid % c4n, ry = tid / c4n;
+    const int g = blockIdx.x, n = blockIdx.y;
+    const int chunk = (HW + G - 1) / G;
+    const int rbeg = g * chunk, rend = min(HW, rbeg + chunk);
+    float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
+    if (ry < ry_n) {
+        for (int r = rbeg + ry; r < rend; r += ry_n) {
+            float4 a, b;
+            f(n, r, cx, a, b);
+            u.x += a.x; u.y += a.y; u.z += a.z; u.w += a.w;
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        float *p0 = &red[0][(ry * c4n + cx) * 4];
+        float *p1 = &red[1][(ry * c4n + cx) * 4];
+        p0[0] = u.x; p0[1] = u.y; p0[2] = u.z; p0[3] = u.w;
+        p1[0] = v.x; p1[1] = v.y; p1[2] = v.z; p1[3] = v.w;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int y = 0; y < ry_n; ++y) {
+            s0 += red[0][y * C + c];
+            s1 += red[1][y * C + c];
+        }
+        const size_t slot = (size_t)n * G + g;
+        const size_t half = (size_t)gridDim.y * G * C;
+        partial[slot * C + c] = s0;
+        partial[half + slot * C + c] = s1;
+    }
+}
+
+struct StatsF {          // (x, x^2)
+    const float *x; int HW, C;
+    __device__ void operator()(int n, int r, int cx, float4 &a, float4 &b) const {
+        a = *reinterpret_cast<const float4 *>(x + ((size_t)n * HW + r) * C + cx * 4);
+        b = make_float4(a.x * a.x, a.y * a.y, a.z * a.z, a.w * a.w);
+    }
+};
+struct BnBwdF {          // (dy, dy * xhat)
+    const float *dy, *x, *mean, *invstd; int HW, C;
+    __device__ void operator()(int n, int r, int cx, float4 &a, float4 &b) const {
+        const size_t o = ((size_t)n * HW + r) * C + cx * 4;
+        a = *reinterpret_cast<const float4 *>(dy + o);
+        const float4 xv = *reinterpret_cast<const float4 *>(x + o);
+        const float4 m = *reinterpret_cast<const float4 *>(mean + cx * 4);
+        const float4 is = *reinterpret_cast<const float4 *>(invstd + cx * 4);
+        b = make_float4(a.x * (xv.x - m.x) * is.x, a.y * (xv.y - m.y) * is.y, a.z * (xv.z - m.z) * is.z,
+                        a.w * (xv.w - m.w) * is.w);
+    }
+};
+struct SeBwdF {          // g = de * (e > 0): (g, g * xhat(c))
+    const float *de, *e, *c, *mean, *invstd; int HW, C;
+    __device__ void operator()(int n, int r, int cx, float4 &a, float4 &b) const {
+        const size_t o = ((size_t)n * HW + r) * C + cx * 4;
+        const float4 d = *reinterpret_cast<const float4 *>(de + o);
+        const float4 ev = *reinterpret_cast<const float4 *>(e + o);
+        const float4 cv = *reinterpret_cast<const float4 *>(c + o);
+        const float4 m = *reinterpret_cast<const float4 *>(mean + cx * 4);
+        const float4 is = *reinterpret_cast<const float4 *>(invstd + cx * 4);
+        a = make_float4(ev.x > 0.f ? d.x : 0.f, ev.y > 0.f ? d.y : 0.f, ev.z > 0.f ? d.z : 0.f,
+                        ev.w > 0.f ? d.w : 0.f);
+        b = make_float4(a.x * (cv.x - m.x) * is.x, a.y * (cv.y - m.y) * is.y, a.z * (cv.z - m.z) * is.z,
+                        a.w * (cv.w - m.w) * is.w);
+    }
+};
+
+// finish: per-sample sums out0[n][c] (optional), per-sample out1[n][c] (optional), batch totals tot0/tot1 [C]
+__global__ void reduce2_final_kernel(const float *__restrict__ partial, float *__restrict__ out0,
+                                     float *__restrict__ out1, float *__restrict__ tot0,
+                                     float *__restrict__ tot1, int N, int G, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const size_t half = (size_t)N * G * C;
+    double t0 = 0.0, t1 = 0.0;
+    for (int n = 0; n < N; ++n) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int g = 0; g < G; ++g) {
+            s0 += (double)partial[((size_t)n * G + g) * C + c];
+            s1 += (double)partial[half + ((size_t)n * G + g) * C + c];
+        }
+        if (out0) out0[(size_t)n * C + c] = (float)s0;
+        if (out1) out1[(size_t)n * C + c] = (float)s1;
+        t0 += s0;
+        t1 += s1;
+    }
+    if (tot0) tot0[c] = (float)t0;
+    if (tot1) tot1[c] = (float)t1;
+}
+
+__global__ void bn_stats_final_kernel(const float *__restrict__ partial, float *__restrict__ ssum,
+                                      float *__restrict__ mean, float *__restrict__ invstd,
+                                      float *__restrict__ rmean, float *__restrict__ rvar, int N, int G, int C,
+                                      double R, float momentum, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const size_t half = (size_t)N * G * C;
+    double t0 = 0.0, t1 = 0.0;
+    for (int n = 0; n < N; ++n) {
+        double s0 = 0.0;
+        for (int g = 0; g < G; ++g) {
+            s0 += (double)partial[((size_t)n * G + g) * C + c];
+            t1 += (double)partial[half + ((size_t)n * G + g) * C + c];
+        }
+        if (ssum) ssum[(size_t)n * C + c] = (float)s0;
+        t0 += s0;
+    }
+    const double m = t0 / R;
+    double var = t1 / R - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+    if (rvar) {
+        const double unbiased = R > 1.0 ? var * R / (R - 1.0) : var;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_eval_stats_kernel(const float *rm, const float *rv, float *mean, float *invstd, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        mean[c] = rm[c];
+        invstd[c] = 1.0f / sqrtf(rv[c] + eps);
+    }
+}
+__global__ void bn_scale_shift_kernel(const float *gamma, const float *beta, const float *mean, const float *invstd,
+                                      float *scale, float *shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float s = gamma[c] * invstd[c];
+        scale[c] = s;
+        shift[c] = beta[c] - mean[c] * s;
+    }
+}
+
+__global__ __launch_bounds__(256) void affine_kernel(const float *__restrict__ x, const float *__restrict__ scale,
+                                                     const float *__restrict__ shift, float *__restrict__ y,
+                                                     long n4, int c4n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int cx = (int)(i % c4n);
+        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+        const float4 s = reinterpret_cast<const float4 *>(scale)[cx];
+        const float4 t = reinterpret_cast<const float4 *>(shift)[cx];
+        reinterpret_cast<float4 *>(y)[i] =
+            make_float4(v.x * s.x + t.x, v.y * s.y + t.y, v.z * s.z + t.z, v.w * s.w + t.w);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ gamma,
+    const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ sdy,
+    const float *__restrict__ sdyx, float *__restrict__ dx, long n4, int c4n, float invR, int relu_mask) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int cx = (int)(i % c4n);
+        const float4 d = reinterpret_cast<const float4 *>(dy)[i];
+        const float4 xv = reinterpret_cast<const float4 *>(x)[i];
+        const float4 g = reinterpret_cast<const float4 *>(gamma)[cx];
+        const float4 m = reinterpret_cast<const float4 *>(mean)[cx];
+        const float4 is = reinterpret_cast<const float4 *>(invstd)[cx];
+        const float4 a = reinterpret_cast<const float4 *>(sdy)[cx];
+        const float4 b = reinterpret_cast<const float4 *>(sdyx)[cx];
+        float4 o;
+        o.x = g.x * is.x * (d.x - a.x * invR - (xv.x - m.x) * is.x * b.x * invR);
+        o.y = g.y * is.y * (d.y - a.y * invR - (xv.y - m.y) * is.y * b.y * invR);
+        o.z = g.z * is.z * (d.z - a.z * invR - (xv.z - m.z) * is.z * b.z * invR);
+        o.w = g.w * is.w * (d.w - a.w * invR - (xv.w - m.w) * is.w * b.w * invR);
+        if (relu_mask) {
+            if (!(xv.x > 0.f)) o.x = 0.f;
+            if (!(xv.y > 0.f)) o.y = 0.f;
+            if (!(xv.z > 0.f)) o.z = 0.f;
+            if (!(xv.w > 0.f)) o.w = 0.f;
+        }
+        reinterpret_cast<float4 *>(dx)[i] = o;
+    }
+}
+__global__ void accum2_kernel(const float *a, const float *b, float *da, float *db, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        if (da) da[c] += a[c];
+        if (db) db[c] += b[c];
+    }
+}
+
+// ---- SE -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void se_fc_fwd_kernel(
+    const float *__restrict__ ssum, const float *__restrict__ scale, const float *__restrict__ shift,
+    const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ w2,
+    const float *__restrict__ b2, float *__restrict__ pooled, float *__restrict__ hid, float *__restrict__ s,
+    int HW, int C, int Cr) {
+    __shared__ float pl[1024];
+    __shared__ float hd[128];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float invHW = 1.0f / (float)HW;
+    for (int c = tid; c < C; c += 256) {
+        const float p = scale[c] * (ssum[(size_t)n * C + c] * invHW) + shift[c];
+        pl[c] = p;
+        pooled[(size_t)n * C + c] = p;
+    }
+    __syncthreads();
+    for (int j = wave; j < Cr; j += 4) {
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a += w1[(size_t)j * C + c] * pl[c];
+        a = wave_sum(a);
+        if (lane == 0) {
+            const float h = fmaxf(a + b1[j], 0.f);
+            hd[j] = h;
+            hid[(size_t)n * Cr + j] = h;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float a = b2[c];
+        for (int j = 0; j < Cr; ++j) a += w2[(size_t)c * Cr + j] * hd[j];
+        s[(size_t)n * C + c] = sigmoidf_(a);
+    }
+}
+
+__global__ __launch_bounds__(256) void se_tail_fwd_kernel(
+    const float *__restrict__ c, const float *__restrict__ r, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ s, float *__restrict__ e, long hw4, int c4n) {
+    // grid (blocks, N): hw4 = HW * C/4 float4 per sample
+    const int n = blockIdx.y;
+    const size_t base = (size_t)n * hw4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw4; i += (long)gridDim.x * blockDim.x) {
+        const int cx = (int)(i % c4n);
+        const float4 cv = reinterpret_cast<const float4 *>(c)[base + i];
+        const float4 rv = reinterpret_cast<const float4 *>(r)[base + i];
+        const float4 sc = reinterpret_cast<const float4 *>(scale)[cx];
+        const float4 sh = reinterpret_cast<const float4 *>(shift)[cx];
+        const float4 sv = reinterpret_cast<const float4 *>(s)[(size_t)n * c4n + cx];
+        float4 o;
+        o.x = fmaxf((cv.x * sc.x + sh.x) * sv.x + rv.x, 0.f);
+        o.y = fmaxf((cv.y * sc.y + sh.y) * sv.y + rv.y, 0.f);
+        o.z = fmaxf((cv.z * sc.z + sh.z) * sv.z + rv.z, 0.f);
+        o.w = fmaxf((cv.w * sc.w + sh.w) * sv.w + rv.w, 0.f);
+        reinterpret_cast<float4 *>(e)[base + i] = o;
+    }
+}
+
+// single workgroup walks the batch: tiny (N*C*Cr) and keeps parameter-gradient sums deterministic
+__global__ __launch_bounds__(256) void se_fc_bwd_kernel(
+    const float *__restrict__ sg, const float *__restrict__ sgx, const float *__restrict__ ssum,
+    const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const float *__restrict__ pooled, const float *__restrict__ hid,
+    const float *__restrict__ s, const float *__restrict__ w1, const float *__restrict__ w2,
+    float *__restrict__ dw1, float *__restrict__ db1, float *__restrict__ dw2, float *__restrict__ db2,
+    float *__restrict__ dpool, float *__restrict__ sdd, float *__restrict__ sddx, float *__restrict__ dgamma,
+    float *__restrict__ dbeta, int N, int HW, int C, int Cr) {
+    // thread c owns channel c (C <= 256); Cr <= 32
+    __shared__ float dz2[256];
+    __shared__ float dz1[32];
+    __shared__ float hd[32];
+    const int c = threadIdx.x;
+    const bool act = c < C;
+    float a_dw2[32], a_dw1[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { a_dw2[j] = 0.f; a_dw1[j] = 0.f; }
+    float a_db2 = 0.f, a_sdd = 0.f, a_sddx = 0.f, a_db1 = 0.f;
+    const float g_c = act ? gamma[c] : 0.f, b_c = act ? beta[c] : 0.f;
+    const float m_c = act ? mean[c] : 0.f, is_c = act ? invstd[c] : 0.f;
+    const float invHW = 1.0f / (float)HW;
+    for (int n = 0; n < N; ++n) {
+        float sgv = 0.f, sgxv = 0.f, sv = 0.f, z2 = 0.f;
+        if (act) {
+            sgv = sg[(size_t)n * C + c];
+            sgxv = sgx[(size_t)n * C + c];
+            sv = s[(size_t)n * C + c];
+            const float ds = g_c * sgxv + b_c * sgv;      // sum_hw g * d,  d = xhat*gamma + beta
+            z2 = ds * sv * (1.f - sv);
+            a_db2 += z2;
+        }
+        __syncthreads();
+        dz2[c] = z2;
+        if (c < Cr) hd[c] = hid[(size_t)n * Cr + c];
+        __syncthreads();
+        if (c < Cr) {
+            float dh = 0.f;
+            for (int k = 0; k < C; ++k) dh += dz2[k] * w2[(size_t)k * Cr + c];
+            const float z1 = hd[c] > 0.f ? dh : 0.f;
+            dz1[c] = z1;
+            a_db1 += z1;
+        }
+        __syncthreads();
+        if (act) {
+            const float pc = pooled[(size_t)n * C + c];
+            float dp = 0.f;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                if (j < Cr) {
+                    a_dw2[j] += z2 * hd[j];
+                    a_dw1[j] += dz1[j] * pc;
+                    dp += dz1[j] * w1[(size_t)j * C + c];
+                }
+            }
+            // pooled = scale*mean_hw(c)+shift  -> d(pooled)/d(d at each pixel) = 1/HW
+            dpool[(size_t)n * C + c] = dp;
+            const float sxhat = (ssum[(size_t)n * C + c] - (float)HW * m_c) * is_c;   // sum_hw xhat
+            a_sdd += sv * sgv + dp;
+            a_sddx += sv * sgxv + dp * invHW * sxhat;
+        }
+    }
+    if (act) {
+        db2[c] += a_db2;
+        sdd[c] = a_sdd;
+        sddx[c] = a_sddx;
+        if (dgamma) dgamma[c] += a_sddx;
+        if (dbeta) dbeta[c] += a_sdd;
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+            if (j < Cr) {
+                dw2[(size_t)c * Cr + j] += a_dw2[j];
+                dw1[(size_t)j * C + c] += a_dw1[j];
+            }
+    }
+    if (c < Cr) db1[c] += a_db1;
+}
+
+__global__ __launch_bounds__(256) void se_tail_bwd_apply_kernel(
+    const float *__restrict__ de, const float *__restrict__ e, const float *__restrict__ c,
+    const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ invstd,
+    const float *__restrict__ s, const float *__restrict__ dpool, const float *__restrict__ sdd,
+    const float *__restrict__ sddx, float *__restrict__ dc, float *__restrict__ dr, long hw4, int c4n,
+    float invHW, float invR) {
+    const int n = blockIdx.y;
+    const size_t base = (size_t)n * hw4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw4; i += (long)gridDim.x * blockDim.x) {
+        const int cx = (int)(i % c4n);
+        const float4 d = reinterpret_cast<const float4 *>(de)[base + i];
+        const float4 ev = reinterpret_cast<const float4 *>(e)[base + i];
+        const float4 cv = reinterpret_cast<const float4 *>(c)[base + i];
+        const float4 ga = reinterpret_cast<const float4 *>(gamma)[cx];
+        const float4 m = reinterpret_cast<const float4 *>(mean)[cx];
+        const float4 is = reinterpret_cast<const float4 *>(invstd)[cx];
+        const float4 sv = reinterpret_cast<const float4 *>(s)[(size_t)n * c4n + cx];
+        const float4 dp = reinterpret_cast<const float4 *>(dpool)[(size_t)n * c4n + cx];
+        const float4 a = reinterpret_cast<const float4 *>(sdd)[cx];
+        const float4 b = reinterpret_cast<const float4 *>(sddx)[cx];
+        float4 g, o;
+        g.x = ev.x > 0.f ? d.x : 0.f;
+        g.y = ev.y > 0.f ? d.y : 0.f;
+        g.z = ev.z > 0.f ? d.z : 0.f;
+        g.w = ev.w > 0.f ? d.w : 0.f;
+        o.x = ga.x * is.x * (g.x * sv.x + dp.x * invHW - a.x * invR - (cv.x - m.x) * is.x * b.x * invR);
+        o.y = ga.y * is.y * (g.y * sv.y + dp.y * invHW - a.y * invR - (cv.y - m.y) * is.y * b.y * invR);
+        o.z = ga.z * is.z * (g.z * sv.z + dp.z * invHW - a.z * invR - (cv.z - m.z) * is.z * b.z * invR);
+        o.w = ga.w * is.w * (g.w * sv.w + dp.w * invHW - a.w * invR - (cv.w - m.w) * is.w * b.w * invR);
+        reinterpret_cast<float4 *>(dc)[base + i] = o;
+        reinterpret_cast<float4 *>(dr)[base + i] = g;
+    }
+}
+
+// ---- AvgPool2d(2,2) -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                           int H, int W, int c4n, long total4) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int cx = (int)(i % c4n);
+        long p = i / c4n;
+        const int wo = (int)(p % Wo);
+        p /= Wo;
+        const int ho = (int)(p % Ho);
+        const long n = p / Ho;
+        const float4 *src = reinterpret_cast<const float4 *>(x) + (((size_t)n * H + 2 * ho) * W + 2 * wo) * c4n + cx;
+        const float4 a = src[0], b = src[c4n], c = src[(size_t)W * c4n], d = src[(size_t)W * c4n + c4n];
+        reinterpret_cast<float4 *>(y)[i] = make_float4(0.25f * (a.x + b.x + c.x + d.x), 0.25f * (a.y + b.y + c.y + d.y),
+                                                       0.25f * (a.z + b.z + c.z + d.z), 0.25f * (a.w + b.w + c.w + d.w));
+    }
+}
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx,
+                                                           int H, int W, int c4n, long total4) {
+    // total4 over the INPUT (H x W) grid
+    const int Ho = H >> 1, Wo = W >> 1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int cx = (int)(i % c4n);
+        long p = i / c4n;
+        const int w = (int)(p % W);
+        p /= W;
+        const int h = (int)(p % H);
+        const long n = p / H;
+        const float4 g = reinterpret_cast<const float4 *>(dy)[(((size_t)n * Ho + (h >> 1)) * Wo + (w >> 1)) * c4n + cx];
+        reinterpret_cast<float4 *>(dx)[i] = make_float4(0.25f * g.x, 0.25f * g.y, 0.25f * g.z, 0.25f * g.w);
+    }
+}
+
+static inline int ew_grid(long n4) {
+    long g = (n4 + 255) / 256;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+static inline bool chan_ok(int C) { return C >= 4 && C <= 1024 && (C % 4) == 0 && (256 % (C / 4)) == 0; }
+static inline int pick_G(int N, int HW) {
+    int G = 1024 / N;
+    if (G < 1) G = 1;
+    const int need = (HW + 63) / 64;
+    if (G > need) G = need;
+    return G;
+}
+
+}  // namespace adyolo
+
+using namespace adyolo;
+
+extern "C" int adyolo_bn_stats(const float *x, float *ssum, float *mean, float *invstd, float *running_mean,
+                               float *running_var, float *partial, int N, int HW, int C, float momentum, float eps,
+                               void *stream) {
+    ADYOLO_REQUIRE(x && mean && invstd && partial && N > 0 && HW > 0, ADYOLO_EINVAL, "bn_stats: bad arguments");
+    ADYOLO_REQUIRE(chan_ok(C) && N <= 1024, ADYOLO_ENOSUP, "bn_stats: unsupported C=%d or N=%d", C, N);
+    hipStream_t st = as_stream(stream);
+    const int G = pick_G(N, HW);
+    StatsF f{x, HW, C};
+    hipLaunchKernelGGL((reduce2_partial_kernel<StatsF>), dim3(G, N), dim3(256), 0, st, f, partial, HW, C, G);
+    int rc = check_launch("bn_stats_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, partial, ssum, mean, invstd,
+                       running_mean, running_var, N, G, C, (double)N * (double)HW, momentum, eps);
+    return check_launch("bn_stats_final");
+}
+
+extern "C" int adyolo_bn_eval_stats(const float *running_mean, const float *running_var, float *mean, float *invstd,
+                                    int C, float eps, void *stream) {
+    ADYOLO_REQUIRE(running_mean && running_var && mean && invstd && C > 0, ADYOLO_EINVAL, "bn_eval_stats: bad arguments");
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(stream), running_mean,
+                       running_var, mean, invstd, C, eps);
+    return check_launch("bn_eval_stats");
+}
+
+extern "C" int adyolo_bn_scale_shift(const float *gamma, const float *beta, const float *mean, const float *invstd,
+                                     float *scale, float *shift, int C, void *stream) {
+    ADYOLO_REQUIRE(gamma && beta && mean && invstd && scale && shift && C > 0, ADYOLO_EINVAL, "bn_scale_shift: bad arguments");
+    hipLaunchKernelGGL(bn_scale_shift_kernel, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(stream), gamma, beta, mean,
+                       invstd, scale, shift, C);
+    return check_launch("bn_scale_shift");
+}
+
+extern "C" int adyolo_affine_nhwc(const float *x, const float *scale, const float *shift, float *y, long rows, int C,
+                                  void *stream) {
+    ADYOLO_REQUIRE(x && scale && shift && y && rows > 0 && C > 0 && C % 4 == 0, ADYOLO_EINVAL, "affine_nhwc: bad arguments");
+    const long n4 = rows * (C / 4);
+    hipLaunchKernelGGL(affine_kernel, dim3(ew_grid(n4)), dim3(256), 0, as_stream(stream), x, scale, shift, y, n4, C / 4);
+    return check_launch("affine_nhwc");
+}
+
+extern "C" int adyolo_bn_bwd_reduce(const float *dy, const float *x, const float *mean, const float *invstd,
+                                    float *sdy, float *sdyx, float *partial, long rows, int C, void *stream) {
+    ADYOLO_REQUIRE(dy && x && mean && invstd && sdy && sdyx && partial && rows > 0, ADYOLO_EINVAL, "bn_bwd_reduce: bad arguments");
+    ADYOLO_REQUIRE(chan_ok(C) && rows < (1L << 31), ADYOLO_ENOSUP, "bn_bwd_reduce: unsupported C=%d", C);
+    hipStream_t st = as_stream(stream);
+    const int HW = (int)rows;
+    int G = (HW + 63) / 64;
+    if (G > 1024) G = 1024;
+    BnBwdF f{dy, x, mean, invstd, HW, C};
+    hipLaunchKernelGGL((reduce2_partial_kernel<BnBwdF>), dim3(G, 1), dim3(256), 0, st, f, partial, HW, C, G);
+    int rc = check_launch("bn_bwd_reduce_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(reduce2_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, partial, (float *)nullptr,
+                       (float *)nullptr, sdy, sdyx, 1, G, C);
+    return check_launch("bn_bwd_reduce_final");
+}
+
+extern "C" int adyolo_bn_bwd_apply(const float *dy, const float *x, const float *gamma, const float *mean,
+                                   const float *invstd, const float *sdy, const float *sdyx, float *dx, float *dgamma,
+                                   float *dbeta, long rows, int C, int relu_mask, void *stream) {
+    ADYOLO_REQUIRE(dy && x && gamma && mean && invstd && sdy && sdyx && dx && rows > 0 && C % 4 == 0, ADYOLO_EINVAL,
+                   "bn_bwd_apply: bad arguments");
+    hipStream_t st = as_stream(stream);
+    const long n4 = rows * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, dy, x, gamma, mean, invstd, sdy, sdyx,
+                       dx, n4, C / 4, (float)(1.0 / (double)rows), relu_mask);
+    int rc = check_launch("bn_bwd_apply");
+    if (rc) return rc;
+    if (dgamma || dbeta) {
+        hipLaunchKernelGGL(accum2_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, sdyx, sdy, dgamma, dbeta, C);
+        rc = check_launch("bn_bwd_accum");
+    }
+    return rc;
+}
+
+extern "C" int adyolo_se_fc_fwd(const float *ssum, const float *scale, const float *shift, const float *w1,
+                                const float *b1, const float *w2, const float *b2, float *pooled, float *hid, float *s,
+                                int N, int HW, int C, int Cr, void *stream) {
+    ADYOLO_REQUIRE(ssum && scale && shift && w1 && b1 && w2 && b2 && pooled && hid && s && N > 0, ADYOLO_EINVAL,
+                   "se_fc_fwd: bad arguments");
+    ADYOLO_REQUIRE(C <= 1024 && Cr <= 128, ADYOLO_ENOSUP, "se_fc_fwd: C=%d Cr=%d too large", C, Cr);
+    hipLaunchKernelGGL(se_fc_fwd_kernel, dim3(N), dim3(256), 0, as_stream(stream), ssum, scale, shift, w1, b1, w2, b2,
+                       pooled, hid, s, HW, C, Cr);
+    return check_launch("se_fc_fwd");
+}
+
+extern "C" int adyolo_se_tail_fwd(const float *c, const float *r, const float *scale, const float *shift,
+                                  const float *s, float *e, int N, int HW, int C, void *stream) {
+    ADYOLO_REQUIRE(c && r && scale && shift && s && e && N > 0 && HW > 0 && C % 4 == 0, ADYOLO_EINVAL,
+                   "se_tail_fwd: bad arguments");
+    const long hw4 = (long)HW * (C / 4);
+    int gx = ew_grid(hw4);
+    if ((long)gx * N > 16384) gx = (int)(16384 / N > 0 ? 16384 / N : 1);
+    hipLaunchKernelGGL(se_tail_fwd_kernel, dim3(gx, N), dim3(256), 0, as_stream(stream), c, r, scale, shift, s, e, hw4,
+                       C / 4);
+    return check_launch("se_tail_fwd");
+}
+
+extern "C" int adyolo_se_tail_bwd_reduce(const float *de, const float *e, const float *c, const float *mean,
+                                         const float *invstd, float *sg, float *sgx, float *partial, int N, int HW,
+                                         int C, void *stream) {
+    ADYOLO_REQUIRE(de && e && c && mean && invstd && sg && sgx && partial && N > 0 && HW > 0, ADYOLO_EINVAL,
+                   "se_tail_bwd_reduce: bad arguments");
+    ADYOLO_REQUIRE(chan_ok(C) && N <= 1024, ADYOLO_ENOSUP, "se_tail_bwd_reduce: unsupported C=%d or N=%d", C, N);
+    hipStream_t st = as_stream(stream);
+    const int G = pick_G(N, HW);
+    SeBwdF f{de, e, c, mean, invstd, HW, C};
+    hipLaunchKernelGGL((reduce2_partial_kernel<SeBwdF>), dim3(G, N), dim3(256), 0, st, f, partial, HW, C, G);
+    int rc = check_launch("se_tail_bwd_reduce_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(reduce2_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, partial, sg, sgx, (float *)nullptr,
+                       (float *)nullptr, N, G, C);
+    return check_launch("se_tail_bwd_reduce_final");
+}
+
+extern "C" int adyolo_se_fc_bwd(const float *sg, const float *sgx, const float *ssum, const float *gamma,
+                                const float *beta, const float *mean, const float *invstd, const float *pooled,
+                                const float *hid, const float *s, const float *w1, const float *w2, float *dw1,
+                                float *db1, float *dw2, float *db2, float *dpool, float *sdd, float *sddx,
+                                float *dgamma, float *dbeta, int N, int HW, int C, int Cr, void *stream) {
+    ADYOLO_REQUIRE(sg && sgx && ssum && gamma && beta && mean && invstd && pooled && hid && s && w1 && w2 && dw1 &&
+                       db1 && dw2 && db2 && dpool && sdd && sddx && N > 0,
+                   ADYOLO_EINVAL, "se_fc_bwd: bad arguments");
+    ADYOLO_REQUIRE(C <= 256 && Cr <= 32, ADYOLO_ENOSUP, "se_fc_bwd: C=%d (<=256) Cr=%d (<=32)", C, Cr);
+    hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), sg, sgx, ssum, gamma, beta, mean,
+                       invstd, pooled, hid, s, w1, w2, dw1, db1, dw2, db2, dpool, sdd, sddx, dgamma, dbeta, N, HW, C,
+                       Cr);
+    return check_launch("se_fc_bwd");
+}
+
+extern "C" int adyolo_se_tail_bwd_apply(const float *de, const float *e, const float *c, const float *gamma,
+                                        const float *mean, const float *invstd, const float *s, const float *dpool,
+                                        const float *sdd, const float *sddx, float *dc, float *dr, int N, int HW,
+                                        int C, void *stream) {
+    ADYOLO_REQUIRE(de && e && c && gamma && mean && invstd && s && dpool && sdd && sddx && dc && dr && N > 0 &&
+                       HW > 0 && C % 4 == 0,
+                   ADYOLO_EINVAL, "se_tail_bwd_apply: bad arguments");
+    const long hw4 = (long)HW * (C / 4);
+    int gx = ew_grid(hw4);
+    if ((long)gx * N > 16384) gx = (int)(16384 / N > 0 ? 16384 / N : 1);
+    hipLaunchKernelGGL(se_tail_bwd_apply_kernel, dim3(gx, N), dim3(256), 0, as_stream(stream), de, e, c, gamma, mean,
+                       invstd, s, dpool, sdd, sddx, dc, dr, hw4, C / 4, 1.0f / (float)HW,
+                       (float)(1.0 / ((double)N * (double)HW)));
+    return check_launch("se_tail_bwd_apply");
+}
+
+extern "C" int adyolo_avgpool2_fwd(const float *x, float *y, int N, int H, int W, int C, void *stream) {
+    ADYOLO_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, ADYOLO_EINVAL,
+                   "avgpool2_fwd: H, W must be even and C %% 4 == 0");
+    const long total4 = (long)N * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, as_stream(stream), x, y, H, W, C / 4,
+                       total4);
+    return check_launch("avgpool2_fwd");
+}
+extern "C" int adyolo_avgpool2_bwd(const float *dy, float *dx, int N, int H, int W, int C, void *stream) {
+    ADYOLO_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, ADYOLO_EINVAL,
+                   "avgpool2_bwd: H, W must be even and C %% 4 == 0");
+    const long total4 = (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, as_stream(stream), dy, dx, H, W, C / 4,
+                       total4);
+    return check_launch("avgpool2_bwd");
+}

@@ -1,0 +1,81 @@
+// K11: fused Adam over one flat parameter buffer (all 6.68 M parameters live in one allocation, so one
+// launch updates the whole model and one RCCL all-reduce covers all gradients).  Arithmetic follows
+// torch.optim.Adam's single-tensor path (used at /root/reference/src/train.py:31,55; amsgrad off):
+//   m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g^2;  p -= lr/(1 - b1^t) * m / (sqrt(v)/sqrt(1 - b2^t) + eps)
+// Also: the error string holder of the library and the NCHW -> NHWC8 entry transpose.
+#include <stdarg.h>
+#include <math.h>
+#include "common.hpp"
+
+namespace adyolo {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                   float *__restrict__ m, float *__restrict__ v, long n, float beta1,
+                                                   float beta2, float eps, float wd, float step_size,
+                                                   float inv_sqrt_bc2, float grad_scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float gi = g[i] * grad_scale;
+        const float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        float mi = m[i], vi = v[i];
+        mi += (gi - mi) * (1.f - beta1);
+        vi = vi * beta2 + (1.f - beta2) * gi * gi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        p[i] = pi - step_size * (mi / denom);
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc8_kernel(const float *__restrict__ x, float *__restrict__ y, int C,
+                                                            long HW, long total) {
+    // one thread per output pixel: gathers C (<= 8) planes, writes 32 contiguous bytes
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / HW, p = i - n * HW;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = c < C ? x[((size_t)n * C + c) * HW + p] : 0.f;
+        float4 *o = reinterpret_cast<float4 *>(y + (size_t)i * 8);
+        o[0] = make_float4(v[0], v[1], v[2], v[3]);
+        o[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
+}  // namespace adyolo
+
+using namespace adyolo;
+
+extern "C" int adyolo_abi_version(void) { return ADYOLO_ABI_VERSION; }
+extern "C" const char *adyolo_last_error(void) { return g_err; }
+
+extern "C" int adyolo_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long n, float lr,
+                                float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                                void *stream) {
+    ADYOLO_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, ADYOLO_EINVAL, "adam_step: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    const long g = (n + 255) / 256;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, as_stream(stream), param, grad,
+                       exp_avg, exp_avg_sq, n, beta1, beta2, eps, weight_decay, step_size, inv_sqrt_bc2, grad_scale);
+    return check_launch("adam_step");
+}
+
+extern "C" int adyolo_nchw_to_nhwc8(const float *x, float *y, int B, int C, int H, int W, void *stream) {
+    ADYOLO_REQUIRE(x && y && B > 0 && C > 0 && C <= 8 && H > 0 && W > 0, ADYOLO_EINVAL, "nchw_to_nhwc8: bad arguments");
+    const long HW = (long)H * W, total = (long)B * HW;
+    const long g = (total + 255) / 256;
+    hipLaunchKernelGGL(nchw_to_nhwc8_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, as_stream(stream), x,
+                       y, C, HW, total);
+    return check_launch("nchw_to_nhwc8");
+}

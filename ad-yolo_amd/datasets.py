@@ -1,0 +1,105 @@
+"""Host-side label logic of the AD-YOLO path and the synthetic workload generator.
+
+Mirror of the label half of /root/reference/src/datasets.py: grid constants :219-238, ``get_yolo_label``
+:457-482 (event -> responsible overlapping grid cells) and ``collate_fn`` :164-184 (rows
+``[batch, frame, Gi, Gj, cls, U, V]``).  Pure NumPy/host code -- tiny next to the GPU path -- but
+vectorised over events instead of the reference's Python loops.  Synthetic inputs follow SURVEY.md 8d.
+"""
+import math
+
+import numpy as np
+import torch
+
+
+class YoloLabelEncoder:
+    def __init__(self, params=None, grid_size=(45, 45), g_overlap=0.5):
+        if params is not None:
+            grid_size = params["train_config"]["grid_size"]
+            g_overlap = params["train_config"]["g_overlap"]
+        gs = np.asarray(grid_size, dtype=np.float64)
+        self.nb_grids = [int(math.ceil(360.0 / gs[0])), int(math.ceil(180.0 / gs[1]))]
+        half = gs * (0.5 + g_overlap)
+        az_c = np.arange(self.nb_grids[0]) * gs[0] - 180.0 + gs[0] * 0.5
+        el_c = np.arange(self.nb_grids[1]) * gs[1] - 90.0 + gs[1] * 0.5
+        self.az_lb, self.az_ub = az_c - half[0], az_c + half[0]
+        self.el_lb = np.clip(el_c - half[1], -90, 90)
+        self.el_ub = np.clip(el_c + half[1], -90, 90)
+
+    def encode_events(self, frames, classes, az, el):
+        """Vectorised datasets.py:467-480 over E events -> rows (M,6) [frame,Gi,Gj,cls,U,V] (float64).
+
+        Row order matches the reference: event by event, cells in (Gi, Gj) lexicographic order."""
+        az = np.asarray(az, dtype=np.float64).copy()
+        el = np.asarray(el, dtype=np.float64)
+        az[az == 180] = -180.0
+        a = az[:, None]
+        az_ok = ((self.az_lb[None] <= a) & (a < self.az_ub[None])) | (a + 360 < self.az_ub[None]) | \
+                (self.az_lb[None] < a - 360)                               # (E, Gaz)
+        e = el[:, None]
+        el_ok = (self.el_lb[None] <= e) & (e < self.el_ub[None])            # (E, Gel)
+        resp = az_ok[:, :, None] & el_ok[:, None, :]                        # (E, Gaz, Gel)
+        ev, gi, gj = np.nonzero(resp)
+        frames = np.asarray(frames, dtype=np.float64)
+        classes = np.asarray(classes, dtype=np.float64)
+        return np.stack([frames[ev], gi.astype(np.float64), gj.astype(np.float64), classes[ev], az[ev], el[ev]], axis=1)
+
+    def get_yolo_label(self, label: dict, nb_label_frames: int):
+        """Same signature/result as the reference's ``get_yolo_label`` (list of rows)."""
+        fr, cl, az, el = [], [], [], []
+        for frame_idx, events in label.items():
+            if frame_idx < nb_label_frames:
+                for ev in events:
+                    fr.append(frame_idx); cl.append(ev[0]); az.append(ev[2]); el.append(ev[3])
+        if not fr:
+            return []
+        rows = self.encode_events(fr, cl, az, el)
+        return [[int(r[0]), int(r[1]), int(r[2]), r[3], r[4], r[5]] for r in rows.tolist()]
+
+
+def collate_fn(batch):
+    """datasets.py:164-184: list of (feat, label_rows) -> (feat (B,...), target (M,7) float32).
+    Raises, like the reference (torch.cat of an empty list), when no sample has any event."""
+    feats, labels = zip(*batch)
+    parts = []
+    for i, rows in enumerate(labels):
+        if len(rows) == 0:
+            continue
+        r = torch.as_tensor(np.asarray(rows, dtype=np.float32).reshape(len(rows), 6))
+        parts.append(torch.cat([torch.full((len(rows), 1), float(i)), r], dim=-1))
+    if not parts:
+        raise RuntimeError("collate_fn: every sample in the batch has an empty label list")
+    return torch.stack([torch.as_tensor(f) for f in feats], 0), torch.cat(parts, 0)
+
+
+# ------------------------------------------------------------------------------------------- synthetic data
+def synthetic_audio(batch, n_samples, seed=1234, device="cpu"):
+    """int16-range noise ``round(clip(N(0,0.1)) * 32768)`` -> ``/32768 + 1e-8`` (datasets.py:147),
+    layout (B, n_samples, 4) float32 (WAV-native interleaving: one float4 per sample)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    out = torch.empty(batch, n_samples, 4, dtype=torch.float32)
+    for b in range(batch):                      # chunked: keeps host memory bounded at B=64 x 60 s
+        x = torch.randn(n_samples, 4, generator=g) * 0.1
+        pcm = torch.clamp(torch.round(torch.clamp(x, -1.0, 1.0) * 32768.0), -32768, 32767)
+        out[b] = (pcm.double() / 32768.0 + 1e-8).float()
+    return out.to(device)
+
+
+def synthetic_targets(batch, nb_label_frames, nb_classes, seed=1234, encoder=None):
+    """Per sample and label frame k ~ {0:.4, 1:.35, 2:.2, 3:.05} events, class ~ U{0..C-1},
+    az ~ U[-180,180), el ~ U[-60,60]; expanded by the label encoder (about 4 rows per event).
+    -> target (M,7) float32 [b, frame, Gi, Gj, cls, U, V]."""
+    rng = np.random.default_rng(seed)
+    enc = encoder or YoloLabelEncoder()
+    k = rng.choice(4, size=(batch, nb_label_frames), p=[0.4, 0.35, 0.2, 0.05])
+    b_idx, f_idx = np.nonzero(k >= 1)
+    reps = k[b_idx, f_idx]
+    b_ev, f_ev = np.repeat(b_idx, reps), np.repeat(f_idx, reps)
+    n = b_ev.shape[0]
+    cls = rng.integers(0, nb_classes, size=n)
+    az = rng.uniform(-180.0, 180.0, size=n)
+    el = rng.uniform(-60.0, 60.0, size=n)
+    ev_id = np.arange(n)
+    rows = enc.encode_events(ev_id, cls, az, el)            # frame column carries the event id for now
+    ids = rows[:, 0].astype(np.int64)
+    target = np.concatenate([b_ev[ids, None].astype(np.float64), f_ev[ids, None].astype(np.float64), rows[:, 1:]], axis=1)
+    return torch.from_numpy(target.astype(np.float32))

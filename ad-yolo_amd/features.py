@@ -1,0 +1,117 @@
+"""K1 front end: raw 4-channel FOA audio -> 7-channel (log-mel x4 + mel-scale intensity vector x3) features
+on the GPU.  Host-side counterpart of ``FeatureLabelProcessor.get_feature``
+(/root/reference/src/datasets.py:187-207, :252-292): this class only builds the constant tables
+(twiddles, Hann window, sparse mel filter bank -- all in float64 on the host, once) and launches
+``adyolo_feat_stft_mel`` + ``adyolo_feat_finish`` (csrc/features.hip).
+
+The mel filter bank follows librosa==0.8.1 ``filters.mel(sr=24000, n_fft=1200, n_mels=64)`` semantics
+(Slaney scale, Slaney area norm, float32) -- see SURVEY.md Appendix B; librosa itself is not available
+in this image, so the formula is restated here (product code; the oracle has its own copy).
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import _p, _stream
+
+SR = 24000
+N_FFT = 1200
+HOP = 600
+N_MELS = 64
+
+
+def _slaney_hz_to_mel(f):
+    f = np.asarray(f, dtype=np.float64)
+    lin = f / (200.0 / 3)
+    log = 15.0 + np.log(np.maximum(f, 1e-30) / 1000.0) / (np.log(6.4) / 27.0)
+    return np.where(f >= 1000.0, log, lin)
+
+
+def _slaney_mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    return np.where(m >= 15.0, 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0)), m * (200.0 / 3))
+
+
+def slaney_mel_matrix(sr=SR, n_fft=N_FFT, n_mels=N_MELS):
+    """(n_mels, n_fft//2+1) float32 triangular filters, area-normalised."""
+    freqs = np.linspace(0.0, sr / 2.0, n_fft // 2 + 1)
+    edges = _slaney_mel_to_hz(np.linspace(_slaney_hz_to_mel(0.0), _slaney_hz_to_mel(sr / 2.0), n_mels + 2))
+    width = np.diff(edges)
+    up = (freqs[None, :] - edges[:-2, None]) / width[:-1, None]
+    down = (edges[2:, None] - freqs[None, :]) / width[1:, None]
+    tri = np.maximum(0.0, np.minimum(up, down))
+    tri *= (2.0 / (edges[2:] - edges[:-2]))[:, None]
+    return tri.astype(np.float32)
+
+
+class FeatureExtractor:
+    """``FeatureExtractor(scaler, device)(audio)``: audio float32 (B, n_samples, 4) on the GPU, already
+    ``int16 / 32768 + 1e-8`` (datasets.py:147) -> features.
+
+    scaler: dict like the reference's ``scaler_wts.pkl`` ({'MEL'|'IV': {'mean','std'}} with shapes
+    (1,64,4)/(1,64,3)) or None for mean 0 / std 1.
+    """
+
+    def __init__(self, scaler=None, device="cuda:0"):
+        self.device = torch.device(device)
+        n = np.arange(N_FFT, dtype=np.float64)
+        tw = np.stack([np.cos(2.0 * np.pi * n / N_FFT), -np.sin(2.0 * np.pi * n / N_FFT)], axis=1)
+        win = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / N_FFT)
+        mel = slaney_mel_matrix()
+        start, length, offs, weights = [], [], [], []
+        for m in range(N_MELS):
+            nz = np.nonzero(mel[m])[0]
+            s, e = int(nz[0]), int(nz[-1]) + 1
+            start.append(s)
+            length.append(e - s)
+            offs.append(len(weights))
+            weights.extend(mel[m, s:e].tolist())
+        mean = np.zeros((7, N_MELS), dtype=np.float64)
+        std = np.ones((7, N_MELS), dtype=np.float64)
+        if scaler is not None:
+            mean[:4] = np.asarray(scaler["MEL"]["mean"], dtype=np.float64).reshape(N_MELS, 4).T
+            std[:4] = np.asarray(scaler["MEL"]["std"], dtype=np.float64).reshape(N_MELS, 4).T
+            mean[4:] = np.asarray(scaler["IV"]["mean"], dtype=np.float64).reshape(N_MELS, 3).T
+            std[4:] = np.asarray(scaler["IV"]["std"], dtype=np.float64).reshape(N_MELS, 3).T
+        dev = self.device
+        f32 = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev).contiguous()   # noqa: E731
+        i32 = lambda a: torch.tensor(np.asarray(a, dtype=np.int32), device=dev).contiguous()     # noqa: E731
+        self.twiddle, self.window = f32(tw), f32(win)
+        self.mel_start, self.mel_len, self.mel_off = i32(start), i32(length), i32(offs)
+        self.mel_w = f32(weights)
+        self.sc_mean, self.sc_rstd = f32(mean), f32(1.0 / std)
+        self.mel_nnz = len(weights)
+
+    def __call__(self, audio, channels_last8=True):
+        """-> (B, T, 64, 8) float32 channels-last (8th channel zero) when ``channels_last8`` (what the
+        encoder consumes), else (B, 7, T, 64) in the reference's layout (datasets.py:158-160)."""
+        if not audio.is_cuda or audio.dtype != torch.float32 or not audio.is_contiguous():
+            raise _lib.AdyoloHipError("FeatureExtractor needs contiguous float32 audio (B, n_samples, 4) on the GPU")
+        b, n, ch = audio.shape
+        if ch != 4 or n % HOP != 0:
+            raise _lib.AdyoloHipError("audio must be (B, n_samples, 4) with n_samples %% 600 == 0")
+        t = n // HOP
+        layout = 1 if channels_last8 else 0
+        out = torch.empty((b, t, N_MELS, 8) if channels_last8 else (b, 7, t, N_MELS), dtype=torch.float32,
+                          device=audio.device)
+        chan_max = torch.empty(b * 4, dtype=torch.float32, device=audio.device)
+        st = _stream()
+        _lib.call("adyolo_feat_stft_mel", _p(audio), _p(self.twiddle), _p(self.window), _p(self.mel_start),
+                  _p(self.mel_len), _p(self.mel_off), _p(self.mel_w), _p(self.sc_mean), _p(self.sc_rstd), _p(out),
+                  _p(chan_max), b, n, layout, st)
+        _lib.call("adyolo_feat_finish", _p(out), _p(chan_max), _p(self.sc_mean), _p(self.sc_rstd), b, t, layout, st)
+        return out
+
+    @staticmethod
+    def algorithmic_bytes(b, n_samples):
+        """HBM bytes one call must move: read 4ch fp32 audio + write 7 x T x 64 fp32."""
+        return b * (n_samples * 4 * 4 + 7 * (n_samples // HOP) * N_MELS * 4)
+
+
+def load_scaler_npz(path):
+    """Scaler statistics stored as .npz (mel_mean/mel_std (1,64,4), iv_mean/iv_std (1,64,3))."""
+    z = np.load(path)
+    return {"MEL": {"mean": z["mel_mean"], "std": z["mel_std"]}, "IV": {"mean": z["iv_mean"], "std": z["iv_std"]}}

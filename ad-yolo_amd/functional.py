@@ -1,0 +1,266 @@
+"""Block-granular autograd nodes: each forward/backward is a hand-ordered sequence of gfx950 kernel
+launches (ops.py -> libadyolo_hip.so).  torch.autograd only chains the nodes and accumulates the
+parameter gradients, so ``loss.backward()`` works exactly as in the reference's train loop
+(/root/reference/src/train.py:49-55).
+
+Activations are channels-last float32: [N][T][F][C].
+"""
+import torch
+
+from . import ops
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _BNState:
+    """Batch-norm running buffers of one layer (updated in place by the stats kernel)."""
+
+    def __init__(self, mod):
+        self.mod = mod
+
+    def stats(self, x, training):
+        m = self.mod
+        if training:
+            ssum, mean, invstd = ops.bn_stats(x, m.running_mean, m.running_var, m.momentum, m.eps)
+            m.num_batches_tracked += 1
+        else:
+            ssum = None
+            mean, invstd = ops.bn_eval_stats(m.running_mean, m.running_var, m.eps)
+        return ssum, mean, invstd
+
+
+class StemFn(torch.autograd.Function):
+    """conv3x3(7->32, bias) -> ReLU -> BatchNorm   (reference resnet.py:183-185; ReLU before BN)."""
+
+    @staticmethod
+    def forward(ctx, x8, w, b, gamma, beta, bn, training):
+        wpk, _ = ops.pack_w3x3(w, 8, want_dgrad=False)
+        a = ops.conv3x3(x8, wpk, w.shape[0], bias=b, relu=True)
+        _, mean, invstd = _BNState(bn).stats(a, training)
+        scale, shift = ops.bn_scale_shift(gamma, beta, mean, invstd)
+        out = ops.affine(a, scale, shift)
+        ctx.training = training
+        ctx.cin_real = w.shape[1]
+        ctx.save_for_backward(x8, a, gamma, mean, invstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
+        x8, a, gamma, mean, invstd = ctx.saved_tensors
+        da, dgamma, dbeta = ops.bn_bwd(_c(dout), a, gamma, mean, invstd, relu_mask=True)
+        dw = ops.conv3x3_wgrad(x8, da, ctx.cin_real)
+        db = ops.colsum(da.view(-1, da.shape[-1]))
+        return None, dw, db, dgamma, dbeta, None, None
+
+
+class SEBlockFn(torch.autograd.Function):
+    """SEBasicBlock (reference resnet.py:25-47):
+    [AvgPool2d(2,2)] -> conv3x3 -> ReLU -> BN1 -> conv3x3 -> BN2 -> SE -> (+ x | BN(conv1x1(x))) -> ReLU.
+
+    BN2 is never materialised: the SE squeeze comes from the per-sample channel sums the BN statistics
+    pass produces anyway (mean_hw(bn2(c)) = scale*mean_hw(c)+shift) and BN2's affine, the SE scale, the
+    residual add and the ReLU are one fused pass.
+    """
+
+    @staticmethod
+    def forward(ctx, x, training, pool, bns, w1, g1, b1, w2, g2, b2, fw1, fb1, fw2, fb2, wd=None, gd=None, bd=None):
+        bn1, bn2, bnd = bns
+        p = ops.avgpool2(x) if pool else x
+        n, h, w_, cin = p.shape
+        c = w1.shape[0]
+        wpk1, wpk1d = ops.pack_w3x3(w1, cin)
+        a = ops.conv3x3(p, wpk1, c, relu=True)
+        _, mean1, invstd1 = _BNState(bn1).stats(a, training)
+        scale1, shift1 = ops.bn_scale_shift(g1, b1, mean1, invstd1)
+        bb = ops.affine(a, scale1, shift1)
+        wpk2, wpk2d = ops.pack_w3x3(w2, c)
+        cc = ops.conv3x3(bb, wpk2, c)
+        if training:
+            ssum2, mean2, invstd2 = _BNState(bn2).stats(cc, True)
+        else:
+            ssum2, _, _ = ops.bn_stats(cc, None, None)
+            _, mean2, invstd2 = _BNState(bn2).stats(cc, False)
+        scale2, shift2 = ops.bn_scale_shift(g2, b2, mean2, invstd2)
+        pooled, hid, s = ops.se_fc_fwd(ssum2, scale2, shift2, fw1, fb1, fw2, fb2, h * w_)
+        q = None
+        meand = invstdd = None
+        if wd is not None:
+            q = ops.gemm(p, wd, n * h * w_, c, cin, cin, cin).view(n, h, w_, c)
+            _, meand, invstdd = _BNState(bnd).stats(q, training)
+            scaled, shiftd = ops.bn_scale_shift(gd, bd, meand, invstdd)
+            r = ops.affine(q, scaled, shiftd)
+        else:
+            r = p
+        e = ops.se_tail_fwd(cc, r, scale2, shift2, s)
+        ctx.training, ctx.pool, ctx.has_down = training, pool, wd is not None
+        ctx.in_hw = (x.shape[1], x.shape[2])
+        tensors = [p, a, bb, cc, e, g1, mean1, invstd1, g2, b2, mean2, invstd2, ssum2, pooled, hid, s, fw1, fw2,
+                   wpk1d, wpk2d]
+        if wd is not None:
+            tensors += [q, wd, gd, meand, invstdd]
+        ctx.save_for_backward(*tensors)
+        return e
+
+    @staticmethod
+    def backward(ctx, de):
+        if not ctx.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
+        t = ctx.saved_tensors
+        (p, a, bb, cc, e, g1, mean1, invstd1, g2, b2, mean2, invstd2, ssum2, pooled, hid, s, fw1, fw2, wpk1d,
+         wpk2d) = t[:20]
+        n, h, w_, cin = p.shape
+        c = cc.shape[-1]
+        dc, dr, dg2, db2, dfw1, dfb1, dfw2, dfb2 = ops.se_tail_bwd(_c(de), e, cc, g2, b2, mean2, invstd2, ssum2,
+                                                                   pooled, hid, s, fw1, fw2)
+        dw2 = ops.conv3x3_wgrad(bb, dc, c)
+        dbb = ops.conv3x3(dc, wpk2d, c)
+        da, dg1, db1 = ops.bn_bwd(dbb, a, g1, mean1, invstd1, relu_mask=True)
+        dw1 = ops.conv3x3_wgrad(p, da, cin)
+        dwd = dgd = dbd = None
+        if ctx.has_down:
+            q, wd, gd, meand, invstdd = t[20:25]
+            dq, dgd, dbd = ops.bn_bwd(dr, q, gd, meand, invstdd, relu_mask=False)
+            rows = n * h * w_
+            splits = max(1, min(64, rows // 4096))
+            dwd = ops.gemm(dq, p, c, cin, rows, c, cin, trans_a=True, trans_b=True, splits=splits).view(c, cin, 1, 1)
+            dp_res = ops.gemm(dq, wd, rows, cin, c, c, cin, trans_b=True).view(n, h, w_, cin)
+            dp = ops.conv3x3(da, wpk1d, cin, addend=dp_res)
+        else:
+            dp = ops.conv3x3(da, wpk1d, cin, addend=dr)
+        dx = ops.avgpool2_bwd(dp, ctx.in_hw[0], ctx.in_hw[1]) if ctx.pool else dp
+        return (dx, None, None, None, dw1, dg1, db1, dw2, dg2, db2, dfw1, dfb1, dfw2, dfb2, dwd, dgd, dbd)
+
+
+class SAPFn(torch.autograd.Function):
+    """SelfAttentionPooling over the F axis (reference resnet.py:115-123): x [B][T][F][C] -> [B][T][C]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        bsz, t, f, c = x.shape
+        y, attn = ops.sap_fwd(x.view(bsz * t, f, c), w.view(-1), b)
+        ctx.save_for_backward(x, w, attn)
+        return y.view(bsz, t, c)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, attn = ctx.saved_tensors
+        bsz, t, f, c = x.shape
+        dx, dw, db = ops.sap_bwd(_c(dy).view(bsz * t, c), x.view(bsz * t, f, c), w.view(-1), attn)
+        return dx.view(bsz, t, f, c), dw.view_as(w), db
+
+
+class BiGRULayerFn(torch.autograd.Function):
+    """One bidirectional GRU layer, hidden 128 (half of nn.GRU(num_layers=2) at reference resnet.py:153)."""
+
+    @staticmethod
+    def forward(ctx, x, wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r, save):
+        bsz, t, cin = x.shape
+        rows = bsz * t
+        x2 = x.view(rows, cin)
+        gx = torch.empty(rows, 768, dtype=torch.float32, device=x.device)
+        ops.gemm(x2, wih_f, rows, 384, cin, cin, cin, bias=bih_f, out=gx, ldc=768)
+        ops.gemm(x2, wih_r, rows, 384, cin, cin, cin, bias=bih_r, out=gx[:, 384:], ldc=768)
+        whh = torch.stack([whh_f, whh_r], 0).contiguous()
+        bhh = torch.stack([bhh_f, bhh_r], 0).contiguous()
+        out, gates, hprev = ops.gru_fwd(gx.view(bsz, t, 2, 384), whh, bhh, save)
+        if save:
+            ctx.save_for_backward(x, wih_f, wih_r, whh, gates, hprev)
+        ctx.saved = save
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.saved:
+            raise NotImplementedError("GRU backward needs the training-mode forward (gates were not saved)")
+        x, wih_f, wih_r, whh, gates, hprev = ctx.saved_tensors
+        bsz, t, cin = x.shape
+        rows = bsz * t
+        x2 = x.view(rows, cin)
+        dgx, dgh = ops.gru_bwd(_c(dout), gates, hprev, whh)
+        dgx2, dgh2, hp2 = dgx.view(rows, 768), dgh.view(rows, 768), hprev.view(rows, 256)
+        splits = max(1, min(64, rows // 2048))
+        grads = []
+        dx = torch.empty_like(x2)
+        for d, wih in enumerate((wih_f, wih_r)):
+            gxd, ghd, hpd = dgx2[:, d * 384:], dgh2[:, d * 384:], hp2[:, d * 128:]
+            dwih = ops.gemm(gxd, x2, 384, cin, rows, 768, cin, trans_a=True, trans_b=True, splits=splits)
+            dwhh = ops.gemm(ghd, hpd, 384, 128, rows, 768, 256, trans_a=True, trans_b=True, splits=splits)
+            dbih = ops.colsum(gxd[:, :384])
+            dbhh = ops.colsum(ghd[:, :384])
+            ops.gemm(gxd, wih, rows, cin, 384, 768, cin, trans_b=True, out=dx, ldc=cin, accumulate=(d == 1))
+            grads += [dwih, dwhh, dbih, dbhh]
+        return (dx.view(bsz, t, cin), *grads, None)
+
+
+class LNTanhFn(torch.autograd.Function):
+    """tanh(LayerNorm(x))  (reference resnet.py:196-197)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        c = x.shape[-1]
+        y = ops.ln_tanh_fwd(x.view(-1, c), gamma, beta, eps)
+        ctx.eps = eps
+        ctx.save_for_backward(x, y, gamma)
+        return y.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma = ctx.saved_tensors
+        c = x.shape[-1]
+        dx, dgamma, dbeta = ops.ln_tanh_bwd(_c(dy).view(-1, c), x.view(-1, c), y, gamma, ctx.eps)
+        return dx.view_as(x), dgamma, dbeta, None
+
+
+class LinearFn(torch.autograd.Function):
+    """nn.Linear on the last axis (reference linearheads.py:95-98)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        k = x.shape[-1]
+        y = ops.linear(x.view(-1, k), w, b)
+        ctx.save_for_backward(x, w)
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        k = x.shape[-1]
+        dx, dw, db = ops.linear_bwd(x.view(-1, k), w, _c(dy).view(-1, w.shape[0]), need_dx=ctx.needs_input_grad[0])
+        return (dx.view_as(x) if dx is not None else None), dw, db
+
+
+class DropoutFn(torch.autograd.Function):
+    """Inter-layer GRU dropout (p = 0.3, training only): y = x * mask, mask in {0, 1/(1-p)}."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        return ops.mul(x, mask)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        return ops.mul(_c(dy), mask), None
+
+
+class ADYOLOLossFn(torch.autograd.Function):
+    """AD-YOLO loss (reference loss.py:189-251); the gradient w.r.t. the logits is produced by the same
+    launch that computes the loss and only rescaled by the incoming gradient in backward."""
+
+    @staticmethod
+    def forward(ctx, logit, target, cfg):
+        loss, dlogit, _ = ops.adyolo_loss(logit, target, cfg["nb_classes"], cfg["grid"], cfg["anchors"], cfg["thr"],
+                                          cfg["gains"], cfg["grid_size"], cfg["g_overlap"],
+                                          need_grad=ctx.needs_input_grad[0])
+        if dlogit is not None:
+            ctx.save_for_backward(dlogit)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dlogit,) = ctx.saved_tensors
+        return ops.scale_dev(dlogit, _c(dloss).view(1)), None, None

@@ -1,0 +1,184 @@
+"""SE-ResNet34 + self-attention pooling + BiGRU encoder on hand-written gfx950 kernels.
+
+Host-side mirror of the reference plugin ``SEResnet34`` (/root/reference/src/models/backbones/resnet.py:126-199):
+same constructor ``(in_feat_shape, out_shape, params)``, same ``enc_out_dim`` attribute, same
+``forward(x (B,7,T,F)) -> (B, T//4, 256)`` and -- because checkpoints are loaded with ``strict=True``
+(reference train.py:148, test.py:90) -- the same ``state_dict`` keys and shapes (301 entries).
+The modules below only HOLD parameters/buffers under the reference names; all arithmetic is in
+``functional.py`` (autograd nodes) -> ``ops.py`` -> ``libadyolo_hip.so``.  There is no CPU path.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from ... import functional as Fn
+from ... import ops
+
+LAYERS = (3, 4, 6, 3)
+WIDTHS = (32, 64, 128, 256)
+
+
+def _uniform_(t, bound):
+    return nn.init.uniform_(t, -bound, bound)
+
+
+class ConvParams(nn.Module):
+    """weight (Cout,Cin,k,k) [+ bias]; initialised like nn.Conv2d (kaiming_uniform(a=sqrt(5)))."""
+
+    def __init__(self, cin, cout, k, bias):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(cout))
+            _uniform_(self.bias, 1.0 / math.sqrt(cin * k * k))
+        else:
+            self.register_parameter("bias", None)
+
+
+class LinearParams(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        self.bias = nn.Parameter(torch.empty(cout))
+        _uniform_(self.bias, 1.0 / math.sqrt(cin))
+
+
+class BatchNormParams(nn.Module):
+    momentum = 0.1
+    eps = 1e-5
+
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class SEParams(nn.Module):
+    """keys se.fc.0.{weight,bias}, se.fc.2.{weight,bias} (reference resnet.py:95-100)."""
+
+    def __init__(self, c, reduction=8):
+        super().__init__()
+        self.fc = nn.ModuleDict({"0": LinearParams(c, c // reduction), "2": LinearParams(c // reduction, c)})
+
+
+class SEBasicBlock(nn.Module):
+    def __init__(self, inplanes, planes, downsample, pool):
+        super().__init__()
+        self.pool = pool is not None
+        self.conv1 = ConvParams(inplanes, planes, 3, bias=False)
+        self.bn1 = BatchNormParams(planes)
+        self.conv2 = ConvParams(planes, planes, 3, bias=False)
+        self.bn2 = BatchNormParams(planes)
+        self.se = SEParams(planes)
+        if downsample:
+            self.downsample = downsample
+        else:
+            self.downsample = None
+
+    def forward(self, x):
+        fc0, fc2 = self.se.fc["0"], self.se.fc["2"]
+        args = [x, self.training, self.pool,
+                (self.bn1, self.bn2, self.downsample["1"] if self.downsample is not None else None),
+                self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight, self.bn2.weight, self.bn2.bias,
+                fc0.weight, fc0.bias, fc2.weight, fc2.bias]
+        if self.downsample is not None:
+            args += [self.downsample["0"].weight, self.downsample["1"].weight, self.downsample["1"].bias]
+        return Fn.SEBlockFn.apply(*args)
+
+
+class AttentionParams(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.W = LinearParams(c, 1)
+
+
+class GRUParams(nn.Module):
+    """Parameter names of nn.GRU(256, 128, num_layers=2, bidirectional=True) (attribute ``lstm`` upstream)."""
+
+    dropout = 0.3
+
+    def __init__(self, cin=256, hidden=128, layers=2):
+        super().__init__()
+        bound = 1.0 / math.sqrt(hidden)
+        for layer in range(layers):
+            lin = cin if layer == 0 else 2 * hidden
+            for sfx in ("", "_reverse"):
+                for name, shape in (("weight_ih", (3 * hidden, lin)), ("weight_hh", (3 * hidden, hidden)),
+                                    ("bias_ih", (3 * hidden,)), ("bias_hh", (3 * hidden,))):
+                    prm = nn.Parameter(torch.empty(*shape))
+                    _uniform_(prm, bound)
+                    setattr(self, "%s_l%d%s" % (name, layer, sfx), prm)
+
+    def layer_params(self, layer):
+        names = ("weight_ih", "weight_hh", "bias_ih", "bias_hh")
+        return [getattr(self, "%s_l%d%s" % (n, layer, sfx)) for sfx in ("", "_reverse") for n in names]
+
+
+class LayerNormParams(nn.Module):
+    eps = 1e-5
+
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+
+class SEResnet34(nn.Module):
+    def __init__(self, in_feat_shape, out_shape, params):
+        super().__init__()
+        n_in = in_feat_shape[1]
+        self.nb_classes = params["data_config"]["nb_classes"]
+        self.enc_out_dim = WIDTHS[-1]
+        self.in_channels = n_in
+        self.conv1 = ConvParams(n_in, WIDTHS[0], 3, bias=True)
+        self.bn1 = BatchNormParams(WIDTHS[0])
+        inpl = WIDTHS[0]
+        for li, (nblk, planes, pool) in enumerate(zip(LAYERS, WIDTHS, (None, 2, 2, None)), start=1):
+            down = None
+            if inpl != planes:          # created before the block, like _make_layer (resnet.py:157-164)
+                down = nn.ModuleDict({"0": ConvParams(inpl, planes, 1, bias=False), "1": BatchNormParams(planes)})
+            blocks = [SEBasicBlock(inpl, planes, down, pool)]
+            inpl = planes
+            blocks += [SEBasicBlock(inpl, planes, None, None) for _ in range(1, nblk)]
+            setattr(self, "layer%d" % li, nn.ModuleList(blocks))
+        self.attention = AttentionParams(WIDTHS[-1])
+        self.lstm = GRUParams(WIDTHS[-1], WIDTHS[-1] // 2, 2)
+        self.norm = LayerNormParams(WIDTHS[-1])
+        # dropout stream of the inter-layer GRU dropout (counter based: seed, running offset)
+        self.dropout_seed = 0x5EED
+        self._dropout_offset = 0
+        self.dropout_mask_override = None       # tests inject a (B,T',256) mask here
+
+    def _dropout(self, y):
+        p = self.lstm.dropout
+        if not self.training or p <= 0.0:
+            return y
+        if self.dropout_mask_override is not None:
+            mask = self.dropout_mask_override.to(y.device, torch.float32).contiguous()
+        else:
+            mask = ops.dropout_mask(y, p, self.dropout_seed, self._dropout_offset)
+            self._dropout_offset += y.numel()
+        return Fn.DropoutFn.apply(y, mask)
+
+    def forward(self, x, channels_last8=False):
+        """x: (B, 7, T, F) float32 on the GPU (reference layout), or (B, T, F, 8) when ``channels_last8``."""
+        if not x.is_cuda:
+            raise RuntimeError("SEResnet34 (adyolo_amd) runs on MI355X only; move the model/input to a HIP device")
+        x8 = x if channels_last8 else ops.nchw_to_nhwc8(x.contiguous().float())
+        y = Fn.StemFn.apply(x8, self.conv1.weight, self.conv1.bias, self.bn1.weight, self.bn1.bias, self.bn1,
+                            self.training)
+        for li in range(1, 5):
+            for blk in getattr(self, "layer%d" % li):
+                y = blk(y)
+        y = Fn.SAPFn.apply(y, self.attention.W.weight, self.attention.W.bias)
+        save = self.training and torch.is_grad_enabled()
+        y = Fn.BiGRULayerFn.apply(y, *self.lstm.layer_params(0), save)
+        y = self._dropout(y)
+        y = Fn.BiGRULayerFn.apply(y, *self.lstm.layer_params(1), save)
+        return Fn.LNTanhFn.apply(y, self.norm.weight, self.norm.bias, self.norm.eps)

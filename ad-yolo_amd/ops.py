@@ -1,0 +1,356 @@
+"""Tensor-level wrappers over the C ABI (include/adyolo_hip.h).
+
+PyTorch is used here only as plumbing: device memory (caching allocator), the current HIP stream and,
+in ``dist.py``, torch.distributed/RCCL.  Every function launches hand-written gfx950 kernels through
+``libadyolo_hip.so``; nothing in this module computes with ATen ops.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_c = _lib.call
+NULL = ctypes.c_void_p(0)
+
+
+def _p(t):
+    if t is None:
+        return NULL
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.AdyoloHipError("adyolo ops need tensors on a HIP device (got %s); there is no CPU path" % t.device)
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise _lib.AdyoloHipError("adyolo ops need contiguous float32 tensors (got %s, contiguous=%s)"
+                                      % (t.dtype, t.is_contiguous()))
+
+
+def _new(like, *shape):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def _zeros(like, *shape):
+    return torch.zeros(shape, dtype=torch.float32, device=like.device)
+
+
+# ---------------------------------------------------------------------------------------------- conv
+def pack_w3x3(w, cin_pad, want_dgrad=True):
+    """w [Cout][Cin][3][3] -> (wpk_fwd [Cout][9][cin_pad], wpk_dgrad [cin_pad][9][Cout] or None)."""
+    _chk(w)
+    cout, cin = w.shape[0], w.shape[1]
+    wf = _new(w, cout, 9, cin_pad)
+    wd = _new(w, cin_pad, 9, cout) if want_dgrad else None
+    _c("adyolo_pack_w3x3", _p(w), _p(wf), _p(wd), cout, cin, cin_pad, _stream())
+    return wf, wd
+
+
+def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False):
+    """x [N][H][W][Cin] -> [N][H][W][cout];  wpk [cout][9][Cin]."""
+    _chk(x, wpk, bias, addend)
+    n, h, w, cin = x.shape
+    y = _new(x, n, h, w, cout)
+    _c("adyolo_conv3x3_fwd", _p(x), _p(wpk), _p(bias), _p(addend), _p(y), n, h, w, cin, cout, int(relu), _stream())
+    return y
+
+
+def conv3x3_wgrad(x, dy, cin_real):
+    """x [N][H][W][Cin], dy [N][H][W][Cout] -> dw [Cout][cin_real][3][3]."""
+    _chk(x, dy)
+    n, h, w, cin = x.shape
+    cout = dy.shape[3]
+    nslab = _lib.load().adyolo_conv3x3_wgrad_slabs(n, h, w, cin, cout)
+    if nslab <= 0:
+        raise _lib.AdyoloHipError("conv3x3_wgrad_slabs rejected the shape")
+    cinp = ((cin + 31) // 32) * 32
+    slabs = _new(x, nslab, cout, 9, cinp)
+    dw = _new(x, cout, cin_real, 3, 3)
+    _c("adyolo_conv3x3_wgrad", _p(x), _p(dy), _p(slabs), _p(dw), n, h, w, cin, cin_real, cout, _stream())
+    return dw
+
+
+# ---------------------------------------------------------------------------------------------- gemm
+def gemm(a, b, m, n, k, lda, ldb, trans_a=False, trans_b=False, bias=None, out=None, ldc=None, accumulate=False,
+         splits=1):
+    """C[m][n] = sum_k opA(m,k) opB(n,k) (+bias).  ``a``/``b``/``out`` may be views with an offset."""
+    if ldc is None:
+        ldc = n
+    if out is None:
+        out = _new(a, m, n)
+        ldc = n
+    slabs = None
+    if splits > 1:
+        slabs = _new(a, splits, m, n)
+    _c("adyolo_gemm", _p(a), _p(b), _p(bias), _p(out), _p(slabs), m, n, k, lda, ldb, ldc, int(trans_a), int(trans_b),
+       splits, int(accumulate), _stream())
+    return out
+
+
+def linear(x2d, w, bias=None):
+    """x2d [R][K] @ w[N][K]^T + bias."""
+    _chk(x2d, w, bias)
+    r, k = x2d.shape
+    return gemm(x2d, w, r, w.shape[0], k, k, k, bias=bias)
+
+
+def linear_bwd(x2d, w, dy2d, need_dx=True):
+    """-> dx [R][K], dw [N][K], db [N]."""
+    _chk(x2d, w, dy2d)
+    r, k = x2d.shape
+    n = w.shape[0]
+    dx = gemm(dy2d, w, r, k, n, n, k, trans_b=True) if need_dx else None
+    splits = max(1, min(64, r // 2048))
+    dw = gemm(dy2d, x2d, n, k, r, n, k, trans_a=True, trans_b=True, splits=splits)
+    db = colsum(dy2d)
+    return dx, dw, db
+
+
+def colsum(a2d, out=None, accumulate=False):
+    r, c = a2d.shape
+    if out is None:
+        out = _new(a2d, c)
+        accumulate = False
+    partial = _new(a2d, 256, c)
+    _c("adyolo_colsum", _p(a2d), _p(out), _p(partial), r, c, a2d.stride(0), int(accumulate), _stream())
+    return out
+
+
+def add(a, b):
+    _chk(a, b)
+    y = torch.empty_like(a)
+    _c("adyolo_add", _p(a), _p(b), _p(y), a.numel(), _stream())
+    return y
+
+
+def scale_dev(a, scalar_dev):
+    """a * scalar_dev[0], the scalar staying on the device (no host sync)."""
+    _chk(a, scalar_dev)
+    y = torch.empty_like(a)
+    _c("adyolo_scale_dev", _p(a), _p(scalar_dev), _p(y), a.numel(), _stream())
+    return y
+
+
+def mul(a, b):
+    _chk(a, b)
+    y = torch.empty_like(a)
+    _c("adyolo_mul", _p(a), _p(b), _p(y), a.numel(), _stream())
+    return y
+
+
+# ---------------------------------------------------------------------------------------------- norm
+def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    """x [N][H][W][C] -> per-sample sums [N][C], mean [C], invstd [C]; updates running stats in place."""
+    _chk(x, running_mean, running_var)
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    ssum, mean, invstd = _new(x, n, c), _new(x, c), _new(x, c)
+    partial = _new(x, 2 * 1024 * c)
+    _c("adyolo_bn_stats", _p(x), _p(ssum), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(partial), n,
+       hw, c, momentum, eps, _stream())
+    return ssum, mean, invstd
+
+
+def bn_eval_stats(running_mean, running_var, eps=1e-5):
+    _chk(running_mean, running_var)
+    c = running_mean.numel()
+    mean, invstd = _new(running_mean, c), _new(running_mean, c)
+    _c("adyolo_bn_eval_stats", _p(running_mean), _p(running_var), _p(mean), _p(invstd), c, eps, _stream())
+    return mean, invstd
+
+
+def bn_scale_shift(gamma, beta, mean, invstd):
+    _chk(gamma, beta, mean, invstd)
+    c = gamma.numel()
+    scale, shift = _new(gamma, c), _new(gamma, c)
+    _c("adyolo_bn_scale_shift", _p(gamma), _p(beta), _p(mean), _p(invstd), _p(scale), _p(shift), c, _stream())
+    return scale, shift
+
+
+def affine(x, scale, shift):
+    _chk(x, scale, shift)
+    c = x.shape[-1]
+    y = torch.empty_like(x)
+    _c("adyolo_affine_nhwc", _p(x), _p(scale), _p(shift), _p(y), x.numel() // c, c, _stream())
+    return y
+
+
+def bn_bwd(dy, x, gamma, mean, invstd, relu_mask=False):
+    """-> dx, dgamma, dbeta.  relu_mask: additionally multiply dx by (x > 0) (x is a ReLU output)."""
+    _chk(dy, x, gamma, mean, invstd)
+    c = x.shape[-1]
+    rows = x.numel() // c
+    sdy, sdyx = _new(x, c), _new(x, c)
+    partial = _new(x, 2 * 1024 * c)
+    _c("adyolo_bn_bwd_reduce", _p(dy), _p(x), _p(mean), _p(invstd), _p(sdy), _p(sdyx), _p(partial), rows, c, _stream())
+    dx = torch.empty_like(x)
+    _c("adyolo_bn_bwd_apply", _p(dy), _p(x), _p(gamma), _p(mean), _p(invstd), _p(sdy), _p(sdyx), _p(dx), NULL, NULL,
+       rows, c, int(relu_mask), _stream())
+    return dx, sdyx, sdy
+
+
+def se_fc_fwd(ssum, scale, shift, w1, b1, w2, b2, hw):
+    _chk(ssum, scale, shift, w1, b1, w2, b2)
+    n, c = ssum.shape
+    cr = w1.shape[0]
+    pooled, hid, s = _new(ssum, n, c), _new(ssum, n, cr), _new(ssum, n, c)
+    _c("adyolo_se_fc_fwd", _p(ssum), _p(scale), _p(shift), _p(w1), _p(b1), _p(w2), _p(b2), _p(pooled), _p(hid), _p(s),
+       n, hw, c, cr, _stream())
+    return pooled, hid, s
+
+
+def se_tail_fwd(c_t, r_t, scale, shift, s):
+    _chk(c_t, r_t, scale, shift, s)
+    n, ch = c_t.shape[0], c_t.shape[-1]
+    hw = c_t.numel() // (n * ch)
+    e = torch.empty_like(c_t)
+    _c("adyolo_se_tail_fwd", _p(c_t), _p(r_t), _p(scale), _p(shift), _p(s), _p(e), n, hw, ch, _stream())
+    return e
+
+
+def se_tail_bwd(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1, w2):
+    """Backward of  e = relu(bn2(c) * s + r)  incl. the SE FCs.
+    -> dc, dr, dgamma, dbeta, dw1, db1, dw2, db2"""
+    _chk(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1, w2)
+    n, ch = c_t.shape[0], c_t.shape[-1]
+    hw = c_t.numel() // (n * ch)
+    cr = w1.shape[0]
+    sg, sgx = _new(c_t, n, ch), _new(c_t, n, ch)
+    partial = _new(c_t, 2 * 1024 * ch)
+    _c("adyolo_se_tail_bwd_reduce", _p(de), _p(e), _p(c_t), _p(mean), _p(invstd), _p(sg), _p(sgx), _p(partial), n, hw,
+       ch, _stream())
+    dw1, db1 = _zeros(c_t, cr, ch), _zeros(c_t, cr)
+    dw2, db2 = _zeros(c_t, ch, cr), _zeros(c_t, ch)
+    dgamma, dbeta = _zeros(c_t, ch), _zeros(c_t, ch)
+    dpool, sdd, sddx = _new(c_t, n, ch), _new(c_t, ch), _new(c_t, ch)
+    _c("adyolo_se_fc_bwd", _p(sg), _p(sgx), _p(ssum), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(pooled), _p(hid),
+       _p(s), _p(w1), _p(w2), _p(dw1), _p(db1), _p(dw2), _p(db2), _p(dpool), _p(sdd), _p(sddx), _p(dgamma), _p(dbeta),
+       n, hw, ch, cr, _stream())
+    dc, dr = torch.empty_like(c_t), torch.empty_like(c_t)
+    _c("adyolo_se_tail_bwd_apply", _p(de), _p(e), _p(c_t), _p(gamma), _p(mean), _p(invstd), _p(s), _p(dpool), _p(sdd),
+       _p(sddx), _p(dc), _p(dr), n, hw, ch, _stream())
+    return dc, dr, dgamma, dbeta, dw1, db1, dw2, db2
+
+
+def avgpool2(x):
+    _chk(x)
+    n, h, w, c = x.shape
+    y = _new(x, n, h // 2, w // 2, c)
+    _c("adyolo_avgpool2_fwd", _p(x), _p(y), n, h, w, c, _stream())
+    return y
+
+
+def avgpool2_bwd(dy, h, w):
+    _chk(dy)
+    n, c = dy.shape[0], dy.shape[3]
+    dx = _new(dy, n, h, w, c)
+    _c("adyolo_avgpool2_bwd", _p(dy), _p(dx), n, h, w, c, _stream())
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------- sequence
+def sap_fwd(x, w, b):
+    """x [R][F][256] -> y [R][256], attn [R][F]."""
+    _chk(x, w, b)
+    r, f, c = x.shape
+    y, attn = _new(x, r, c), _new(x, r, f)
+    _c("adyolo_sap_fwd", _p(x), _p(w), _p(b), _p(y), _p(attn), r, f, c, _stream())
+    return y, attn
+
+
+def sap_bwd(dy, x, w, attn):
+    _chk(dy, x, w, attn)
+    r, f, c = x.shape
+    dx = torch.empty_like(x)
+    dw, db = _zeros(x, c), _zeros(x, 1)
+    partial = _new(x, 1024 * 260)
+    _c("adyolo_sap_bwd", _p(dy), _p(x), _p(w), _p(attn), _p(dx), _p(dw), _p(db), _p(partial), r, f, c, _stream())
+    return dx, dw, db
+
+
+def gru_fwd(gx, whh, bhh, save):
+    """gx [B][T][2][384], whh [2][384][128], bhh [2][384] -> out [B][T][256] (+ gates, hprev when ``save``)."""
+    _chk(gx, whh, bhh)
+    b, t = gx.shape[0], gx.shape[1]
+    out = _new(gx, b, t, 256)
+    gates = _new(gx, b, t, 2, 4, 128) if save else None
+    hprev = _new(gx, b, t, 2, 128) if save else None
+    _c("adyolo_gru_fwd", _p(gx), _p(whh), _p(bhh), _p(out), _p(gates), _p(hprev), b, t, _stream())
+    return out, gates, hprev
+
+
+def gru_bwd(dout, gates, hprev, whh):
+    _chk(dout, gates, hprev, whh)
+    b, t = dout.shape[0], dout.shape[1]
+    dgx, dgh = _new(dout, b, t, 2, 384), _new(dout, b, t, 2, 384)
+    _c("adyolo_gru_bwd", _p(dout), _p(gates), _p(hprev), _p(whh), _p(dgx), _p(dgh), b, t, _stream())
+    return dgx, dgh
+
+
+def ln_tanh_fwd(x2d, gamma, beta, eps=1e-5):
+    _chk(x2d, gamma, beta)
+    r, c = x2d.shape
+    y = torch.empty_like(x2d)
+    _c("adyolo_ln_tanh_fwd", _p(x2d), _p(gamma), _p(beta), _p(y), r, c, eps, _stream())
+    return y
+
+
+def ln_tanh_bwd(dy2d, x2d, y2d, gamma, eps=1e-5):
+    _chk(dy2d, x2d, y2d, gamma)
+    r, c = x2d.shape
+    dx = torch.empty_like(x2d)
+    dgamma, dbeta = _zeros(x2d, c), _zeros(x2d, c)
+    partial = _new(x2d, 1024 * 512)
+    _c("adyolo_ln_tanh_bwd", _p(dy2d), _p(x2d), _p(y2d), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), _p(partial), r, c,
+       eps, _stream())
+    return dx, dgamma, dbeta
+
+
+def dropout_mask(like, p, seed, offset):
+    mask = torch.empty_like(like)
+    _c("adyolo_dropout_mask", _p(mask), mask.numel(), float(p), ctypes.c_uint64(seed), ctypes.c_uint64(offset), _stream())
+    return mask
+
+
+# ---------------------------------------------------------------------------------------------- loss / optim
+def adyolo_loss(logit, target, nb_classes, grid=(8, 4), anchors=5, thr=(45.0, 25.0, 10.0),
+                gains=(5.0, 1.0, 5.0, 3.0), grid_size=(45.0, 45.0), g_overlap=0.5, need_grad=True, grad_scale=1.0,
+                want_dist=False):
+    """logit [B][T][G*A*(C+3)], target [M][7] (device) -> loss (1,), dlogit (or None), dist (or None)."""
+    _chk(logit, target)
+    b, t = logit.shape[0], logit.shape[1]
+    m = target.shape[0]
+    words = _lib.load().adyolo_loss_workspace_words(b * t, grid[0] * grid[1], anchors, m)
+    ws = _new(logit, words)
+    loss = _new(logit, 1)
+    dlogit = torch.empty_like(logit) if need_grad else None
+    dist = _new(logit, m, anchors) if want_dist else None
+    thr_h = (ctypes.c_float * 3)(*[float(v) for v in thr])
+    gains_h = (ctypes.c_float * 4)(*[float(v) for v in gains])
+    _c("adyolo_loss_fwd_bwd", _p(logit), _p(target), _p(ws), _p(loss), _p(dlogit), _p(dist), b, t, grid[0], grid[1],
+       anchors, nb_classes, m, ctypes.cast(thr_h, ctypes.c_void_p), ctypes.cast(gains_h, ctypes.c_void_p),
+       float(grid_size[0]), float(grid_size[1]), float(g_overlap), float(grad_scale), _stream())
+    return loss, dlogit, dist
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+              grad_scale=1.0):
+    _chk(param, grad, exp_avg, exp_avg_sq)
+    _c("adyolo_adam_step", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, betas[0], betas[1],
+       eps, weight_decay, int(step), grad_scale, _stream())
+
+
+def nchw_to_nhwc8(x):
+    _chk(x)
+    b, c, h, w = x.shape
+    y = _new(x, b, h, w, 8)
+    _c("adyolo_nchw_to_nhwc8", _p(x), _p(y), b, c, h, w, _stream())
+    return y

@@ -1,0 +1,87 @@
+"""Train step of the AD-YOLO hot path: features (K1) -> encoder+head forward -> AD-YOLO loss ->
+backward -> [bucketed RCCL all-reduce] -> fused Adam.  Mirror of ``get_optimizers`` / ``train_one_epoch``
+(/root/reference/src/train.py:29-62) with the data-parallel layer the reference lacks.
+
+FusedAdam keeps torch.optim.Adam's hyper-parameters and produces a ``state_dict`` in the stock Adam
+format (train.py:149,236 save/restore it) while running one HIP launch over the flat parameter buffer.
+"""
+import torch
+
+from . import ops
+from .dist import BucketedAllReduce, FlatParameters
+
+
+class FusedAdam:
+    """Adam over a FlatParameters buffer (csrc/optim.hip); lr 1e-3, betas (0.9,0.999), eps 1e-8, wd 0 by
+    default like the reference config (src/configs/hyp_train.yaml:7-9)."""
+
+    def __init__(self, flat: FlatParameters, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.flat = flat
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros_like(flat.flat)
+        self.exp_avg_sq = torch.zeros_like(flat.flat)
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()
+
+    def step(self, grad_scale=1.0):
+        self.step_count += 1
+        ops.adam_step(self.flat.flat, self.flat.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
+                      self.betas, self.eps, self.weight_decay, grad_scale)
+
+    def state_dict(self):
+        """torch.optim.Adam-format state (parameter index = position in ``flat.params`` order reversed back to
+        module.parameters() order is NOT attempted: indices follow ``flat.params``)."""
+        state = {}
+        for i, (off, n) in enumerate(self.flat.offsets):
+            shape = self.flat.params[i].shape
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.exp_avg[off:off + n].view(shape).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + n].view(shape).clone()}
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "params": list(range(len(self.flat.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+        for i, (off, n) in enumerate(self.flat.offsets):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            self.step_count = int(st["step"])
+
+
+def get_optimizers(params: dict, flat: FlatParameters):
+    """reference train.py:29-37 (only Adam is on the gfx950 path)."""
+    tc = params["train_config"]
+    if tc.get("optim", "Adam") == "Adam":
+        return FusedAdam(flat, lr=tc.get("lr", 1e-3), weight_decay=tc.get("weight_decay", 0.0))
+    raise NotImplementedError(tc["optim"])
+
+
+class TrainStep:
+    """One data-parallel optimisation step on raw audio.
+
+    step(audio (B, n_samples, 4) float32 on the GPU, target (M,7)) -> loss tensor (1,) on the device (no host sync).
+    """
+
+    def __init__(self, model, criterion, feature_extractor, params=None, n_buckets=4, lr=1e-3):
+        self.model, self.criterion, self.features = model, criterion, feature_extractor
+        self.flat = FlatParameters(model)
+        self.optimizer = get_optimizers(params, self.flat) if params is not None else FusedAdam(self.flat, lr=lr)
+        self.reducer = BucketedAllReduce(self.flat, n_buckets=n_buckets)
+
+    def step(self, audio, target):
+        self.model.train()
+        feat = self.features(audio, channels_last8=True)
+        output = self.model(feat, channels_last8=True)
+        self.optimizer.zero_grad()
+        loss = self.criterion(output, target)
+        loss.backward()
+        scale = self.reducer.finish()
+        self.optimizer.step(grad_scale=scale)
+        return loss.detach()

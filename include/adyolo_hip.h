@@ -1,0 +1,218 @@
+/*
+ * adyolo_hip.h -- C ABI of libadyolo_hip.so: the MI355X (gfx950) hot path of AD-YOLO.
+ *
+ * The reference (sadPororo/AD-YOLO) has NO FFI: its plugin boundary is Python class dispatch
+ * (src/wrapper.py:26-50, :70-85) and every arithmetic step is an implicit ATen / NumPy / librosa
+ * call.  This header is therefore the boundary the build defines: each entry point replaces the
+ * implicit library call(s) cited next to it.  All pointers are DEVICE pointers (HBM) unless a name
+ * ends in _host; sizes are plain ints; `stream` is a hipStream_t passed as void* (NULL = default
+ * stream).  Activations are float32, channels-last:  x[n][h][w][c]  with h = time frame, w = mel bin.
+ * Every function returns 0 on success, a negative ADYOLO_E* code on bad arguments, or a positive
+ * hipError_t; adyolo_last_error() returns a static description of the last failure on this thread.
+ * No function allocates device memory or synchronises the device: workspaces are passed in.
+ */
+#ifndef ADYOLO_HIP_H
+#define ADYOLO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADYOLO_ABI_VERSION 1
+#define ADYOLO_EINVAL (-1)   /* bad shape / alignment / null pointer */
+#define ADYOLO_ENOSUP (-2)   /* shape outside what the kernels are built for */
+
+int         adyolo_abi_version(void);
+const char *adyolo_last_error(void);
+/* number of float32 words a workspace must hold, for the calls that take one */
+
+/* ------------------------------------------------------------------------------------------------
+ * K1  feature extraction: STFT(n_fft=1200, hop=600, periodic Hann, reflect-centre) -> log-mel (4 ch)
+ *     + mel-scale FOA intensity vector (3 ch) -> z-score.
+ *     replaces src/datasets.py:252-292 (librosa.core.stft :255, mel GEMM :264/:275, power_to_db :265,
+ *     scaler :289-290) and the tensorise/concat step :158-160.
+ *   audio   [B][n_samples][4] float32, already int16/32768 + 1e-8 (datasets.py:147), channels W,Y,Z,X
+ *   twiddle [1200][2]  exp(-2 pi i n/1200) (re,im);  window [1200];
+ *   mel_start/mel_len [64] int32: first FFT bin and number of bins of each (contiguous) mel filter;
+ *   mel_w   [sum(mel_len)] float32 weights, filter after filter (mel_off[m] = prefix sum, [64] int32)
+ *   scaler_mean/scaler_rstd [7][64]: (x-mean)*rstd per (feature channel, mel bin)
+ *   out     layout 0: [B][7][T][64]  (reference order, datasets.py:160)
+ *           layout 1: [B][T][64][8]  (channels-last, 8th channel zero) -- what the encoder consumes
+ *   chan_max [B][4] float32 workspace (per clip/channel max of the un-clipped log-mel, for top_db=80)
+ *   T = n_samples / 600 (n_samples must be a multiple of 600).
+ * Two launches: adyolo_feat_stft_mel (writes IV final, log-mel un-clipped + chan_max) then
+ * adyolo_feat_finish (top_db clip relative to chan_max + z-score of the 4 log-mel channels).
+ * ---------------------------------------------------------------------------------------------- */
+int adyolo_feat_stft_mel(const float *audio, const float *twiddle, const float *window,
+                         const int32_t *mel_start, const int32_t *mel_len, const int32_t *mel_off,
+                         const float *mel_w, const float *scaler_mean, const float *scaler_rstd,
+                         float *out, float *chan_max, int B, int n_samples, int layout, void *stream);
+int adyolo_feat_finish(float *out, const float *chan_max, const float *scaler_mean,
+                       const float *scaler_rstd, int B, int T, int layout, void *stream);
+/* [B][C][H][W] (C<=8) -> [B][H][W][8] zero padded; entry of WrapperModel.forward (wrapper.py:52-57) */
+int adyolo_nchw_to_nhwc8(const float *x, float *y, int B, int C, int H, int W, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K2  3x3 convolution, stride 1, pad 1, as an fp32-MFMA implicit GEMM (v_mfma_f32_32x32x2_f32).
+ *     replaces nn.Conv2d forward/backward at src/models/backbones/resnet.py:16,18,142.
+ *   x [N][H][W][Cin]; y [N][H][W][Cout];  Cin in {8, multiples of 32}, Cout multiple of 32.
+ *   wpk   packed weights [Cout][9][Cin]  (tap = ky*3+kx, Cin fastest) -- see adyolo_pack_w3x3
+ *   bias  [Cout] or NULL;  addend [N][H][W][Cout] or NULL (added before the optional ReLU)
+ *   y = relu?( conv(x, w) + bias + addend )
+ * data-gradient = the same call with the dgrad packing (wpk_dgrad, Cin<->Cout swapped).
+ * weight-gradient: adyolo_conv3x3_wgrad accumulates into `slabs` ([n_slabs][Cout][9][CinP] float32,
+ * n_slabs = adyolo_conv3x3_wgrad_slabs(...)) then reduces them into dw in the reference layout
+ * [Cout][Cin_real][3][3] (Cin_real <= Cin: 7 for the stem whose activations are padded to 8).
+ * ---------------------------------------------------------------------------------------------- */
+int adyolo_pack_w3x3(const float *w /*[Cout][Cin_real][3][3]*/, float *wpk_fwd /*[Cout][9][Cin]*/,
+                     float *wpk_dgrad /*[Cin][9][Cout] or NULL*/, int Cout, int Cin_real, int Cin,
+                     void *stream);
+int adyolo_conv3x3_fwd(const float *x, const float *wpk, const float *bias, const float *addend,
+                       float *y, int N, int H, int W, int Cin, int Cout, int relu, void *stream);
+int adyolo_conv3x3_wgrad_slabs(int N, int H, int W, int Cin, int Cout);
+int adyolo_conv3x3_wgrad(const float *x, const float *dy, float *slabs, float *dw, int N, int H,
+                         int W, int Cin, int Cin_real, int Cout, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K7  dense GEMM on fp32 MFMA:  C[m][n] = sum_k opA(m,k) * opB(n,k) (+ bias[n])
+ *     opA(m,k) = transA ? A[k*lda+m] : A[m*lda+k];   opB(n,k) = transB ? B[k*ldb+n] : B[n*ldb+k]
+ *     replaces nn.Linear (linearheads.py:95-98, resnet.py:96-98), the 1x1 downsample conv
+ *     (resnet.py:160-162), the GRU input projections (resnet.py:153) and their backward passes.
+ *   K and every leading dimension must be multiples of 4; transposed operands need M (resp. N) % 4 == 0.
+ *   splits > 1: K is cut into `splits` ranges, partial products go to `slabs` ([splits][M][N]) and are
+ *   summed deterministically into C (bias added once).  accumulate != 0: C += result.
+ * ---------------------------------------------------------------------------------------------- */
+int adyolo_gemm(const float *A, const float *B, const float *bias, float *C, float *slabs, int M,
+                int N, int K, int lda, int ldb, int ldc, int transA, int transB, int splits,
+                int accumulate, void *stream);
+/* out[c] (+)= sum_r A[r*lda + c], deterministic two-stage; partial: [256][C] workspace */
+int adyolo_colsum(const float *A, float *out, float *partial, int R, int C, int lda, int accumulate,
+                  void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K3  BatchNorm2d (train-mode batch statistics / eval-mode running statistics), channels-last.
+ *     replaces nn.BatchNorm2d at resnet.py:17,19,144,163 (momentum 0.1, eps 1e-5).
+ *   adyolo_bn_stats: per-sample channel sums  ssum[N][C]  (these are also the SE squeeze, K3b) and
+ *     mean/invstd [C] of the whole batch; updates running_mean / running_var (unbiased) in place when
+ *     they are non-NULL.  partial: workspace of 2*1024*C floats.
+ *   adyolo_bn_scale_shift: scale = gamma*invstd, shift = beta - mean*scale   (train)
+ *     or from running stats when mean == NULL is not allowed: pass running_mean/invstd computed by
+ *     adyolo_bn_eval_stats.
+ *   adyolo_affine_nhwc: y = x*scale[c] + shift[c]
+ *   adyolo_bn_bwd_reduce: sdy[c] = sum dy, sdyx[c] = sum dy * xhat   (partial: 2*1024*C floats)
+ *   adyolo_bn_bwd_apply:  dx = gamma*invstd*(dy - sdy/R - xhat*sdyx/R) [* (x > 0) when relu_mask]
+ *     and dgamma += sdyx, dbeta += sdy when those pointers are non-NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int adyolo_bn_stats(const float *x, float *ssum, float *mean, float *invstd, float *running_mean,
+                    float *running_var, float *partial, int N, int HW, int C, float momentum,
+                    float eps, void *stream);
+int adyolo_bn_eval_stats(const float *running_mean, const float *running_var, float *mean,
+                         float *invstd, int C, float eps, void *stream);
+int adyolo_bn_scale_shift(const float *gamma, const float *beta, const float *mean,
+                          const float *invstd, float *scale, float *shift, int C, void *stream);
+int adyolo_affine_nhwc(const float *x, const float *scale, const float *shift, float *y, long rows,
+                       int C, void *stream);
+int adyolo_bn_bwd_reduce(const float *dy, const float *x, const float *mean, const float *invstd,
+                         float *sdy, float *sdyx, float *partial, long rows, int C, void *stream);
+int adyolo_bn_bwd_apply(const float *dy, const float *x, const float *gamma, const float *mean,
+                        const float *invstd, const float *sdy, const float *sdyx, float *dx,
+                        float *dgamma, float *dbeta, long rows, int C, int relu_mask, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K3b squeeze-excite + residual tail of SEBasicBlock (resnet.py:38-47, SELayer :91-106), fused:
+ *     d = c*scale + shift (bn2);  s = sigmoid(W2 relu(W1 mean_hw(d) + b1) + b2);  e = relu(d*s + r)
+ *   adyolo_se_fc_fwd: pooled[n][c] = scale*ssum/HW + shift;  hid = relu(W1 pooled + b1) [N][Cr];
+ *                     s = sigmoid(W2 hid + b2) [N][C]
+ *   adyolo_se_tail_fwd: e = relu((c*scale+shift)*s[n][c] + r)
+ *   adyolo_se_tail_bwd_reduce: g = de*(e>0);  sg[n][c] = sum_hw g;  sgx[n][c] = sum_hw g*xhat
+ *   adyolo_se_fc_bwd: from sg, sgx: ds -> dW2, db2, dW1, db1 (accumulated) and dpool[n][c]; also the
+ *                     batch sums needed by bn2's backward: sdd[c] = sum dd, sddx[c] = sum dd*xhat
+ *   adyolo_se_tail_bwd_apply: dc = scale*( g*s + dpool/HW - sdd/R - xhat*sddx/R ),  dr = g
+ * ---------------------------------------------------------------------------------------------- */
+int adyolo_se_fc_fwd(const float *ssum, const float *scale, const float *shift, const float *w1,
+                     const float *b1, const float *w2, const float *b2, float *pooled, float *hid,
+                     float *s, int N, int HW, int C, int Cr, void *stream);
+int adyolo_se_tail_fwd(const float *c, const float *r, const float *scale, const float *shift,
+                       const float *s, float *e, int N, int HW, int C, void *stream);
+int adyolo_se_tail_bwd_reduce(const float *de, const float *e, const float *c, const float *mean,
+                              const float *invstd, float *sg, float *sgx, float *partial, int N,
+                              int HW, int C, void *stream);
+int adyolo_se_fc_bwd(const float *sg, const float *sgx, const float *ssum, const float *gamma,
+                     const float *beta, const float *mean, const float *invstd, const float *pooled,
+                     const float *hid, const float *s, const float *w1, const float *w2, float *dw1,
+                     float *db1, float *dw2, float *db2, float *dpool, float *sdd, float *sddx,
+                     float *dgamma, float *dbeta, int N, int HW, int C, int Cr, void *stream);
+int adyolo_se_tail_bwd_apply(const float *de, const float *e, const float *c, const float *gamma,
+                             const float *mean, const float *invstd, const float *s,
+                             const float *dpool, const float *sdd, const float *sddx, float *dc,
+                             float *dr, int N, int HW, int C, void *stream);
+
+/* K4  AvgPool2d(2,2) (resnet.py:13,27-29), channels-last; H and W even.  bwd: dx = dy/4 broadcast (+= if accumulate) */
+int adyolo_avgpool2_fwd(const float *x, float *y, int N, int H, int W, int C, void *stream);
+int adyolo_avgpool2_bwd(const float *dy, float *dx, int N, int H, int W, int C, void *stream);
+/* y = a + b (elementwise, n float32);  adyolo_scale_dev: y = a * scalar_dev[0] (scalar read on device: no host sync) */
+int adyolo_add(const float *a, const float *b, float *y, long n, void *stream);
+int adyolo_scale_dev(const float *a, const float *scalar_dev, float *y, long n, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K5  self-attention pooling over the 16 mel positions (resnet.py:109-123)
+ *   x [R][F][C] (R = B*T'), w [C], b [1] -> y [R][C], attn [R][F]    (F <= 32, C == 256)
+ *   bwd: dx [R][F][C]; dw_partial [nblk][C+1] workspace (last column = db), reduced into dw[C], db[1]
+ * ---------------------------------------------------------------------------------------------- */
+int adyolo_sap_fwd(const float *x, const float *w, const float *b, float *y, float *attn, int R,
+                   int F, int C, void *stream);
+int adyolo_sap_bwd(const float *dy, const float *x, const float *w, const float *attn, float *dx,
+                   float *dw, float *db, float *partial, int R, int F, int C, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K6  one bidirectional GRU layer, hidden 128 (nn.GRU at resnet.py:153,195; gate order r,z,n)
+ *   gx  [B][T][2][384]  = x W_ih^T + b_ih for both directions (from adyolo_gemm)
+ *   whh [2][384][128], bhh [2][384]
+ *   out [B][T][256] (forward hidden | backward hidden);  gates [B][T][2][4][128] saves r,z,n,hn;
+ *   hprev [B][T][2][128] saves the hidden state entering each step (gates/hprev may be NULL in eval)
+ *   bwd: dout [B][T][256] -> dgx [B][T][2][384], dgh [B][T][2][384]
+ *        (dW_ih = dgx^T x, dW_hh = dgh^T hprev, db = column sums, dx = dgx W_ih: adyolo_gemm/colsum)
+ * K6b LayerNorm(256) + tanh (resnet.py:154,196-197): y = tanh(LN(x));
+ *     bwd: dx, and dgamma/dbeta through `partial` ([nblk][2*C]) reduced into dgamma/dbeta (accumulated)
+ * dropout mask for the inter-layer dropout (p = 0.3, train only): mask[i] = keep ? 1/(1-p) : 0 from a
+ * counter-based generator (seed, offset); adyolo_mul applies it.
+ * ---------------------------------------------------------------------------------------------- */
+int adyolo_gru_fwd(const float *gx, const float *whh, const float *bhh, float *out, float *gates,
+                   float *hprev, int B, int T, void *stream);
+int adyolo_gru_bwd(const float *dout, const float *gates, const float *hprev, const float *whh,
+                   float *dgx, float *dgh, int B, int T, void *stream);
+int adyolo_ln_tanh_fwd(const float *x, const float *gamma, const float *beta, float *y, long R,
+                       int C, float eps, void *stream);
+int adyolo_ln_tanh_bwd(const float *dy, const float *x, const float *y, const float *gamma,
+                       float *dx, float *dgamma, float *dbeta, float *partial, long R, int C,
+                       float eps, void *stream);
+int adyolo_dropout_mask(float *mask, long n, float p, uint64_t seed, uint64_t offset, void *stream);
+int adyolo_mul(const float *a, const float *b, float *y, long n, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K8  AD-YOLO loss, forward + backward in one pass over the logits (src/models/loss.py:189-251)
+ *   logit  [B*T][Gaz*Gel][A][C+3]  (channel order obj, cls x C, u, v)
+ *   target [M][7] float32 (b, frame, Gi, Gj, cls, U, V) -- datasets.py:164-184
+ *   thr[3] responsibility thresholds in degrees (train_unify), gains[4] = angular, object, nonobj, class
+ *   ws: workspace of adyolo_loss_workspace_words(...) 32-bit words (zeroed by the call itself)
+ *   loss [1] float32;  dlogit same shape as logit or NULL (eval).  grad_scale multiplies dlogit.
+ *   dist [M][A] (optional, may be NULL): angular distances D, for tests.
+ * ---------------------------------------------------------------------------------------------- */
+long adyolo_loss_workspace_words(int BT, int G, int A, int M);
+int  adyolo_loss_fwd_bwd(const float *logit, const float *target, float *ws, float *loss,
+                         float *dlogit, float *dist, int B, int T, int Gaz, int Gel, int A, int C,
+                         int M, const float *thr_host, const float *gains_host, float grid_az,
+                         float grid_el, float g_overlap, float grad_scale, void *stream);
+
+/* K11 fused Adam over one flat parameter buffer (torch.optim.Adam at src/train.py:31,55; no amsgrad) */
+int adyolo_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long n,
+                     float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                     float grad_scale, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADYOLO_HIP_H */

@@ -201,6 +201,21 @@ class _Wrap(torch.nn.Module):
         self.head = head
 
 
+def gen_init():
+    """Reference default initialisation under torch.manual_seed(100) (main.py:47 default seed): fingerprints only."""
+    from models.backbones.resnet import SEResnet34
+    from models.linearheads import ADYOLOhead
+    torch.manual_seed(100)
+    enc = SEResnet34((1, 7, 800, 64), (), make_params())
+    head = ADYOLOhead(256, 256, 12, [45, 45], 5)
+    sd = _Wrap(enc, head).state_dict()
+    names = sorted(k for k, v in sd.items() if v.is_floating_point())
+    sums = np.asarray([float(sd[k].double().sum()) for k in names])
+    first = np.asarray([float(sd[k].reshape(-1)[0]) for k in names])
+    np.savez_compressed(os.path.join(HERE, "init_seed100.npz"), names=np.asarray(names), sums=sums, first=first)
+    print("init_seed100.npz", len(names))
+
+
 def gen_scaler():
     import pickle
     for d in ("DCASE2021", "DCASE2022"):
@@ -218,4 +233,5 @@ if __name__ == "__main__":
     flp = gen_labels()
     gen_loss(flp)
     gen_encoder()
+    gen_init()
     gen_scaler()

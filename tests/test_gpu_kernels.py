@@ -1,0 +1,444 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): every hand-written kernel, through the C ABI
+(ctypes -> libadyolo_hip.so), against the CPU oracle / a plain PyTorch-CPU fp32 reference of the same op on the
+same seeded inputs.  Tolerances: 1e-3 (BASELINE.json north_star) or tighter, written at each assert."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import adyolo_amd  # noqa: F401
+    from adyolo_amd import ops as _ops
+    return _ops
+
+
+def dev(t):
+    return t.to("cuda:0").contiguous()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def assert_close(got, ref, tol, what):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, "%s: shape %s vs %s" % (what, tuple(got.shape), tuple(ref.shape))
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((got - ref).abs().max())
+    assert np.isfinite(err) and err <= tol * scale, "%s: max abs err %.3e (ref absmax %.3e, tol %.1e)" % (what, err, scale, tol)
+
+
+# ------------------------------------------------------------------------------------------------ conv
+@pytest.mark.parametrize("n,h,w,cin,cout,relu,bias,addend", [
+    (2, 20, 64, 7, 32, True, True, False),       # stem shape family (Cin 7 padded to 8), W=64 -> TW=32
+    (1, 9, 16, 7, 32, False, True, False),       # ragged H, TW=16 path
+    (2, 16, 64, 32, 32, False, False, True),     # layer1
+    (2, 13, 32, 32, 64, True, False, False),     # layer2.0 conv1, ragged H
+    (1, 24, 32, 64, 64, False, False, True),
+    (2, 18, 16, 64, 128, False, False, False),   # TW=16
+    (1, 16, 16, 128, 128, True, False, False),
+    (1, 8, 16, 128, 256, False, False, False),
+    (1, 10, 16, 256, 256, False, False, True),
+    (1, 5, 5, 32, 32, False, False, False),      # tile much larger than the image
+    (1, 33, 40, 32, 64, True, False, False),     # ragged both ways, TW=32
+])
+def test_conv3x3_forward(ops, n, h, w, cin, cout, relu, bias, addend):
+    g = torch.Generator().manual_seed(n * 1000 + h * 10 + cin)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
+    b = torch.randn(cout, generator=g) if bias else None
+    add = torch.randn(n, cout, h, w, generator=g) if addend else None
+    ref = F.conv2d(x, wt, b, padding=1)
+    if add is not None:
+        ref = ref + add
+    if relu:
+        ref = F.relu(ref)
+    cin_p = 8 if cin == 7 else cin
+    xg = dev(nhwc(x))
+    if cin_p != cin:
+        xg = dev(F.pad(nhwc(x), (0, cin_p - cin)))
+    wpk, _ = ops.pack_w3x3(dev(wt), cin_p, want_dgrad=False)
+    y = ops.conv3x3(xg, wpk, cout, bias=dev(b) if bias else None, addend=dev(nhwc(add)) if addend else None, relu=relu)
+    torch.cuda.synchronize()
+    assert_close(nchw(y), ref, 2e-5, "conv3x3 fwd")
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", [
+    (2, 16, 64, 32, 32), (2, 13, 32, 32, 64), (1, 18, 16, 64, 128), (1, 9, 16, 256, 256), (2, 20, 64, 7, 32),
+    (3, 40, 64, 32, 32),
+])
+def test_conv3x3_dgrad_wgrad(ops, n, h, w, cin, cout):
+    g = torch.Generator().manual_seed(7 + cin + cout)
+    x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)).requires_grad_(True)
+    dy = torch.randn(n, cout, h, w, generator=g)
+    F.conv2d(x, wt, None, padding=1).backward(dy)
+    cin_p = 8 if cin == 7 else cin
+    xg = dev(F.pad(nhwc(x.detach()), (0, cin_p - cin)))
+    dyg = dev(nhwc(dy))
+    dw = ops.conv3x3_wgrad(xg, dyg, cin)
+    torch.cuda.synchronize()
+    assert_close(dw, wt.grad, 2e-5, "conv3x3 wgrad")
+    if cin != 7:
+        _, wpk_d = ops.pack_w3x3(dev(wt.detach()), cin_p, want_dgrad=True)
+        dx = ops.conv3x3(dyg, wpk_d, cin)
+        torch.cuda.synchronize()
+        assert_close(nchw(dx), x.grad, 2e-5, "conv3x3 dgrad")
+
+
+# ------------------------------------------------------------------------------------------------ gemm
+@pytest.mark.parametrize("m,n,k,ta,tb,bias,splits", [
+    (300, 2400, 256, False, False, True, 1),      # head
+    (130, 70, 36, False, False, False, 1),        # ragged everywhere
+    (512, 256, 2400, False, True, False, 1),      # dX = dY W
+    (384, 256, 3000, True, True, False, 4),       # dW = dY^T X, split-K
+    (64, 8, 64, False, False, True, 1),           # SE-sized
+    (260, 132, 520, True, False, False, 3),
+])
+def test_gemm(ops, m, n, k, ta, tb, bias, splits):
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(k, m, generator=g) if ta else torch.randn(m, k, generator=g)
+    b = torch.randn(k, n, generator=g) if tb else torch.randn(n, k, generator=g)
+    bv = torch.randn(n, generator=g) if bias else None
+    ref = (a.t() if ta else a) @ (b if tb else b.t())
+    if bias:
+        ref = ref + bv
+    out = ops.gemm(dev(a), dev(b), m, n, k, a.shape[1], b.shape[1], trans_a=ta, trans_b=tb,
+                   bias=dev(bv) if bias else None, splits=splits)
+    torch.cuda.synchronize()
+    assert_close(out, ref, 3e-5, "gemm")
+    acc = ops.gemm(dev(a), dev(b), m, n, k, a.shape[1], b.shape[1], trans_a=ta, trans_b=tb, out=out.clone(),
+                   accumulate=True, splits=splits)
+    torch.cuda.synchronize()
+    assert_close(acc, 2 * ref, 3e-5, "gemm accumulate")
+
+
+def test_colsum_and_elementwise(ops):
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(1000, 768, generator=g)
+    s = ops.colsum(dev(a)[:, 384:])
+    torch.cuda.synchronize()
+    assert_close(s, a[:, 384:].sum(0), 1e-5, "colsum strided")
+    b = torch.randn(1000, 768, generator=g)
+    assert_close(ops.add(dev(a), dev(b)), a + b, 1e-6, "add")
+    assert_close(ops.mul(dev(a), dev(b)), a * b, 1e-6, "mul")
+    assert_close(ops.scale_dev(dev(a), dev(torch.tensor([0.25]))), a * 0.25, 1e-6, "scale_dev")
+
+
+# ------------------------------------------------------------------------------------------------ norm
+@pytest.mark.parametrize("n,h,w,c", [(3, 20, 16, 32), (2, 7, 8, 64), (1, 50, 16, 256), (4, 5, 4, 128)])
+def test_batchnorm_train_fwd_bwd(ops, n, h, w, c):
+    g = torch.Generator().manual_seed(c + n)
+    x = (torch.randn(n, c, h, w, generator=g) * 2 + 0.5).relu().requires_grad_(True)    # BN input is a ReLU output
+    gamma = (torch.rand(c, generator=g) + 0.5).requires_grad_(True)
+    beta = torch.randn(c, generator=g).requires_grad_(True)
+    rm, rv = torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y_ref = F.batch_norm(x, rm_ref, rv_ref, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    dy = torch.randn(n, c, h, w, generator=g)
+    y_ref.backward(dy)
+    xg = dev(nhwc(x.detach()))
+    rmg, rvg = dev(rm), dev(rv)
+    ssum, mean, invstd = ops.bn_stats(xg, rmg, rvg, 0.1, 1e-5)
+    scale, shift = ops.bn_scale_shift(dev(gamma.detach()), dev(beta.detach()), mean, invstd)
+    y = ops.affine(xg, scale, shift)
+    dx, dgamma, dbeta = ops.bn_bwd(dev(nhwc(dy)), xg, dev(gamma.detach()), mean, invstd, relu_mask=False)
+    torch.cuda.synchronize()
+    assert_close(nchw(y), y_ref, 2e-5, "bn fwd")
+    assert_close(rmg, rm_ref, 1e-5, "running_mean")
+    assert_close(rvg, rv_ref, 1e-5, "running_var")
+    assert_close(ssum, x.detach().sum(dim=(2, 3)), 1e-5, "per-sample sums")
+    assert_close(nchw(dx), x.grad, 5e-5, "bn dx")
+    assert_close(dgamma, gamma.grad, 5e-5, "bn dgamma")
+    assert_close(dbeta, beta.grad, 5e-5, "bn dbeta")
+    dxm, _, _ = ops.bn_bwd(dev(nhwc(dy)), xg, dev(gamma.detach()), mean, invstd, relu_mask=True)
+    assert_close(nchw(dxm), x.grad * (x.detach() > 0), 5e-5, "bn dx with relu mask")
+
+
+def test_avgpool(ops):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 32, 12, 16, generator=g, requires_grad=True)
+    y_ref = F.avg_pool2d(x, 2, 2)
+    dy = torch.randn_like(y_ref)
+    y_ref.backward(dy)
+    y = ops.avgpool2(dev(nhwc(x.detach())))
+    dx = ops.avgpool2_bwd(dev(nhwc(dy)), 12, 16)
+    assert_close(nchw(y), y_ref, 1e-6, "avgpool fwd")
+    assert_close(nchw(dx), x.grad, 1e-6, "avgpool bwd")
+
+
+# ------------------------------------------------------------------------------------------------ blocks vs oracle
+def _block_sd(prefix, cin, c, down, seed):
+    from oracle.filler import fill_value
+    names = [("conv1.weight", (c, cin, 3, 3)), ("bn1.weight", (c,)), ("bn1.bias", (c,)), ("bn1.running_mean", (c,)),
+             ("bn1.running_var", (c,)), ("conv2.weight", (c, c, 3, 3)), ("bn2.weight", (c,)), ("bn2.bias", (c,)),
+             ("bn2.running_mean", (c,)), ("bn2.running_var", (c,)), ("se.fc.0.weight", (c // 8, c)),
+             ("se.fc.0.bias", (c // 8,)), ("se.fc.2.weight", (c, c // 8)), ("se.fc.2.bias", (c,))]
+    if down:
+        names += [("downsample.0.weight", (c, cin, 1, 1)), ("downsample.1.weight", (c,)), ("downsample.1.bias", (c,)),
+                  ("downsample.1.running_mean", (c,)), ("downsample.1.running_var", (c,))]
+    return {prefix + "." + k: fill_value("seed%d.%s.%s" % (seed, prefix, k), s) for k, s in names}
+
+
+@pytest.mark.parametrize("cin,c,pool,n,h,w,training", [
+    (32, 32, False, 2, 12, 64, True),
+    (32, 64, True, 2, 16, 64, True),
+    (64, 128, True, 2, 16, 32, True),
+    (128, 256, False, 1, 10, 16, True),
+    (256, 256, False, 2, 6, 16, True),
+    (32, 64, True, 2, 16, 64, False),
+    (64, 64, False, 1, 8, 32, False),
+])
+def test_se_basic_block_matches_oracle(ops, cin, c, pool, n, h, w, training):
+    from oracle import seresnet as onet
+    from adyolo_amd.models.backbones.resnet import SEBasicBlock, ConvParams, BatchNormParams
+    import torch.nn as nn
+    down = cin != c
+    sd = _block_sd("blk", cin, c, down, seed=cin + c)
+    dmod = nn.ModuleDict({"0": ConvParams(cin, c, 1, False), "1": BatchNormParams(c)}) if down else None
+    blk = SEBasicBlock(cin, c, dmod, 2 if pool else None)
+    blk.load_state_dict({k[4:]: v for k, v in sd.items()}, strict=False)
+    blk = blk.to("cuda:0")
+    blk.train(training)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, cin, h, w, generator=g).relu()
+    probe = torch.randn(n, c, h // 2 if pool else h, w // 2 if pool else w, generator=g)
+    # oracle
+    osd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    yo = onet.se_basic_block(osd, "blk", xo, (2, 2) if pool else None, training, update_stats=True)
+    # device
+    xg = dev(nhwc(x)).requires_grad_(True)
+    yg = blk(xg)
+    torch.cuda.synchronize()
+    assert_close(nchw(yg), yo, 1e-4, "block forward")
+    if training:
+        (yo * probe).sum().backward()
+        (yg * dev(nhwc(probe))).sum().backward()
+        torch.cuda.synchronize()
+        assert_close(nchw(xg.grad), xo.grad, 1e-3, "block dx")
+        for name, prm in blk.named_parameters():
+            assert_close(prm.grad, osd["blk." + name].grad, 1e-3, "block grad " + name)
+        for name, buf in blk.named_buffers():
+            if "running" in name:
+                assert_close(buf, osd["blk." + name], 1e-4, "block buffer " + name)
+
+
+def test_sap_gru_ln_linear_match_oracle(ops):
+    from oracle import seresnet as onet
+    from oracle.filler import fill_state_dict
+    from adyolo_amd import functional as Fn
+    enc, head = onet.split_state_dict(fill_state_dict(onet.state_dict_spec()))
+    g = torch.Generator().manual_seed(31)
+    bsz, t, f = 3, 11, 16
+    x = torch.randn(bsz, t, f, 256, generator=g)
+    # --- SAP
+    xo = x.clone().requires_grad_(True)
+    wo = enc["attention.W.weight"].clone().requires_grad_(True)
+    bo = enc["attention.W.bias"].clone().requires_grad_(True)
+    yo = onet.self_attention_pooling({"attention.W.weight": wo, "attention.W.bias": bo}, xo)
+    probe = torch.randn(bsz, t, 256, generator=g)
+    (yo * probe).sum().backward()
+    xg, wg, bg = dev(x).requires_grad_(True), dev(wo.detach()).requires_grad_(True), dev(bo.detach()).requires_grad_(True)
+    yg = Fn.SAPFn.apply(xg, wg, bg)
+    (yg * dev(probe)).sum().backward()
+    assert_close(yg, yo, 1e-5, "sap fwd")
+    assert_close(xg.grad, xo.grad, 1e-4, "sap dx")
+    assert_close(wg.grad, wo.grad, 1e-4, "sap dW")
+    assert_close(bg.grad, bo.grad, 1e-4, "sap db")
+    # --- BiGRU layer 0 and 1 (+ explicit mask in between), LN+tanh, head
+    names = ["weight_ih", "weight_hh", "bias_ih", "bias_hh"]
+    s = torch.randn(bsz, t, 256, generator=g)
+    mask = (torch.rand(bsz, t, 256, generator=g) > 0.3).float() / 0.7
+    osd = {k: v.clone().requires_grad_(True) for k, v in enc.items() if k.startswith(("lstm.", "norm."))}
+    so = s.clone().requires_grad_(True)
+    go = onet.bigru(osd, so, dropout_mask=mask)
+    lo = torch.tanh(F.layer_norm(go, (256,), osd["norm.weight"], osd["norm.bias"], 1e-5))
+    hsd = {k: v.clone().requires_grad_(True) for k, v in head.items()}
+    ho = onet.adyolo_head(hsd, lo)
+    probe2 = torch.randn(bsz, t, 2400, generator=g)
+    (ho * probe2).sum().backward()
+    gsd = {k: dev(v.detach()).requires_grad_(True) for k, v in osd.items()}
+    ghd = {k: dev(v.detach()).requires_grad_(True) for k, v in hsd.items()}
+    sg = dev(s).requires_grad_(True)
+
+    def lp(layer):
+        return [gsd["lstm.%s_l%d%s" % (nm, layer, sfx)] for sfx in ("", "_reverse") for nm in names]
+    y0 = Fn.BiGRULayerFn.apply(sg, *lp(0), True)
+    y0 = Fn.DropoutFn.apply(y0, dev(mask))
+    y1 = Fn.BiGRULayerFn.apply(y0, *lp(1), True)
+    yl = Fn.LNTanhFn.apply(y1, gsd["norm.weight"], gsd["norm.bias"], 1e-5)
+    yh = Fn.LinearFn.apply(Fn.LinearFn.apply(yl, ghd["yolo_head.0.weight"], ghd["yolo_head.0.bias"]),
+                           ghd["yolo_head.1.weight"], ghd["yolo_head.1.bias"])
+    (yh * dev(probe2)).sum().backward()
+    torch.cuda.synchronize()
+    assert_close(y1, go, 1e-4, "bigru fwd")
+    assert_close(yl, lo, 1e-4, "ln tanh fwd")
+    assert_close(yh, ho, 1e-3, "head fwd")
+    assert_close(sg.grad, so.grad, 1e-3, "gru dx")
+    for k in osd:
+        assert_close(gsd[k].grad, osd[k].grad, 1e-3, "grad " + k)
+    for k in hsd:
+        assert_close(ghd[k].grad, hsd[k].grad, 1e-3, "grad " + k)
+
+
+def test_dropout_mask_statistics(ops):
+    x = torch.ones(1 << 20, device="cuda:0")
+    m = ops.dropout_mask(x, 0.3, 1234, 0)
+    m2 = ops.dropout_mask(x, 0.3, 1234, 0)
+    m3 = ops.dropout_mask(x, 0.3, 1234, 1 << 20)
+    torch.cuda.synchronize()
+    keep = float((m > 0).float().mean())
+    assert abs(keep - 0.7) < 5e-3, keep
+    assert torch.equal(m, m2) and not torch.equal(m, m3)
+    vals = torch.unique(m).cpu().tolist()
+    assert len(vals) == 2 and abs(vals[1] - 1 / 0.7) < 1e-6 and vals[0] == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ loss
+@pytest.mark.parametrize("tag,nb_classes", [("c12", 12), ("c13", 13), ("sat", 12)])
+def test_loss_matches_golden_and_oracle(ops, tag, nb_classes):
+    from oracle import adyolo_loss as oloss
+    g = np.load(os.path.join(G, "adyolo_loss.npz"))
+    logit = torch.from_numpy(g[tag + "_logit"])
+    target = torch.from_numpy(g[tag + "_target"])
+    loss, dlogit, dist = ops.adyolo_loss(dev(logit), dev(target), nb_classes, want_dist=True)
+    torch.cuda.synchronize()
+    lo = logit.clone().requires_grad_(True)
+    ref, aux = oloss.adyolo_loss(lo, target, nb_classes, return_aux=True)
+    assert_close(dist, aux["D"], 2e-5, "angular distances")
+    assert_close(loss, torch.from_numpy(g[tag + "_loss"]), 1e-5, "loss vs golden")
+    gold = torch.from_numpy(g[tag + "_dlogit"])
+    err = float((dlogit.cpu() - gold).abs().max())
+    assert err <= 1e-3 * float(gold.abs().max()), "dlogit abs err %.3e vs absmax %.3e" % (err, float(gold.abs().max()))
+
+
+def test_loss_large_random_vs_oracle(ops):
+    from oracle import adyolo_loss as oloss
+    from adyolo_amd.datasets import synthetic_targets
+    b, t, c = 4, 50, 12
+    g = torch.Generator().manual_seed(77)
+    logit = torch.randn(b, t, 8 * 4 * 5 * (c + 3), generator=g) * 1.5
+    target = synthetic_targets(b, t, c, seed=5)
+    lo = logit.clone().requires_grad_(True)
+    ref = oloss.adyolo_loss(lo, target, c)
+    ref.backward()
+    loss, dlogit, _ = ops.adyolo_loss(dev(logit), dev(target), c)
+    torch.cuda.synchronize()
+    assert_close(loss, ref.detach(), 1e-5, "loss")
+    err = float((dlogit.cpu() - lo.grad).abs().max())
+    assert err < 2e-7 + 1e-3 * float(lo.grad.abs().max()), "dlogit abs err %.3e" % err
+
+
+# ------------------------------------------------------------------------------------------------ features
+def test_features_match_oracle(ops):
+    from oracle import features as ofeat
+    from adyolo_amd.features import FeatureExtractor, load_scaler_npz
+    from adyolo_amd.datasets import synthetic_audio
+    scaler = load_scaler_npz(os.path.join(G, "scaler_DCASE2021.npz"))
+    audio = synthetic_audio(2, 24000 * 2, seed=9)                    # 2 clips x 2 s -> T = 80
+    # make the second clip quiet in one channel so the top_db clip actually bites
+    audio[1, :, 2] *= 1e-4
+    fx = FeatureExtractor(scaler, "cuda:0")
+    out_ref_layout = fx(dev(audio), channels_last8=False).cpu()
+    out_cl8 = fx(dev(audio), channels_last8=True).cpu()
+    torch.cuda.synchronize()
+    for b in range(2):
+        ref, _ = ofeat.get_feature(audio[b].double().numpy(), scaler)
+        ref = torch.from_numpy(ref)
+        assert_close(out_ref_layout[b, :4], ref[:4], 1e-3, "log-mel (clip %d)" % b)
+        err_iv = float((out_ref_layout[b, 4:] - ref[4:]).abs().max())
+        assert err_iv < 1e-3, "IV abs err %.3e" % err_iv
+        assert_close(out_cl8[b, :, :, :7].permute(2, 0, 1), ref, 1e-3, "channels-last layout")
+        assert float(out_cl8[b, :, :, 7].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ whole model
+def _params(nb_classes=12):
+    return {"args": {"device": "cuda:0", "encoder": "se-resnet34", "loss": "adyolo"},
+            "data_config": {"nb_classes": nb_classes},
+            "train_config": {"grid_size": [45, 45], "nb_anchors": 5, "train_unify": [45.0, 25.0, 10.0], "g_overlap": 0.5,
+                             "loss_gains": {"angular_gain": 5.0, "object_gain": 1.0, "nonobj_gain": 5.0, "class_gain": 3.0},
+                             "optim": "Adam", "lr": 1e-3, "weight_decay": 0.0}}
+
+
+def test_wrapper_model_matches_reference_golden(ops):
+    from oracle.filler import fill_module_
+    from adyolo_amd.wrapper import WrapperModel
+    g = np.load(os.path.join(G, "encoder.npz"))
+    model = WrapperModel((1, 7, 64, 64), (), _params())
+    fill_module_(model)
+    model = model.to("cuda:0")
+    x = torch.from_numpy(g["x"])
+    model.eval()
+    with torch.no_grad():
+        y = model.encoder(dev(x))
+        hy = model.head(y)
+        y1 = model.encoder(dev(x[:1]))
+    torch.cuda.synchronize()
+    assert_close(y, torch.from_numpy(g["y_eval"]), 1e-3, "encoder eval output vs reference")
+    assert_close(y1, torch.from_numpy(g["y_eval_b1"]), 1e-3, "encoder eval output (batch 1) vs reference")
+    assert_close(hy, torch.from_numpy(g["head_eval"]), 1e-3, "head output vs reference")
+    # train mode (dropout off like the golden), gradients of <out, probe>
+    model.train()
+    model.encoder.lstm.dropout = 0.0
+    xg = dev(x)
+    y = model.encoder(xg)
+    (y * dev(torch.from_numpy(g["probe"]))).sum().backward()
+    torch.cuda.synchronize()
+    assert_close(y, torch.from_numpy(g["y_train"]), 1e-3, "encoder train output vs reference")
+    named = dict(model.encoder.named_parameters())
+    sd = model.encoder.state_dict()
+    for key in g.files:
+        if key.startswith("grad_"):
+            got = named[key[5:]].grad.reshape(-1)[:g[key].size]
+            assert_close(got, torch.from_numpy(g[key].reshape(-1)), 2e-3, key)
+        if key.startswith("stat_") and not key.endswith("num_batches_tracked"):
+            assert_close(sd[key[5:]], torch.from_numpy(g[key]), 1e-4, key)
+    assert int(sd["bn1.num_batches_tracked"]) == int(g["stat_bn1.num_batches_tracked"])
+
+
+def test_adam_matches_torch(ops):
+    g = torch.Generator().manual_seed(2)
+    p0 = torch.randn(10001 + 3, generator=g)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    pg, m, v = dev(p0), torch.zeros(p0.numel(), device="cuda:0"), torch.zeros(p0.numel(), device="cuda:0")
+    for step in range(1, 6):
+        grad = torch.randn(p0.numel(), generator=g)
+        ref.grad = grad.clone()
+        opt.step()
+        ops.adam_step(pg, dev(grad * 2.0), m, v, step, grad_scale=0.5)
+    torch.cuda.synchronize()
+    assert_close(pg, ref.detach(), 1e-6, "adam params")
+
+
+def test_train_step_runs_and_learns(ops):
+    from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
+    from adyolo_amd.features import FeatureExtractor
+    from adyolo_amd.datasets import synthetic_audio, synthetic_targets
+    from adyolo_amd.train import TrainStep
+    torch.manual_seed(100)
+    prm = _params()
+    model = WrapperModel((1, 7, 80, 64), (), prm).to("cuda:0")
+    step = TrainStep(model, WrapperCriterion(prm), FeatureExtractor(None, "cuda:0"), prm)
+    audio = dev(synthetic_audio(2, 24000 * 2, seed=3))
+    target = synthetic_targets(2, 20, 12, seed=3)
+    losses = [float(step.step(audio, target)) for _ in range(8)]
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses

@@ -1,0 +1,119 @@
+"""CPU: host-side logic of the product package (label encoder, collate, synthetic workload, parameter
+naming / initialisation) and the C-ABI surface (library loads, exports every declared symbol).
+No compute kernels are launched here (no GPU in this container)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import adyolo_amd  # noqa: F401  (import shim at the repo root)
+from adyolo_amd import _lib
+from adyolo_amd.datasets import YoloLabelEncoder, collate_fn, synthetic_audio, synthetic_targets
+from oracle import labels as olab
+from oracle import seresnet as onet
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def test_header_symbols_are_exported_and_bound():
+    """Every function declared in include/adyolo_hip.h is exported by the .so and bound in _lib.SIGNATURES."""
+    hdr = open(os.path.join(ROOT, "include", "adyolo_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(adyolo_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 35
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()                       # raises if the library or a symbol is missing
+    assert lib.adyolo_abi_version() == 1
+    assert lib.adyolo_loss_workspace_words(4, 32, 5, 10) > 6 * 4 * 32 * 5
+
+
+def test_ops_refuse_cpu_tensors():
+    from adyolo_amd import ops
+    with pytest.raises(_lib.AdyoloHipError):
+        ops.add(torch.zeros(8), torch.zeros(8))
+    from adyolo_amd.models.backbones.resnet import SEResnet34
+    enc = SEResnet34((1, 7, 16, 64), (), {"data_config": {"nb_classes": 12}})
+    with pytest.raises(RuntimeError):
+        enc(torch.zeros(1, 7, 16, 64))
+
+
+def test_label_encoder_matches_reference_golden():
+    g = np.load(os.path.join(G, "labels.npz"))
+    enc = YoloLabelEncoder()
+    got = []
+    for i, (az, el) in enumerate(g["sweep_in"]):
+        for r in enc.get_yolo_label({0: [[1, 0, float(az), float(el)]]}, 1):
+            got.append([i] + [float(v) for v in r])
+    np.testing.assert_array_equal(np.asarray(got), g["sweep_rows"])
+
+
+def test_label_encoder_and_collate_match_oracle():
+    events = {0: [[3, 0, 10.0, 5.0]], 1: [[3, 0, 10.0, 5.0], [7, 1, -170.0, 40.0]], 2: [[0, 0, 180.0, -30.0]],
+              4: [[5, 0, 44.9, -90.0], [2, 2, 47.0, -85.0]], 9: [[6, 0, 20.0, 20.0]]}
+    enc = YoloLabelEncoder()
+    rows = enc.get_yolo_label({k: [list(e) for e in v] for k, v in events.items()}, 8)
+    ref = olab.yolo_label({k: [list(e) for e in v] for k, v in events.items()}, 8)
+    np.testing.assert_array_equal(np.asarray(rows, dtype=np.float64), np.asarray(ref, dtype=np.float64))
+    feats = [torch.zeros(7, 8, 4), torch.ones(7, 8, 4)]
+    feat, target = collate_fn(list(zip(feats, [rows, []])))
+    _, tref = olab.collate([f.numpy() for f in feats], [ref, []])
+    np.testing.assert_array_equal(target.numpy(), tref)
+    assert feat.shape == (2, 7, 8, 4)
+    with pytest.raises(RuntimeError):
+        collate_fn(list(zip(feats, [[], []])))
+
+
+def test_synthetic_workload_shapes():
+    a = synthetic_audio(2, 1200, seed=1)
+    assert a.shape == (2, 1200, 4) and a.dtype == torch.float32
+    pcm = (a.double() - 1e-8) * 32768.0
+    assert float((pcm - pcm.round()).abs().max()) < 1e-3 and float(a.std()) == pytest.approx(0.1, rel=0.1)
+    t = synthetic_targets(4, 50, 12, seed=2)
+    assert t.shape[1] == 7 and t.dtype == torch.float32
+    assert int(t[:, 0].max()) <= 3 and int(t[:, 1].max()) <= 49 and int(t[:, 4].max()) <= 11
+    assert 2.5 < t.shape[0] / (4 * 50) < 4.5          # ~3.4 rows per (sample, frame), SURVEY 8d
+
+
+def _params():
+    return {"args": {"device": "cpu", "encoder": "se-resnet34", "loss": "adyolo"}, "data_config": {"nb_classes": 12},
+            "train_config": {"grid_size": [45, 45], "nb_anchors": 5, "train_unify": [45.0, 25.0, 10.0], "g_overlap": 0.5,
+                             "loss_gains": {"angular_gain": 5.0, "object_gain": 1.0, "nonobj_gain": 5.0,
+                                            "class_gain": 3.0}}}
+
+
+def test_state_dict_is_abi_compatible_with_reference():
+    from adyolo_amd.wrapper import WrapperModel
+    model = WrapperModel((1, 7, 800, 64), (), _params())
+    sd = model.state_dict()
+    spec = dict(onet.state_dict_spec())
+    assert set(sd) == set(spec)
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(spec[k]), k
+    assert sum(p.numel() for p in model.parameters()) == 6682093
+
+
+def test_default_init_is_bit_identical_to_reference_under_seed_100():
+    """Same seed -> same initial weights as the reference modules (fingerprints from make_golden.gen_init)."""
+    from adyolo_amd.wrapper import WrapperModel
+    g = np.load(os.path.join(G, "init_seed100.npz"))
+    torch.manual_seed(100)
+    sd = WrapperModel((1, 7, 800, 64), (), _params()).state_dict()
+    for name, s, f in zip(g["names"], g["sums"], g["first"]):
+        v = sd[str(name)]
+        assert float(v.reshape(-1)[0]) == float(f), name
+        assert float(v.double().sum()) == pytest.approx(float(s), rel=1e-12, abs=1e-12), name
+
+
+def test_wrapper_rejects_unknown_names():
+    from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
+    p = _params()
+    p["args"]["encoder"] = "nope"
+    with pytest.raises(NotImplementedError):
+        WrapperModel((1, 7, 8, 64), (), p)
+    p = _params()
+    p["args"]["loss"] = "nope"
+    with pytest.raises(NotImplementedError):
+        WrapperCriterion(p)
