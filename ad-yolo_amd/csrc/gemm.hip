@@ -198,10 +198,11 @@ extern "C" int adyolo_gemm(const float *A, const float *B, const float *bias, fl
                            int N, int K, int lda, int ldb, int ldc, int transA, int transB, int splits,
                            int accumulate, void *stream) {
     ADYOLO_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, ADYOLO_EINVAL, "gemm: bad arguments");
-    ADYOLO_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0, ADYOLO_ENOSUP,
-                   "gemm: K=%d lda=%d ldb=%d must be multiples of 4", K, lda, ldb);
-    ADYOLO_REQUIRE((!transA || M % 4 == 0) && (!transB || N % 4 == 0), ADYOLO_ENOSUP,
-                   "gemm: transposed operands need M (N) %% 4 == 0 (M=%d N=%d)", M, N);
+    // 16-byte vector loads run along the contiguous axis of each operand: k for k-major, m/n for transposed
+    ADYOLO_REQUIRE(lda % 4 == 0 && ldb % 4 == 0, ADYOLO_ENOSUP, "gemm: lda=%d ldb=%d must be multiples of 4", lda, ldb);
+    ADYOLO_REQUIRE((transA ? M : K) % 4 == 0 && (transB ? N : K) % 4 == 0, ADYOLO_ENOSUP,
+                   "gemm: contiguous axis of each operand must be a multiple of 4 (M=%d N=%d K=%d tA=%d tB=%d)", M, N,
+                   K, transA, transB);
     if (splits < 1) splits = 1;
     ADYOLO_REQUIRE(splits == 1 || slabs, ADYOLO_EINVAL, "gemm: splits > 1 needs a slab workspace");
     hipStream_t st = as_stream(stream);

@@ -81,7 +81,8 @@ int adyolo_conv3x3_wgrad(const float *x, const float *dy, float *slabs, float *d
  *     opA(m,k) = transA ? A[k*lda+m] : A[m*lda+k];   opB(n,k) = transB ? B[k*ldb+n] : B[n*ldb+k]
  *     replaces nn.Linear (linearheads.py:95-98, resnet.py:96-98), the 1x1 downsample conv
  *     (resnet.py:160-162), the GRU input projections (resnet.py:153) and their backward passes.
- *   K and every leading dimension must be multiples of 4; transposed operands need M (resp. N) % 4 == 0.
+ *   Leading dimensions must be multiples of 4, and so must each operand's contiguous axis (K for a
+ *   k-major operand, M resp. N for a transposed one) -- 16-byte vector loads run along it.
  *   splits > 1: K is cut into `splits` ranges, partial products go to `slabs` ([splits][M][N]) and are
  *   summed deterministically into C (bias added once).  accumulate != 0: C += result.
  * ---------------------------------------------------------------------------------------------- */

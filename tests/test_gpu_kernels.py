@@ -125,7 +125,7 @@ def test_gemm(ops, m, n, k, ta, tb, bias, splits):
     acc = ops.gemm(dev(a), dev(b), m, n, k, a.shape[1], b.shape[1], trans_a=ta, trans_b=tb, out=out.clone(),
                    accumulate=True, splits=splits)
     torch.cuda.synchronize()
-    assert_close(acc, 2 * ref, 3e-5, "gemm accumulate")
+    assert_close(acc, 2 * ref - (bv if bias else 0), 3e-5, "gemm accumulate (bias only in the first call)")
 
 
 def test_colsum_and_elementwise(ops):
@@ -404,13 +404,37 @@ def test_wrapper_model_matches_reference_golden(ops):
     assert_close(y, torch.from_numpy(g["y_train"]), 1e-3, "encoder train output vs reference")
     named = dict(model.encoder.named_parameters())
     sd = model.encoder.state_dict()
+    # Gradients of the early layers are ill-conditioned in fp32 (34 normalised layers on a 2 x 64 x 64 input): the
+    # reference's OWN fp32 gradients deviate from an fp64 evaluation of the same graph by up to 2.6e-3 of their
+    # absmax.  So: (a) vs the reference golden at 1e-2, and (b) vs an fp64 evaluation of the oracle at
+    # max(1e-3, 2 x the reference's own fp32 deviation from fp64).
+    from oracle import seresnet as onet
+    from oracle.filler import fill_state_dict
+    enc64, _ = onet.split_state_dict(fill_state_dict(onet.state_dict_spec()))
+    enc64 = {k: (v.double() if v.is_floating_point() else v) for k, v in enc64.items()}
+    for k, v in enc64.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    y64 = onet.encoder_forward(enc64, x.double(), training=True)
+    (y64 * torch.from_numpy(g["probe"]).double()).sum().backward()
+    worst = 0.0
     for key in g.files:
         if key.startswith("grad_"):
-            got = named[key[5:]].grad.reshape(-1)[:g[key].size]
-            assert_close(got, torch.from_numpy(g[key].reshape(-1)), 2e-3, key)
+            ref = torch.from_numpy(g[key].reshape(-1))
+            got = named[key[5:]].grad.reshape(-1)[:ref.numel()].cpu()
+            t64 = enc64[key[5:]].grad.reshape(-1)[:ref.numel()]
+            am = float(t64.abs().max())
+            if am < 1e-9:
+                continue
+            ref_noise = float((ref.double() - t64).abs().max()) / am
+            mine = float((got.double() - t64).abs().max()) / am
+            worst = max(worst, mine)
+            assert mine <= max(1e-3, 2.0 * ref_noise), "%s: %.2e of absmax vs fp64 (reference fp32: %.2e)" % (key, mine, ref_noise)
+            assert_close(got, ref, 1e-2, key + " vs reference golden")
         if key.startswith("stat_") and not key.endswith("num_batches_tracked"):
             assert_close(sd[key[5:]], torch.from_numpy(g[key]), 1e-4, key)
     assert int(sd["bn1.num_batches_tracked"]) == int(g["stat_bn1.num_batches_tracked"])
+    print("worst gradient deviation from fp64: %.2e of absmax" % worst)
 
 
 def test_adam_matches_torch(ops):
