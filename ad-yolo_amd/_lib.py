@@ -37,7 +37,8 @@ SIGNATURES = {
     "adyolo_se_fc_fwd": (I, [P] * 10 + [I, I, I, I, P]),
     "adyolo_se_tail_fwd": (I, [P] * 6 + [I, I, I, P]),
     "adyolo_se_tail_bwd_reduce": (I, [P] * 8 + [I, I, I, P]),
-    "adyolo_se_fc_bwd": (I, [P] * 21 + [I, I, I, I, P]),
+    "adyolo_se_fc_bwd_words": (L, [I, I]),
+    "adyolo_se_fc_bwd": (I, [P] * 16 + [I, I, I, I, P]),
     "adyolo_se_tail_bwd_apply": (I, [P] * 12 + [I, I, I, P]),
     "adyolo_avgpool2_fwd": (I, [P, P, I, I, I, I, P]),
     "adyolo_avgpool2_bwd": (I, [P, P, I, I, I, I, P]),

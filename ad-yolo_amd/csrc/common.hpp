@@ -53,4 +53,24 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Sum `nparts` partial rows of a [nparts][ld] fp32 array for 32 consecutive columns starting at c0, in double.
+// Call from a 256-thread workgroup (32 columns x 8 part-groups); returns the column total in threads with
+// (threadIdx.x >> 5) == 0 (valid for c0 + (threadIdx.x & 31) < C).  `red` = 256 doubles of LDS.
+__device__ __forceinline__ double block_colsum32(const float *__restrict__ partial, int nparts, size_t ld, int c0,
+                                                 int C, double *red) {
+    const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+    const int c = c0 + cx;
+    double s = 0.0;
+    if (c < C)
+        for (int p = py; p < nparts; p += 8) s += (double)partial[(size_t)p * ld + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (py == 0) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) s += red[k * 32 + cx];
+    }
+    __syncthreads();
+    return s;
+}
+
 }  // namespace adyolo

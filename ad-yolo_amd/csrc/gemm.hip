@@ -139,22 +139,28 @@ __global__ void gemm_slab_reduce_kernel(const float *__restrict__ slabs, const f
     C[o] = s;
 }
 
-// column sums: stage 1 partial[blk][c] over a strip of rows, stage 2 sums the partials in double.
-__global__ void colsum_partial_kernel(const float *__restrict__ A, float *__restrict__ partial, long R, int C,
-                                      int lda) {
-    const int c = blockIdx.y * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// column sums: stage 1 partial[blk][c] over a strip of rows (64 columns x 4 row-lanes per workgroup, LDS
+// combine), stage 2 sums the partials in double (32 columns x 8 part-groups per workgroup).
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ A, float *__restrict__ partial,
+                                                             long R, int C, int lda, long rows_per_block) {
+    __shared__ float red[256];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cx;
+    const long rbeg = (long)blockIdx.x * rows_per_block;
+    const long rend = rbeg + rows_per_block < R ? rbeg + rows_per_block : R;
     float s = 0.f;
-    for (long r = blockIdx.x; r < R; r += gridDim.x) s += A[(size_t)r * lda + c];
-    partial[(size_t)blockIdx.x * C + c] = s;
+    if (c < C)
+        for (long r = rbeg + ry; r < rend; r += 4) s += A[(size_t)r * lda + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (ry == 0 && c < C) partial[(size_t)blockIdx.x * C + c] = red[cx] + red[64 + cx] + red[128 + cx] + red[192 + cx];
 }
-__global__ void colsum_final_kernel(const float *__restrict__ partial, float *__restrict__ out, int nblk, int C,
-                                    int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * C + c];
-    out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ partial, float *__restrict__ out,
+                                                           int nblk, int C, int accumulate) {
+    __shared__ double red[256];
+    const double s = block_colsum32(partial, nblk, (size_t)C, blockIdx.x * 32, C, red);
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    if ((threadIdx.x >> 5) == 0 && c < C) out[c] = (accumulate ? out[c] : 0.f) + (float)s;
 }
 
 __global__ void add_kernel(const float4 *__restrict__ a, const float4 *__restrict__ b, float4 *__restrict__ y,
@@ -231,12 +237,14 @@ extern "C" int adyolo_colsum(const float *A, float *out, float *partial, int R, 
                              void *stream) {
     ADYOLO_REQUIRE(A && out && partial && R > 0 && C > 0, ADYOLO_EINVAL, "colsum: bad arguments");
     hipStream_t st = as_stream(stream);
-    const int nblk = R < 256 ? R : 256;
-    const int tx = C >= 256 ? 256 : 64;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, cdiv(C, tx)), dim3(tx), 0, st, A, partial, (long)R, C, lda);
+    int nblk = cdiv(R, 64);
+    if (nblk > 1024) nblk = 1024;
+    const long rpb = ((long)R + nblk - 1) / nblk;
+    nblk = cdiv(R, rpb);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, cdiv(C, 64)), dim3(256), 0, st, A, partial, (long)R, C, lda, rpb);
     int rc = check_launch("colsum_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, partial, out, nblk, C, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, partial, out, nblk, C, accumulate);
     return check_launch("colsum_final");
 }
 

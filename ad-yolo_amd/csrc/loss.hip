@@ -195,23 +195,29 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const float *__restrict_
             red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ void loss_final_kernel(const float *__restrict__ partial, int nblk, const float *__restrict__ ang_partial,
-                                  int nang, const unsigned *__restrict__ hdr, LossGeom g, long NA,
-                                  float *__restrict__ loss) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double s[9];
-    for (int i = 0; i < 9; ++i) s[i] = 0.0;
-    for (int b = 0; b < nblk; ++b)
-        for (int i = 0; i < 9; ++i) s[i] += (double)partial[(size_t)b * 9 + i];
-    double ang = 0.0;
-    for (int b = 0; b < nang; ++b) ang += (double)ang_partial[b];
-    double total = (double)g.gain_ang * ang / (double)hdr[3];
-    for (int i = 0; i < 3; ++i) {
-        const double np_ = (double)hdr[i], nn_ = (double)(NA - (long)hdr[i]);
-        total += ((double)g.gain_obj * s[i] / np_ + (double)g.gain_nonobj * s[3 + i] / nn_ +
-                  (double)g.gain_cls * s[6 + i] / (np_ * (double)g.C)) / 3.0;
+__global__ __launch_bounds__(256) void loss_final_kernel(const float *__restrict__ partial, int nblk,
+                                                         const float *__restrict__ ang_partial, int nang,
+                                                         const unsigned *__restrict__ hdr, LossGeom g, long NA,
+                                                         float *__restrict__ loss) {
+    __shared__ double red[256];
+    __shared__ double tot[10];
+    const double s = block_colsum32(partial, nblk, 9, 0, 9, red);        // 9 BCE sums
+    if ((threadIdx.x >> 5) == 0 && (threadIdx.x & 31) < 9) tot[threadIdx.x & 31] = s;
+    double a = 0.0;
+    for (int b = threadIdx.x; b < nang; b += 256) a += (double)ang_partial[b];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ang = 0.0;
+        for (int k = 0; k < 256; ++k) ang += red[k];
+        double total = (double)g.gain_ang * ang / (double)hdr[3];
+        for (int i = 0; i < 3; ++i) {
+            const double np_ = (double)hdr[i], nn_ = (double)(NA - (long)hdr[i]);
+            total += ((double)g.gain_obj * tot[i] / np_ + (double)g.gain_nonobj * tot[3 + i] / nn_ +
+                      (double)g.gain_cls * tot[6 + i] / (np_ * (double)g.C)) / 3.0;
+        }
+        loss[0] = (float)total;
     }
-    loss[0] = (float)total;
 }
 
 constexpr int LOSS_MAIN_BLOCKS = 2048;
@@ -266,7 +272,7 @@ extern "C" int adyolo_loss_fwd_bwd(const float *logit, const float *target, floa
                        ang_grad, dlogit, partial, NA, grad_scale);
     rc = check_launch("loss_main");
     if (rc) return rc;
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, partial, (int)nb, ang_partial, nang, hdr, g, NA,
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, partial, (int)nb, ang_partial, nang, hdr, g, NA,
                        loss);
     return check_launch("loss_final");
 }

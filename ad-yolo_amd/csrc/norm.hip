@@ -83,45 +83,35 @@ struct SeBwdF {          // g = de * (e > 0): (g, g * xhat(c))
     }
 };
 
-// finish: per-sample sums out0[n][c] (optional), per-sample out1[n][c] (optional), batch totals tot0/tot1 [C]
-__global__ void reduce2_final_kernel(const float *__restrict__ partial, float *__restrict__ out0,
-                                     float *__restrict__ out1, float *__restrict__ tot0,
-                                     float *__restrict__ tot1, int N, int G, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// stage 2: per-sample sums of the two reduced quantities (32 channels x 8 part-groups per workgroup, double)
+// grid (ceil(C/32), N)
+__global__ __launch_bounds__(256) void persample_reduce_kernel(const float *__restrict__ partial,
+                                                               float *__restrict__ out0, float *__restrict__ out1,
+                                                               int N, int G, int C) {
+    __shared__ double red[256];
+    const int n = blockIdx.y, c0 = blockIdx.x * 32;
     const size_t half = (size_t)N * G * C;
-    double t0 = 0.0, t1 = 0.0;
-    for (int n = 0; n < N; ++n) {
-        double s0 = 0.0, s1 = 0.0;
-        for (int g = 0; g < G; ++g) {
-            s0 += (double)partial[((size_t)n * G + g) * C + c];
-            s1 += (double)partial[half + ((size_t)n * G + g) * C + c];
-        }
-        if (out0) out0[(size_t)n * C + c] = (float)s0;
-        if (out1) out1[(size_t)n * C + c] = (float)s1;
-        t0 += s0;
-        t1 += s1;
+    const float *base = partial + (size_t)n * G * C;
+    const double s0 = block_colsum32(base, G, (size_t)C, c0, C, red);
+    const double s1 = block_colsum32(base + half, G, (size_t)C, c0, C, red);
+    const int c = c0 + (threadIdx.x & 31);
+    if ((threadIdx.x >> 5) == 0 && c < C) {
+        out0[(size_t)n * C + c] = (float)s0;
+        out1[(size_t)n * C + c] = (float)s1;
     }
-    if (tot0) tot0[c] = (float)t0;
-    if (tot1) tot1[c] = (float)t1;
 }
 
-__global__ void bn_stats_final_kernel(const float *__restrict__ partial, float *__restrict__ ssum,
+// stage 3 (BatchNorm forward): batch mean / invstd from the per-sample sums, running statistics update
+__global__ void bn_stats_final_kernel(const float *__restrict__ ps0, const float *__restrict__ ps1,
                                       float *__restrict__ mean, float *__restrict__ invstd,
-                                      float *__restrict__ rmean, float *__restrict__ rvar, int N, int G, int C,
-                                      double R, float momentum, float eps) {
+                                      float *__restrict__ rmean, float *__restrict__ rvar, int N, int C, double R,
+                                      float momentum, float eps) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const size_t half = (size_t)N * G * C;
     double t0 = 0.0, t1 = 0.0;
     for (int n = 0; n < N; ++n) {
-        double s0 = 0.0;
-        for (int g = 0; g < G; ++g) {
-            s0 += (double)partial[((size_t)n * G + g) * C + c];
-            t1 += (double)partial[half + ((size_t)n * G + g) * C + c];
-        }
-        if (ssum) ssum[(size_t)n * C + c] = (float)s0;
-        t0 += s0;
+        t0 += (double)ps0[(size_t)n * C + c];
+        t1 += (double)ps1[(size_t)n * C + c];
     }
     const double m = t0 / R;
     double var = t1 / R - m * m;
@@ -256,82 +246,64 @@ __global__ __launch_bounds__(256) void se_tail_fwd_kernel(
     }
 }
 
-// single workgroup walks the batch: tiny (N*C*Cr) and keeps parameter-gradient sums deterministic
-__global__ __launch_bounds__(256) void se_fc_bwd_kernel(
+// One workgroup per sample: dpool[n][:] and this sample's contribution to every parameter gradient / batch sum,
+// written to part[n][P] with P = 2*C*Cr + Cr + 3*C laid out [dw1 Cr*C | db1 Cr | dw2 C*Cr | db2 C | sdd C | sddx C];
+// a deterministic column sum over the N rows finishes the job.
+__global__ __launch_bounds__(256) void se_fc_bwd_sample_kernel(
     const float *__restrict__ sg, const float *__restrict__ sgx, const float *__restrict__ ssum,
     const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ mean,
     const float *__restrict__ invstd, const float *__restrict__ pooled, const float *__restrict__ hid,
     const float *__restrict__ s, const float *__restrict__ w1, const float *__restrict__ w2,
-    float *__restrict__ dw1, float *__restrict__ db1, float *__restrict__ dw2, float *__restrict__ db2,
-    float *__restrict__ dpool, float *__restrict__ sdd, float *__restrict__ sddx, float *__restrict__ dgamma,
-    float *__restrict__ dbeta, int N, int HW, int C, int Cr) {
-    // thread c owns channel c (C <= 256); Cr <= 32
-    __shared__ float dz2[256];
-    __shared__ float dz1[32];
-    __shared__ float hd[32];
-    const int c = threadIdx.x;
-    const bool act = c < C;
-    float a_dw2[32], a_dw1[32];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) { a_dw2[j] = 0.f; a_dw1[j] = 0.f; }
-    float a_db2 = 0.f, a_sdd = 0.f, a_sddx = 0.f, a_db1 = 0.f;
-    const float g_c = act ? gamma[c] : 0.f, b_c = act ? beta[c] : 0.f;
-    const float m_c = act ? mean[c] : 0.f, is_c = act ? invstd[c] : 0.f;
+    float *__restrict__ dpool, float *__restrict__ part, int HW, int C, int Cr) {
+    __shared__ float dz2[1024];
+    __shared__ float pl[1024];
+    __shared__ float hd[128];
+    __shared__ float dz1[128];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t P = (size_t)2 * C * Cr + Cr + 3 * (size_t)C;
+    float *p_dw1 = part + (size_t)n * P;
+    float *p_db1 = p_dw1 + (size_t)Cr * C;
+    float *p_dw2 = p_db1 + Cr;
+    float *p_db2 = p_dw2 + (size_t)C * Cr;
+    float *p_sdd = p_db2 + C;
+    float *p_sddx = p_sdd + C;
     const float invHW = 1.0f / (float)HW;
-    for (int n = 0; n < N; ++n) {
-        float sgv = 0.f, sgxv = 0.f, sv = 0.f, z2 = 0.f;
-        if (act) {
-            sgv = sg[(size_t)n * C + c];
-            sgxv = sgx[(size_t)n * C + c];
-            sv = s[(size_t)n * C + c];
-            const float ds = g_c * sgxv + b_c * sgv;      // sum_hw g * d,  d = xhat*gamma + beta
-            z2 = ds * sv * (1.f - sv);
-            a_db2 += z2;
-        }
-        __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const float sgv = sg[(size_t)n * C + c], sgxv = sgx[(size_t)n * C + c], sv = s[(size_t)n * C + c];
+        const float ds = gamma[c] * sgxv + beta[c] * sgv;           // sum_hw g * d,  d = xhat*gamma + beta
+        const float z2 = ds * sv * (1.f - sv);
         dz2[c] = z2;
-        if (c < Cr) hd[c] = hid[(size_t)n * Cr + c];
-        __syncthreads();
-        if (c < Cr) {
-            float dh = 0.f;
-            for (int k = 0; k < C; ++k) dh += dz2[k] * w2[(size_t)k * Cr + c];
-            const float z1 = hd[c] > 0.f ? dh : 0.f;
-            dz1[c] = z1;
-            a_db1 += z1;
-        }
-        __syncthreads();
-        if (act) {
-            const float pc = pooled[(size_t)n * C + c];
-            float dp = 0.f;
-#pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                if (j < Cr) {
-                    a_dw2[j] += z2 * hd[j];
-                    a_dw1[j] += dz1[j] * pc;
-                    dp += dz1[j] * w1[(size_t)j * C + c];
-                }
-            }
-            // pooled = scale*mean_hw(c)+shift  -> d(pooled)/d(d at each pixel) = 1/HW
-            dpool[(size_t)n * C + c] = dp;
-            const float sxhat = (ssum[(size_t)n * C + c] - (float)HW * m_c) * is_c;   // sum_hw xhat
-            a_sdd += sv * sgv + dp;
-            a_sddx += sv * sgxv + dp * invHW * sxhat;
+        pl[c] = pooled[(size_t)n * C + c];
+        p_db2[c] = z2;
+    }
+    for (int j = tid; j < Cr; j += 256) hd[j] = hid[(size_t)n * Cr + j];
+    __syncthreads();
+    for (int j = wave; j < Cr; j += 4) {
+        float dh = 0.f;
+        for (int c = lane; c < C; c += 64) dh += dz2[c] * w2[(size_t)c * Cr + j];
+        dh = wave_sum(dh);
+        if (lane == 0) {
+            const float z1 = hd[j] > 0.f ? dh : 0.f;
+            dz1[j] = z1;
+            p_db1[j] = z1;
         }
     }
-    if (act) {
-        db2[c] += a_db2;
-        sdd[c] = a_sdd;
-        sddx[c] = a_sddx;
-        if (dgamma) dgamma[c] += a_sddx;
-        if (dbeta) dbeta[c] += a_sdd;
-#pragma unroll
-        for (int j = 0; j < 32; ++j)
-            if (j < Cr) {
-                dw2[(size_t)c * Cr + j] += a_dw2[j];
-                dw1[(size_t)j * C + c] += a_dw1[j];
-            }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const float z2 = dz2[c], pc = pl[c];
+        float dp = 0.f;
+        for (int j = 0; j < Cr; ++j) {
+            const float z1 = dz1[j];
+            dp += z1 * w1[(size_t)j * C + c];
+            p_dw1[(size_t)j * C + c] = z1 * pc;
+            p_dw2[(size_t)c * Cr + j] = z2 * hd[j];
+        }
+        dpool[(size_t)n * C + c] = dp;
+        const float sv = s[(size_t)n * C + c];
+        const float sxhat = (ssum[(size_t)n * C + c] - (float)HW * mean[c]) * invstd[c];     // sum_hw xhat
+        p_sdd[c] = sv * sg[(size_t)n * C + c] + dp;
+        p_sddx[c] = sv * sgx[(size_t)n * C + c] + dp * invHW * sxhat;
     }
-    if (c < Cr) db1[c] += a_db1;
 }
 
 __global__ __launch_bounds__(256) void se_tail_bwd_apply_kernel(
@@ -418,6 +390,7 @@ static inline int pick_G(int N, int HW) {
 
 using namespace adyolo;
 
+// workspace `partial`: 4*1024*C floats = [2*1024*C stage-1 partials][1024*C per-sample sum][1024*C per-sample sum-sq]
 extern "C" int adyolo_bn_stats(const float *x, float *ssum, float *mean, float *invstd, float *running_mean,
                                float *running_var, float *partial, int N, int HW, int C, float momentum, float eps,
                                void *stream) {
@@ -429,8 +402,13 @@ extern "C" int adyolo_bn_stats(const float *x, float *ssum, float *mean, float *
     hipLaunchKernelGGL((reduce2_partial_kernel<StatsF>), dim3(G, N), dim3(256), 0, st, f, partial, HW, C, G);
     int rc = check_launch("bn_stats_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, partial, ssum, mean, invstd,
-                       running_mean, running_var, N, G, C, (double)N * (double)HW, momentum, eps);
+    float *ps0 = ssum ? ssum : partial + (size_t)2 * 1024 * C;
+    float *ps1 = partial + (size_t)3 * 1024 * C;
+    hipLaunchKernelGGL(persample_reduce_kernel, dim3(cdiv(C, 32), N), dim3(256), 0, st, partial, ps0, ps1, N, G, C);
+    rc = check_launch("bn_stats_persample");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, ps0, ps1, mean, invstd, running_mean,
+                       running_var, N, C, (double)N * (double)HW, momentum, eps);
     return check_launch("bn_stats_final");
 }
 
@@ -470,8 +448,7 @@ extern "C" int adyolo_bn_bwd_reduce(const float *dy, const float *x, const float
     hipLaunchKernelGGL((reduce2_partial_kernel<BnBwdF>), dim3(G, 1), dim3(256), 0, st, f, partial, HW, C, G);
     int rc = check_launch("bn_bwd_reduce_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(reduce2_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, partial, (float *)nullptr,
-                       (float *)nullptr, sdy, sdyx, 1, G, C);
+    hipLaunchKernelGGL(persample_reduce_kernel, dim3(cdiv(C, 32), 1), dim3(256), 0, st, partial, sdy, sdyx, 1, G, C);
     return check_launch("bn_bwd_reduce_final");
 }
 
@@ -528,24 +505,27 @@ extern "C" int adyolo_se_tail_bwd_reduce(const float *de, const float *e, const 
     hipLaunchKernelGGL((reduce2_partial_kernel<SeBwdF>), dim3(G, N), dim3(256), 0, st, f, partial, HW, C, G);
     int rc = check_launch("se_tail_bwd_reduce_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(reduce2_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, partial, sg, sgx, (float *)nullptr,
-                       (float *)nullptr, N, G, C);
+    hipLaunchKernelGGL(persample_reduce_kernel, dim3(cdiv(C, 32), N), dim3(256), 0, st, partial, sg, sgx, N, G, C);
     return check_launch("se_tail_bwd_reduce_final");
 }
 
+extern "C" long adyolo_se_fc_bwd_words(int C, int Cr) { return 2L * C * Cr + Cr + 3L * C; }
+
 extern "C" int adyolo_se_fc_bwd(const float *sg, const float *sgx, const float *ssum, const float *gamma,
                                 const float *beta, const float *mean, const float *invstd, const float *pooled,
-                                const float *hid, const float *s, const float *w1, const float *w2, float *dw1,
-                                float *db1, float *dw2, float *db2, float *dpool, float *sdd, float *sddx,
-                                float *dgamma, float *dbeta, int N, int HW, int C, int Cr, void *stream) {
-    ADYOLO_REQUIRE(sg && sgx && ssum && gamma && beta && mean && invstd && pooled && hid && s && w1 && w2 && dw1 &&
-                       db1 && dw2 && db2 && dpool && sdd && sddx && N > 0,
+                                const float *hid, const float *s, const float *w1, const float *w2, float *dpool,
+                                float *part, float *packed, float *colsum_ws, int N, int HW, int C, int Cr,
+                                void *stream) {
+    ADYOLO_REQUIRE(sg && sgx && ssum && gamma && beta && mean && invstd && pooled && hid && s && w1 && w2 && dpool &&
+                       part && packed && colsum_ws && N > 0,
                    ADYOLO_EINVAL, "se_fc_bwd: bad arguments");
-    ADYOLO_REQUIRE(C <= 256 && Cr <= 32, ADYOLO_ENOSUP, "se_fc_bwd: C=%d (<=256) Cr=%d (<=32)", C, Cr);
-    hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), sg, sgx, ssum, gamma, beta, mean,
-                       invstd, pooled, hid, s, w1, w2, dw1, db1, dw2, db2, dpool, sdd, sddx, dgamma, dbeta, N, HW, C,
-                       Cr);
-    return check_launch("se_fc_bwd");
+    ADYOLO_REQUIRE(C <= 1024 && Cr <= 128, ADYOLO_ENOSUP, "se_fc_bwd: C=%d (<=1024) Cr=%d (<=128)", C, Cr);
+    hipLaunchKernelGGL(se_fc_bwd_sample_kernel, dim3(N), dim3(256), 0, as_stream(stream), sg, sgx, ssum, gamma, beta,
+                       mean, invstd, pooled, hid, s, w1, w2, dpool, part, HW, C, Cr);
+    int rc = check_launch("se_fc_bwd_sample");
+    if (rc) return rc;
+    const long P = adyolo_se_fc_bwd_words(C, Cr);
+    return adyolo_colsum(part, packed, colsum_ws, N, (int)P, (int)P, 0, stream);
 }
 
 extern "C" int adyolo_se_tail_bwd_apply(const float *de, const float *e, const float *c, const float *gamma,

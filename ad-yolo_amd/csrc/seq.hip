@@ -103,14 +103,15 @@ __global__ __launch_bounds__(256) void sap_bwd_kernel(const float *__restrict__ 
         partial[(size_t)blockIdx.x * 260 + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
-__global__ void sap_bwd_final_kernel(const float *__restrict__ partial, float *__restrict__ dw, float *__restrict__ db,
-                                     int nblk) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c > 256) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * 260 + c];
-    if (c < 256) dw[c] += (float)s;
-    else db[0] += (float)s;
+__global__ __launch_bounds__(256) void sap_bwd_final_kernel(const float *__restrict__ partial, float *__restrict__ dw,
+                                                            float *__restrict__ db, int nblk) {
+    __shared__ double red[256];
+    const double s = block_colsum32(partial, nblk, 260, blockIdx.x * 32, 257, red);
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    if ((threadIdx.x >> 5) == 0 && c <= 256) {
+        if (c < 256) dw[c] += (float)s;
+        else db[0] += (float)s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------- GRU (H = 128)
@@ -290,14 +291,16 @@ __global__ __launch_bounds__(256) void ln_tanh_bwd_kernel(const float *__restric
     for (int c = threadIdx.x; c < 512; c += 256)
         partial[(size_t)blockIdx.x * 512 + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
-__global__ void ln_bwd_final_kernel(const float *__restrict__ partial, float *__restrict__ dgamma,
-                                    float *__restrict__ dbeta, int nblk) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 512) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * 512 + c];
-    if (c < 256) dgamma[c] += (float)s;
-    else dbeta[c - 256] += (float)s;
+__global__ __launch_bounds__(256) void ln_bwd_final_kernel(const float *__restrict__ partial,
+                                                           float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                           int nblk) {
+    __shared__ double red[256];
+    const double s = block_colsum32(partial, nblk, 512, blockIdx.x * 32, 512, red);
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    if ((threadIdx.x >> 5) == 0) {
+        if (c < 256) dgamma[c] += (float)s;
+        else dbeta[c - 256] += (float)s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------- dropout mask
@@ -346,7 +349,7 @@ extern "C" int adyolo_sap_bwd(const float *dy, const float *x, const float *w, c
     else hipLaunchKernelGGL((sap_bwd_kernel<4>), dim3(nblk), dim3(256), 0, st, dy, x, w, attn, dx, partial, R, rpb);
     int rc = check_launch("sap_bwd");
     if (rc) return rc;
-    hipLaunchKernelGGL(sap_bwd_final_kernel, dim3(2), dim3(256), 0, st, partial, dw, db, nblk);
+    hipLaunchKernelGGL(sap_bwd_final_kernel, dim3(9), dim3(256), 0, st, partial, dw, db, nblk);
     return check_launch("sap_bwd_final");
 }
 
@@ -383,7 +386,7 @@ extern "C" int adyolo_ln_tanh_bwd(const float *dy, const float *x, const float *
     hipLaunchKernelGGL(ln_tanh_bwd_kernel, dim3(nblk), dim3(256), 0, st, dy, x, y, gamma, dx, partial, R, rpb, eps);
     int rc = check_launch("ln_tanh_bwd");
     if (rc) return rc;
-    hipLaunchKernelGGL(ln_bwd_final_kernel, dim3(2), dim3(256), 0, st, partial, dgamma, dbeta, nblk);
+    hipLaunchKernelGGL(ln_bwd_final_kernel, dim3(16), dim3(256), 0, st, partial, dgamma, dbeta, nblk);
     return check_launch("ln_bwd_final");
 }
 

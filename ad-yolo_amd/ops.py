@@ -119,7 +119,7 @@ def colsum(a2d, out=None, accumulate=False):
     if out is None:
         out = _new(a2d, c)
         accumulate = False
-    partial = _new(a2d, 256, c)
+    partial = _new(a2d, 1024, c)
     _c("adyolo_colsum", _p(a2d), _p(out), _p(partial), r, c, a2d.stride(0), int(accumulate), _stream())
     return out
 
@@ -153,7 +153,7 @@ def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
     n, c = x.shape[0], x.shape[-1]
     hw = x.numel() // (n * c)
     ssum, mean, invstd = _new(x, n, c), _new(x, c), _new(x, c)
-    partial = _new(x, 2 * 1024 * c)
+    partial = _new(x, 4 * 1024 * c)
     _c("adyolo_bn_stats", _p(x), _p(ssum), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(partial), n,
        hw, c, momentum, eps, _stream())
     return ssum, mean, invstd
@@ -227,13 +227,19 @@ def se_tail_bwd(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1,
     partial = _new(c_t, 2 * 1024 * ch)
     _c("adyolo_se_tail_bwd_reduce", _p(de), _p(e), _p(c_t), _p(mean), _p(invstd), _p(sg), _p(sgx), _p(partial), n, hw,
        ch, _stream())
-    dw1, db1 = _zeros(c_t, cr, ch), _zeros(c_t, cr)
-    dw2, db2 = _zeros(c_t, ch, cr), _zeros(c_t, ch)
-    dgamma, dbeta = _zeros(c_t, ch), _zeros(c_t, ch)
-    dpool, sdd, sddx = _new(c_t, n, ch), _new(c_t, ch), _new(c_t, ch)
+    pw = 2 * ch * cr + cr + 3 * ch
+    part, packed, cws = _new(c_t, n, pw), _new(c_t, pw), _new(c_t, 1024, pw)
+    dpool = _new(c_t, n, ch)
     _c("adyolo_se_fc_bwd", _p(sg), _p(sgx), _p(ssum), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(pooled), _p(hid),
-       _p(s), _p(w1), _p(w2), _p(dw1), _p(db1), _p(dw2), _p(db2), _p(dpool), _p(sdd), _p(sddx), _p(dgamma), _p(dbeta),
-       n, hw, ch, cr, _stream())
+       _p(s), _p(w1), _p(w2), _p(dpool), _p(part), _p(packed), _p(cws), n, hw, ch, cr, _stream())
+    o = 0
+    dw1 = packed[o:o + cr * ch].view(cr, ch); o += cr * ch
+    db1 = packed[o:o + cr]; o += cr
+    dw2 = packed[o:o + ch * cr].view(ch, cr); o += ch * cr
+    db2 = packed[o:o + ch]; o += ch
+    sdd = packed[o:o + ch]; o += ch
+    sddx = packed[o:o + ch]
+    dgamma, dbeta = sddx, sdd
     dc, dr = torch.empty_like(c_t), torch.empty_like(c_t)
     _c("adyolo_se_tail_bwd_apply", _p(de), _p(e), _p(c_t), _p(gamma), _p(mean), _p(invstd), _p(s), _p(dpool), _p(sdd),
        _p(sddx), _p(dc), _p(dr), n, hw, ch, _stream())

@@ -89,7 +89,7 @@ int adyolo_conv3x3_wgrad(const float *x, const float *dy, float *slabs, float *d
 int adyolo_gemm(const float *A, const float *B, const float *bias, float *C, float *slabs, int M,
                 int N, int K, int lda, int ldb, int ldc, int transA, int transB, int splits,
                 int accumulate, void *stream);
-/* out[c] (+)= sum_r A[r*lda + c], deterministic two-stage; partial: [256][C] workspace */
+/* out[c] (+)= sum_r A[r*lda + c], deterministic two-stage; partial: [1024][C] workspace */
 int adyolo_colsum(const float *A, float *out, float *partial, int R, int C, int lda, int accumulate,
                   void *stream);
 
@@ -98,7 +98,7 @@ int adyolo_colsum(const float *A, float *out, float *partial, int R, int C, int 
  *     replaces nn.BatchNorm2d at resnet.py:17,19,144,163 (momentum 0.1, eps 1e-5).
  *   adyolo_bn_stats: per-sample channel sums  ssum[N][C]  (these are also the SE squeeze, K3b) and
  *     mean/invstd [C] of the whole batch; updates running_mean / running_var (unbiased) in place when
- *     they are non-NULL.  partial: workspace of 2*1024*C floats.
+ *     they are non-NULL.  partial: workspace of 4*1024*C floats.
  *   adyolo_bn_scale_shift: scale = gamma*invstd, shift = beta - mean*scale   (train)
  *     or from running stats when mean == NULL is not allowed: pass running_mean/invstd computed by
  *     adyolo_bn_eval_stats.
@@ -129,8 +129,10 @@ int adyolo_bn_bwd_apply(const float *dy, const float *x, const float *gamma, con
  *                     s = sigmoid(W2 hid + b2) [N][C]
  *   adyolo_se_tail_fwd: e = relu((c*scale+shift)*s[n][c] + r)
  *   adyolo_se_tail_bwd_reduce: g = de*(e>0);  sg[n][c] = sum_hw g;  sgx[n][c] = sum_hw g*xhat
- *   adyolo_se_fc_bwd: from sg, sgx: ds -> dW2, db2, dW1, db1 (accumulated) and dpool[n][c]; also the
- *                     batch sums needed by bn2's backward: sdd[c] = sum dd, sddx[c] = sum dd*xhat
+ *   adyolo_se_fc_bwd: from sg, sgx: dpool[n][c] and, packed as [dW1 Cr*C | db1 Cr | dW2 C*Cr | db2 C | sdd C | sddx C]
+ *                     (P words, one workgroup per sample + a deterministic column sum over the batch), the FC
+ *                     gradients and the batch sums bn2's backward needs: sdd[c] = sum dd (= dbeta2),
+ *                     sddx[c] = sum dd*xhat (= dgamma2)
  *   adyolo_se_tail_bwd_apply: dc = scale*( g*s + dpool/HW - sdd/R - xhat*sddx/R ),  dr = g
  * ---------------------------------------------------------------------------------------------- */
 int adyolo_se_fc_fwd(const float *ssum, const float *scale, const float *shift, const float *w1,
@@ -141,11 +143,12 @@ int adyolo_se_tail_fwd(const float *c, const float *r, const float *scale, const
 int adyolo_se_tail_bwd_reduce(const float *de, const float *e, const float *c, const float *mean,
                               const float *invstd, float *sg, float *sgx, float *partial, int N,
                               int HW, int C, void *stream);
+long adyolo_se_fc_bwd_words(int C, int Cr);   /* P = 2*C*Cr + Cr + 3*C */
 int adyolo_se_fc_bwd(const float *sg, const float *sgx, const float *ssum, const float *gamma,
                      const float *beta, const float *mean, const float *invstd, const float *pooled,
-                     const float *hid, const float *s, const float *w1, const float *w2, float *dw1,
-                     float *db1, float *dw2, float *db2, float *dpool, float *sdd, float *sddx,
-                     float *dgamma, float *dbeta, int N, int HW, int C, int Cr, void *stream);
+                     const float *hid, const float *s, const float *w1, const float *w2, float *dpool,
+                     float *part /*[N][P]*/, float *packed /*[P]*/, float *colsum_ws /*[1024][P]*/, int N,
+                     int HW, int C, int Cr, void *stream);
 int adyolo_se_tail_bwd_apply(const float *de, const float *e, const float *c, const float *gamma,
                              const float *mean, const float *invstd, const float *s,
                              const float *dpool, const float *sdd, const float *sddx, float *dc,
