@@ -78,36 +78,50 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(
     for (int ch = 0; ch < nchunks; ++ch) {
         const int c0 = ch * KC;
         __syncthreads();
-        for (int idx = tid; idx < NPIX * Q; idx += 256) {
-            const int pix = idx / Q, q = idx - pix * Q;
-            const int hy = pix / HW_, hx = pix - hy * HW_;
-            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = *reinterpret_cast<const float4 *>(x + (((size_t)n * H + gy) * W + gx) * Cin + c0 + q * 4);
-            *reinterpret_cast<float4 *>(&As[pix * AS + q * 4]) = v;
+        // stage the halo patch: issue every global load first (registers), then write LDS -- one exposed
+        // memory latency per chunk instead of one per 16-byte piece
+        constexpr int APT = (NPIX * Q + 255) / 256;
+        float4 av[APT];
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int idx = tid + i * 256;
+            av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < NPIX * Q) {
+                const int pix = idx / Q, q = idx - pix * Q;
+                const int hy = pix / HW_, hx = pix - hy * HW_;
+                const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                    av[i] = *reinterpret_cast<const float4 *>(x + (((size_t)n * H + gy) * W + gx) * Cin + c0 + q * 4);
+            }
         }
-        for (int idx = tid; idx < BN * Q; idx += 256) {
-            const int co = idx / Q, q = idx - co * Q;
-            *reinterpret_cast<float4 *>(&Ws[0][co * AS + q * 4]) =
-                *reinterpret_cast<const float4 *>(wpk + ((size_t)(co0 + co) * 9 + 0) * Cin + c0 + q * 4);
+        // (named registers, not an array: hipcc would otherwise promote the tiny array to LDS)
+        float4 w0a = make_float4(0.f, 0.f, 0.f, 0.f), w0b = w0a;
+        const int wco_a = tid / Q, wq_a = tid - wco_a * Q;
+        const int wco_b = (tid + 256) / Q, wq_b = (tid + 256) - wco_b * Q;
+        if (tid < BN * Q) w0a = *reinterpret_cast<const float4 *>(wpk + ((size_t)(co0 + wco_a) * 9 + 0) * Cin + c0 + wq_a * 4);
+        if (WPT > 1 && tid + 256 < BN * Q)
+            w0b = *reinterpret_cast<const float4 *>(wpk + ((size_t)(co0 + wco_b) * 9 + 0) * Cin + c0 + wq_b * 4);
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < NPIX * Q) {
+                const int pix = idx / Q, q = idx - pix * Q;
+                *reinterpret_cast<float4 *>(&As[pix * AS + q * 4]) = av[i];
+            }
         }
+        if (tid < BN * Q) *reinterpret_cast<float4 *>(&Ws[0][wco_a * AS + wq_a * 4]) = w0a;
+        if (WPT > 1 && tid + 256 < BN * Q) *reinterpret_cast<float4 *>(&Ws[0][wco_b * AS + wq_b * 4]) = w0b;
         __syncthreads();
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
             const int cur = tap & 1;
-            float4 wn[WPT];
+            float4 wna = make_float4(0.f, 0.f, 0.f, 0.f), wnb = wna;
             if (tap < 8) {
-#pragma unroll
-                for (int i = 0; i < WPT; ++i) {
-                    const int idx = tid + i * 256;
-                    if (idx < BN * Q) {
-                        const int co = idx / Q, q = idx - co * Q;
-                        wn[i] = *reinterpret_cast<const float4 *>(
-                            wpk + ((size_t)(co0 + co) * 9 + tap + 1) * Cin + c0 + q * 4);
-                    }
-                }
+                if (tid < BN * Q)
+                    wna = *reinterpret_cast<const float4 *>(wpk + ((size_t)(co0 + wco_a) * 9 + tap + 1) * Cin + c0 + wq_a * 4);
+                if (WPT > 1 && tid + 256 < BN * Q)
+                    wnb = *reinterpret_cast<const float4 *>(wpk + ((size_t)(co0 + wco_b) * 9 + tap + 1) * Cin + c0 + wq_b * 4);
             }
 #pragma unroll
             for (int s = 0; s < KC / 8; ++s) {
@@ -130,14 +144,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(
                     }
             }
             if (tap < 8) {
-#pragma unroll
-                for (int i = 0; i < WPT; ++i) {
-                    const int idx = tid + i * 256;
-                    if (idx < BN * Q) {
-                        const int co = idx / Q, q = idx - co * Q;
-                        *reinterpret_cast<float4 *>(&Ws[cur ^ 1][co * AS + q * 4]) = wn[i];
-                    }
-                }
+                if (tid < BN * Q) *reinterpret_cast<float4 *>(&Ws[cur ^ 1][wco_a * AS + wq_a * 4]) = wna;
+                if (WPT > 1 && tid + 256 < BN * Q) *reinterpret_cast<float4 *>(&Ws[cur ^ 1][wco_b * AS + wq_b * 4]) = wnb;
                 __syncthreads();
             }
         }
@@ -205,25 +213,44 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(
         const int n = b / tilesH;
         const int ty0 = th * TH, tx0 = tw * TW;
         __syncthreads();
-#pragma unroll 2
-        for (int idx = tid; idx < NPIX * 8; idx += 256) {
-            const int pix = idx >> 3, q = idx & 7;
-            const int hy = pix / HW_, hx = pix - hy * HW_;
-            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q * 4 < cvalid && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = *reinterpret_cast<const float4 *>(x + (((size_t)n * H + gy) * W + gx) * Cin + c0 + q * 4);
-            *reinterpret_cast<float4 *>(&Xs[pix * XS + q * 4]) = v;
+        {
+            constexpr int XPT = (NPIX * 8 + 255) / 256;
+            float4 xv[XPT];
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int idx = tid + i * 256;
+                xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < NPIX * 8) {
+                    const int pix = idx >> 3, q = idx & 7;
+                    const int hy = pix / HW_, hx = pix - hy * HW_;
+                    const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+                    if (q * 4 < cvalid && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                        xv[i] = *reinterpret_cast<const float4 *>(x + (((size_t)n * H + gy) * W + gx) * Cin + c0 + q * 4);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int idx = tid + i * 256;
+                if (idx < NPIX * 8) *reinterpret_cast<float4 *>(&Xs[(idx >> 3) * XS + (idx & 7) * 4]) = xv[i];
+            }
         }
-#pragma unroll 2
-        for (int idx = tid; idx < 256 * 8; idx += 256) {
-            const int pix = idx >> 3, q = idx & 7;
-            const int py = pix / TW, px = pix - py * TW;
-            const int gy = ty0 + py, gx = tx0 + px;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy < H && gx < W)
-                v = *reinterpret_cast<const float4 *>(dy + (((size_t)n * H + gy) * W + gx) * Cout + co0 + q * 4);
-            *reinterpret_cast<float4 *>(&Ds[pix * DS + q * 4]) = v;
+        {
+            float4 dv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = tid + i * 256;
+                const int pix = idx >> 3, q = idx & 7;
+                const int py = pix / TW, px = pix - py * TW;
+                const int gy = ty0 + py, gx = tx0 + px;
+                dv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gy < H && gx < W)
+                    dv[i] = *reinterpret_cast<const float4 *>(dy + (((size_t)n * H + gy) * W + gx) * Cout + co0 + q * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = tid + i * 256;
+                *reinterpret_cast<float4 *>(&Ds[(idx >> 3) * DS + (idx & 7) * 4]) = dv[i];
+            }
         }
         __syncthreads();
         constexpr int ROWS_PER_WAVE = TH / 4;     // 2 (TW=32) or 4 (TW=16)
