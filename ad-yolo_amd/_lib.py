@@ -23,12 +23,14 @@ SIGNATURES = {
     "adyolo_feat_finish": (I, [P] * 4 + [I, I, I, P]),
     "adyolo_nchw_to_nhwc8": (I, [P, P, I, I, I, I, P]),
     "adyolo_pack_w3x3": (I, [P, P, P, I, I, I, P]),
-    "adyolo_conv3x3_fwd": (I, [P] * 5 + [I] * 6 + [P]),
+    "adyolo_conv3x3_tiles": (I, [I] * 3),
+    "adyolo_conv3x3_fwd": (I, [P] * 9 + [I] * 6 + [P]),
     "adyolo_conv3x3_wgrad_slabs": (I, [I] * 5),
-    "adyolo_conv3x3_wgrad": (I, [P] * 4 + [I] * 6 + [P]),
+    "adyolo_conv3x3_wgrad": (I, [P] * 6 + [I] * 6 + [P]),
     "adyolo_gemm": (I, [P] * 5 + [I] * 10 + [P]),
     "adyolo_colsum": (I, [P, P, P, I, I, I, I, P]),
     "adyolo_bn_stats": (I, [P] * 7 + [I, I, I, F, F, P]),
+    "adyolo_bn_stats_tiles": (I, [P] * 7 + [I, I, I, I, F, F, P]),
     "adyolo_bn_eval_stats": (I, [P] * 4 + [I, F, P]),
     "adyolo_bn_scale_shift": (I, [P] * 6 + [I, P]),
     "adyolo_affine_nhwc": (I, [P] * 4 + [L, I, P]),

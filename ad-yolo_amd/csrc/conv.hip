@@ -37,8 +37,9 @@ struct ConvCfg {
 template <int KC, int BN, int TW>
 __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(
     const float *__restrict__ x, const float *__restrict__ wpk, const float *__restrict__ bias,
-    const float *__restrict__ addend, float *__restrict__ y, int H, int W, int Cin, int Cout,
-    int tilesW, int tilesH, int relu) {
+    const float *__restrict__ addend, const float *__restrict__ addend_mask, const float *__restrict__ in_scale,
+    const float *__restrict__ in_shift, float *__restrict__ y, float *__restrict__ stats, int H, int W, int Cin,
+    int Cout, int tilesW, int tilesH, int relu) {
     using Cfg = ConvCfg<KC, BN, TW>;
     constexpr int TH = Cfg::TH, HW_ = Cfg::HW_, NPIX = Cfg::NPIX, AS = Cfg::AS, NT = Cfg::NT, Q = Cfg::Q;
     constexpr int WPT = Cfg::WPT;
@@ -81,17 +82,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(
         // stage the halo patch: issue every global load first (registers), then write LDS -- one exposed
         // memory latency per chunk instead of one per 16-byte piece
         constexpr int APT = (NPIX * Q + 255) / 256;
+        constexpr int PSTEP = 256 / Q;                  // pixels advanced per pass; the 16-byte piece q is fixed per thread
+        const int sq = tid % Q, spix0 = tid / Q;
+        float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in_scale) {                                 // fused BatchNorm affine of the producer (padding stays exactly 0)
+            isc = *reinterpret_cast<const float4 *>(in_scale + c0 + sq * 4);
+            ish = *reinterpret_cast<const float4 *>(in_shift + c0 + sq * 4);
+        }
         float4 av[APT];
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
-            const int idx = tid + i * 256;
+            const int pix = spix0 + i * PSTEP;
             av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < NPIX * Q) {
-                const int pix = idx / Q, q = idx - pix * Q;
+            if (pix < NPIX) {
                 const int hy = pix / HW_, hx = pix - hy * HW_;
                 const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-                if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-                    av[i] = *reinterpret_cast<const float4 *>(x + (((size_t)n * H + gy) * W + gx) * Cin + c0 + q * 4);
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    const float4 v = *reinterpret_cast<const float4 *>(x + (((size_t)n * H + gy) * W + gx) * Cin + c0 + sq * 4);
+                    av[i] = make_float4(v.x * isc.x + ish.x, v.y * isc.y + ish.y, v.z * isc.z + ish.z, v.w * isc.w + ish.w);
+                }
             }
         }
         // (named registers, not an array: hipcc would otherwise promote the tiny array to LDS)
@@ -103,11 +112,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(
             w0b = *reinterpret_cast<const float4 *>(wpk + ((size_t)(co0 + wco_b) * 9 + 0) * Cin + c0 + wq_b * 4);
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < NPIX * Q) {
-                const int pix = idx / Q, q = idx - pix * Q;
-                *reinterpret_cast<float4 *>(&As[pix * AS + q * 4]) = av[i];
-            }
+            const int pix = spix0 + i * PSTEP;
+            if (pix < NPIX) *reinterpret_cast<float4 *>(&As[pix * AS + sq * 4]) = av[i];
         }
         if (tid < BN * Q) *reinterpret_cast<float4 *>(&Ws[0][wco_a * AS + wq_a * 4]) = w0a;
         if (WPT > 1 && tid + 256 < BN * Q) *reinterpret_cast<float4 *>(&Ws[0][wco_b * AS + wq_b * 4]) = w0b;
@@ -151,6 +157,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(
         }
     }
 
+    float ssum[NT], ssq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) ssum[nt] = ssq[nt] = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -172,11 +181,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(
                     const size_t o = (((size_t)n * H + gy) * W + gx) * Cout + co;
                     float v = acc[mt][nt][r];
                     if (bias) v += bias[co];
-                    if (addend) v += addend[o];
+                    if (addend) {
+                        const float ad = addend[o];
+                        v += addend_mask ? (addend_mask[o] > 0.f ? ad : 0.f) : ad;
+                    }
                     if (relu) v = fmaxf(v, 0.f);
                     y[o] = v;
+                    ssum[nt] += v;
+                    ssq[nt] += v * v;
                 }
             }
+        }
+    }
+    if (stats) {
+        // per-tile, per-channel sum / sum of squares of the stored output: BatchNorm statistics (and the SE
+        // squeeze) without a separate read pass.  layout [2][tiles][Cout], tile = blockIdx.x
+        __syncthreads();
+        float *red = As;                               // 4 waves x BN x 2 floats
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float a0 = ssum[nt] + __shfl_xor(ssum[nt], 32, 64);
+            const float a1 = ssq[nt] + __shfl_xor(ssq[nt], 32, 64);
+            if (lh == 0) {
+                red[(wave * BN + nt * 32 + li) * 2 + 0] = a0;
+                red[(wave * BN + nt * 32 + li) * 2 + 1] = a1;
+            }
+        }
+        __syncthreads();
+        if (tid < BN * 2) {
+            const int c = tid >> 1, which = tid & 1;
+            const float v = red[(0 * BN + c) * 2 + which] + red[(1 * BN + c) * 2 + which] +
+                            red[(2 * BN + c) * 2 + which] + red[(3 * BN + c) * 2 + which];
+            const size_t half = (size_t)gridDim.x * Cout;
+            stats[which * half + (size_t)blockIdx.x * Cout + co0 + c] = v;
         }
     }
 }
@@ -184,8 +221,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(
 // ---------------------------------------------------------------------------------------------
 template <int TW>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(
-    const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ slabs, int H, int W,
-    int Cin, int Cout, int tilesW, int tilesH, int ntiles, int nsplit, int cinBlocks) {
+    const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ in_scale,
+    const float *__restrict__ in_shift, float *__restrict__ slabs, int H, int W, int Cin, int Cout, int tilesW,
+    int tilesH, int ntiles, int nsplit, int cinBlocks) {
     constexpr int TH = 256 / TW, HW_ = TW + 2, HH_ = TH + 2, NPIX = HW_ * HH_;
     constexpr int XS = 32, DS = 32;
     __shared__ __attribute__((aligned(16))) float Xs[NPIX * XS];   // 43.5 KB, reused for the cross-wave sum
@@ -215,23 +253,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(
         __syncthreads();
         {
             constexpr int XPT = (NPIX * 8 + 255) / 256;
+            const int sq = tid & 7, spix0 = tid >> 3;        // piece q fixed per thread, 32 pixels per pass
+            float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in_scale && sq * 4 < cvalid) {
+                isc = *reinterpret_cast<const float4 *>(in_scale + c0 + sq * 4);
+                ish = *reinterpret_cast<const float4 *>(in_shift + c0 + sq * 4);
+            }
             float4 xv[XPT];
 #pragma unroll
             for (int i = 0; i < XPT; ++i) {
-                const int idx = tid + i * 256;
+                const int pix = spix0 + i * 32;
                 xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < NPIX * 8) {
-                    const int pix = idx >> 3, q = idx & 7;
+                if (pix < NPIX) {
                     const int hy = pix / HW_, hx = pix - hy * HW_;
                     const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-                    if (q * 4 < cvalid && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                        xv[i] = *reinterpret_cast<const float4 *>(x + (((size_t)n * H + gy) * W + gx) * Cin + c0 + q * 4);
+                    if (sq * 4 < cvalid && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                        const float4 v = *reinterpret_cast<const float4 *>(x + (((size_t)n * H + gy) * W + gx) * Cin + c0 + sq * 4);
+                        xv[i] = make_float4(v.x * isc.x + ish.x, v.y * isc.y + ish.y, v.z * isc.z + ish.z, v.w * isc.w + ish.w);
+                    }
                 }
             }
 #pragma unroll
             for (int i = 0; i < XPT; ++i) {
-                const int idx = tid + i * 256;
-                if (idx < NPIX * 8) *reinterpret_cast<float4 *>(&Xs[(idx >> 3) * XS + (idx & 7) * 4]) = xv[i];
+                const int pix = spix0 + i * 32;
+                if (pix < NPIX) *reinterpret_cast<float4 *>(&Xs[pix * XS + sq * 4]) = xv[i];
             }
         }
         {
@@ -339,13 +384,14 @@ __global__ void pack_w3x3_kernel(const float *__restrict__ w, float *__restrict_
 }
 
 template <int KC, int BN, int TW>
-static int launch_fwd(const float *x, const float *wpk, const float *bias, const float *addend, float *y,
+static int launch_fwd(const float *x, const float *wpk, const float *bias, const float *addend,
+                      const float *addend_mask, const float *in_scale, const float *in_shift, float *y, float *stats,
                       int N, int H, int W, int Cin, int Cout, int relu, hipStream_t st) {
     constexpr int TH = 256 / TW;
     const int tilesW = cdiv(W, TW), tilesH = cdiv(H, TH);
     dim3 grid((unsigned)(N * tilesH * tilesW), (unsigned)(Cout / BN));
-    hipLaunchKernelGGL((conv3x3_fwd_kernel<KC, BN, TW>), grid, dim3(256), 0, st, x, wpk, bias, addend, y, H, W,
-                       Cin, Cout, tilesW, tilesH, relu);
+    hipLaunchKernelGGL((conv3x3_fwd_kernel<KC, BN, TW>), grid, dim3(256), 0, st, x, wpk, bias, addend, addend_mask,
+                       in_scale, in_shift, y, stats, H, W, Cin, Cout, tilesW, tilesH, relu);
     return check_launch("conv3x3_fwd");
 }
 
@@ -374,23 +420,28 @@ extern "C" int adyolo_pack_w3x3(const float *w, float *wpk_fwd, float *wpk_dgrad
     return check_launch("pack_w3x3");
 }
 
+extern "C" int adyolo_conv3x3_tiles(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return ADYOLO_EINVAL;
+    const int TW = W >= 32 ? 32 : 16, TH = 256 / TW;
+    return N * cdiv(H, TH) * cdiv(W, TW);
+}
+
 extern "C" int adyolo_conv3x3_fwd(const float *x, const float *wpk, const float *bias, const float *addend,
-                                  float *y, int N, int H, int W, int Cin, int Cout, int relu, void *stream) {
+                                  const float *addend_mask, const float *in_scale, const float *in_shift, float *y,
+                                  float *stats, int N, int H, int W, int Cin, int Cout, int relu, void *stream) {
     ADYOLO_REQUIRE(x && wpk && y && N > 0 && H > 0 && W > 0, ADYOLO_EINVAL, "conv3x3_fwd: bad arguments");
     ADYOLO_REQUIRE((Cin == 8 || Cin % 32 == 0) && Cout % 32 == 0, ADYOLO_ENOSUP,
                    "conv3x3_fwd: Cin=%d must be 8 or a multiple of 32, Cout=%d a multiple of 32", Cin, Cout);
+    ADYOLO_REQUIRE((in_scale == nullptr) == (in_shift == nullptr) && (!addend_mask || addend), ADYOLO_EINVAL,
+                   "conv3x3_fwd: in_scale/in_shift come together; addend_mask needs addend");
     hipStream_t st = as_stream(stream);
     const bool wide = W >= 32;
-    if (Cin == 8) {
-        return wide ? launch_fwd<8, 32, 32>(x, wpk, bias, addend, y, N, H, W, Cin, Cout, relu, st)
-                    : launch_fwd<8, 32, 16>(x, wpk, bias, addend, y, N, H, W, Cin, Cout, relu, st);
-    }
-    if (Cout % 64 == 0) {
-        return wide ? launch_fwd<32, 64, 32>(x, wpk, bias, addend, y, N, H, W, Cin, Cout, relu, st)
-                    : launch_fwd<32, 64, 16>(x, wpk, bias, addend, y, N, H, W, Cin, Cout, relu, st);
-    }
-    return wide ? launch_fwd<32, 32, 32>(x, wpk, bias, addend, y, N, H, W, Cin, Cout, relu, st)
-                : launch_fwd<32, 32, 16>(x, wpk, bias, addend, y, N, H, W, Cin, Cout, relu, st);
+#define ADYOLO_FWD(KC_, BN_, TW_) \
+    launch_fwd<KC_, BN_, TW_>(x, wpk, bias, addend, addend_mask, in_scale, in_shift, y, stats, N, H, W, Cin, Cout, relu, st)
+    if (Cin == 8) return wide ? ADYOLO_FWD(8, 32, 32) : ADYOLO_FWD(8, 32, 16);
+    if (Cout % 64 == 0) return wide ? ADYOLO_FWD(32, 64, 32) : ADYOLO_FWD(32, 64, 16);
+    return wide ? ADYOLO_FWD(32, 32, 32) : ADYOLO_FWD(32, 32, 16);
+#undef ADYOLO_FWD
 }
 
 extern "C" int adyolo_conv3x3_wgrad_slabs(int N, int H, int W, int Cin, int Cout) {
@@ -398,8 +449,9 @@ extern "C" int adyolo_conv3x3_wgrad_slabs(int N, int H, int W, int Cin, int Cout
     return wgrad_splits(N, H, W, Cin, Cout, nullptr);
 }
 
-extern "C" int adyolo_conv3x3_wgrad(const float *x, const float *dy, float *slabs, float *dw, int N, int H,
-                                    int W, int Cin, int Cin_real, int Cout, void *stream) {
+extern "C" int adyolo_conv3x3_wgrad(const float *x, const float *dy, const float *in_scale, const float *in_shift,
+                                    float *slabs, float *dw, int N, int H, int W, int Cin, int Cin_real, int Cout,
+                                    void *stream) {
     ADYOLO_REQUIRE(x && dy && slabs && dw && N > 0 && H > 0 && W > 0, ADYOLO_EINVAL, "conv3x3_wgrad: bad arguments");
     ADYOLO_REQUIRE((Cin == 8 || Cin % 32 == 0) && Cout % 32 == 0 && Cin_real <= Cin, ADYOLO_ENOSUP,
                    "conv3x3_wgrad: unsupported channels Cin=%d Cout=%d", Cin, Cout);
@@ -412,11 +464,11 @@ extern "C" int adyolo_conv3x3_wgrad(const float *x, const float *dy, float *slab
     const int cinBlocks = cdiv(Cin, 32);
     dim3 grid((unsigned)nsplit, (unsigned)((Cout / 32) * cinBlocks));
     if (TW == 32)
-        hipLaunchKernelGGL((conv3x3_wgrad_kernel<32>), grid, dim3(256), 0, st, x, dy, slabs, H, W, Cin, Cout,
-                           tilesW, tilesH, ntiles, nsplit, cinBlocks);
+        hipLaunchKernelGGL((conv3x3_wgrad_kernel<32>), grid, dim3(256), 0, st, x, dy, in_scale, in_shift, slabs, H, W,
+                           Cin, Cout, tilesW, tilesH, ntiles, nsplit, cinBlocks);
     else
-        hipLaunchKernelGGL((conv3x3_wgrad_kernel<16>), grid, dim3(256), 0, st, x, dy, slabs, H, W, Cin, Cout,
-                           tilesW, tilesH, ntiles, nsplit, cinBlocks);
+        hipLaunchKernelGGL((conv3x3_wgrad_kernel<16>), grid, dim3(256), 0, st, x, dy, in_scale, in_shift, slabs, H, W,
+                           Cin, Cout, tilesW, tilesH, ntiles, nsplit, cinBlocks);
     int rc = check_launch("conv3x3_wgrad");
     if (rc) return rc;
     const int CinP = cinBlocks * 32;

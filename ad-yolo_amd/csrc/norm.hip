@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void se_tail_bwd_apply_kernel(
         o.z = ga.z * is.z * (g.z * sv.z + dp.z * invHW - a.z * invR - (cv.z - m.z) * is.z * b.z * invR);
         o.w = ga.w * is.w * (g.w * sv.w + dp.w * invHW - a.w * invR - (cv.w - m.w) * is.w * b.w * invR);
         reinterpret_cast<float4 *>(dc)[base + i] = o;
-        reinterpret_cast<float4 *>(dr)[base + i] = g;
+        if (dr) reinterpret_cast<float4 *>(dr)[base + i] = g;
     }
 }
 
@@ -410,6 +410,22 @@ extern "C" int adyolo_bn_stats(const float *x, float *ssum, float *mean, float *
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, ps0, ps1, mean, invstd, running_mean,
                        running_var, N, C, (double)N * (double)HW, momentum, eps);
     return check_launch("bn_stats_final");
+}
+
+extern "C" int adyolo_bn_stats_tiles(const float *tile_stats, float *ssum, float *mean, float *invstd,
+                                     float *running_mean, float *running_var, float *partial, int N, int G, int HW,
+                                     int C, float momentum, float eps, void *stream) {
+    ADYOLO_REQUIRE(tile_stats && mean && invstd && partial && N > 0 && G > 0 && HW > 0 && C > 0 && N <= 1024,
+                   ADYOLO_EINVAL, "bn_stats_tiles: bad arguments");
+    hipStream_t st = as_stream(stream);
+    float *ps0 = ssum ? ssum : partial;
+    float *ps1 = partial + (size_t)1024 * C;
+    hipLaunchKernelGGL(persample_reduce_kernel, dim3(cdiv(C, 32), N), dim3(256), 0, st, tile_stats, ps0, ps1, N, G, C);
+    int rc = check_launch("bn_stats_tiles_persample");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, ps0, ps1, mean, invstd, running_mean,
+                       running_var, N, C, (double)N * (double)HW, momentum, eps);
+    return check_launch("bn_stats_tiles_final");
 }
 
 extern "C" int adyolo_bn_eval_stats(const float *running_mean, const float *running_var, float *mean, float *invstd,
@@ -532,7 +548,7 @@ extern "C" int adyolo_se_tail_bwd_apply(const float *de, const float *e, const f
                                         const float *mean, const float *invstd, const float *s, const float *dpool,
                                         const float *sdd, const float *sddx, float *dc, float *dr, int N, int HW,
                                         int C, void *stream) {
-    ADYOLO_REQUIRE(de && e && c && gamma && mean && invstd && s && dpool && sdd && sddx && dc && dr && N > 0 &&
+    ADYOLO_REQUIRE(de && e && c && gamma && mean && invstd && s && dpool && sdd && sddx && dc && N > 0 &&
                        HW > 0 && C % 4 == 0,
                    ADYOLO_EINVAL, "se_tail_bwd_apply: bad arguments");
     const long hw4 = (long)HW * (C / 4);

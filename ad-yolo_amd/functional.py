@@ -5,9 +5,16 @@ parameter gradients, so ``loss.backward()`` works exactly as in the reference's 
 
 Activations are channels-last float32: [N][T][F][C].
 """
+import os
+
 import torch
 
 from . import ops
+
+# Fusion switches (all on by default; the env override exists so that A/B timings can be taken in one process)
+FUSE_AFFINE = os.environ.get("ADYOLO_FUSE_AFFINE", "1") != "0"   # BN1 affine applied while conv2 stages its input
+FUSE_STATS = os.environ.get("ADYOLO_FUSE_STATS", "1") != "0"     # BN statistics from the conv epilogue
+FUSE_DR = os.environ.get("ADYOLO_FUSE_DR", "1") != "0"           # identity-shortcut gradient formed in the dgrad epilogue
 
 
 def _c(t):
@@ -30,6 +37,17 @@ class _BNState:
             mean, invstd = ops.bn_eval_stats(m.running_mean, m.running_var, m.eps)
         return ssum, mean, invstd
 
+    def stats_tiles(self, tile_stats, x, update=True):
+        """Training-mode statistics from the per-patch sums a conv epilogue produced (no extra read pass)."""
+        m = self.mod
+        n, c = x.shape[0], x.shape[-1]
+        hw = x.numel() // (n * c)
+        if update:
+            out = ops.bn_stats_tiles(tile_stats, n, hw, m.running_mean, m.running_var, m.momentum, m.eps)
+            m.num_batches_tracked += 1
+            return out
+        return ops.bn_stats_tiles(tile_stats, n, hw, None, None, m.momentum, m.eps)
+
 
 class StemFn(torch.autograd.Function):
     """conv3x3(7->32, bias) -> ReLU -> BatchNorm   (reference resnet.py:183-185; ReLU before BN)."""
@@ -37,8 +55,12 @@ class StemFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x8, w, b, gamma, beta, bn, training):
         wpk, _ = ops.pack_w3x3(w, 8, want_dgrad=False)
-        a = ops.conv3x3(x8, wpk, w.shape[0], bias=b, relu=True)
-        _, mean, invstd = _BNState(bn).stats(a, training)
+        if training and FUSE_STATS:
+            a, st = ops.conv3x3(x8, wpk, w.shape[0], bias=b, relu=True, want_stats=True)
+            _, mean, invstd = _BNState(bn).stats_tiles(st, a)
+        else:
+            a = ops.conv3x3(x8, wpk, w.shape[0], bias=b, relu=True)
+            _, mean, invstd = _BNState(bn).stats(a, False)
         scale, shift = ops.bn_scale_shift(gamma, beta, mean, invstd)
         out = ops.affine(a, scale, shift)
         ctx.training = training
@@ -73,17 +95,33 @@ class SEBlockFn(torch.autograd.Function):
         n, h, w_, cin = p.shape
         c = w1.shape[0]
         wpk1, wpk1d = ops.pack_w3x3(w1, cin)
-        a = ops.conv3x3(p, wpk1, c, relu=True)
-        _, mean1, invstd1 = _BNState(bn1).stats(a, training)
-        scale1, shift1 = ops.bn_scale_shift(g1, b1, mean1, invstd1)
-        bb = ops.affine(a, scale1, shift1)
-        wpk2, wpk2d = ops.pack_w3x3(w2, c)
-        cc = ops.conv3x3(bb, wpk2, c)
-        if training:
-            ssum2, mean2, invstd2 = _BNState(bn2).stats(cc, True)
+        if training and FUSE_STATS:
+            a, st1 = ops.conv3x3(p, wpk1, c, relu=True, want_stats=True)
+            _, mean1, invstd1 = _BNState(bn1).stats_tiles(st1, a)
         else:
-            ssum2, _, _ = ops.bn_stats(cc, None, None)
-            _, mean2, invstd2 = _BNState(bn2).stats(cc, False)
+            a = ops.conv3x3(p, wpk1, c, relu=True)
+            _, mean1, invstd1 = _BNState(bn1).stats(a, training)
+        scale1, shift1 = ops.bn_scale_shift(g1, b1, mean1, invstd1)
+        wpk2, wpk2d = ops.pack_w3x3(w2, c)
+        if FUSE_AFFINE:
+            # BN1's affine is applied while conv2 stages its input: bn1(a) is never written to HBM
+            src, aff = a, (scale1, shift1)
+        else:
+            src, aff = ops.affine(a, scale1, shift1), None
+        if FUSE_STATS:
+            cc, st2 = ops.conv3x3(src, wpk2, c, in_affine=aff, want_stats=True)
+            if training:
+                ssum2, mean2, invstd2 = _BNState(bn2).stats_tiles(st2, cc)
+            else:
+                ssum2, _, _ = _BNState(bn2).stats_tiles(st2, cc, update=False)
+                _, mean2, invstd2 = _BNState(bn2).stats(cc, False)
+        else:
+            cc = ops.conv3x3(src, wpk2, c, in_affine=aff)
+            if training:
+                ssum2, mean2, invstd2 = _BNState(bn2).stats(cc, True)
+            else:
+                ssum2, _, _ = ops.bn_stats(cc, None, None)
+                _, mean2, invstd2 = _BNState(bn2).stats(cc, False)
         scale2, shift2 = ops.bn_scale_shift(g2, b2, mean2, invstd2)
         pooled, hid, s = ops.se_fc_fwd(ssum2, scale2, shift2, fw1, fb1, fw2, fb2, h * w_)
         q = None
@@ -98,8 +136,10 @@ class SEBlockFn(torch.autograd.Function):
         e = ops.se_tail_fwd(cc, r, scale2, shift2, s)
         ctx.training, ctx.pool, ctx.has_down = training, pool, wd is not None
         ctx.in_hw = (x.shape[1], x.shape[2])
-        tensors = [p, a, bb, cc, e, g1, mean1, invstd1, g2, b2, mean2, invstd2, ssum2, pooled, hid, s, fw1, fw2,
-                   wpk1d, wpk2d]
+        ctx.fused_affine = aff is not None
+        ctx.a_unfused = None if aff is not None else a      # (A/B switch only; keeps `a` alive for BN1's backward)
+        tensors = [p, src, scale1, cc, e, g1, mean1, invstd1, g2, b2, mean2, invstd2, ssum2, pooled, hid, s, fw1, fw2,
+                   wpk1d, wpk2d, shift1]
         if wd is not None:
             tensors += [q, wd, gd, meand, invstdd]
         ctx.save_for_backward(*tensors)
@@ -110,19 +150,26 @@ class SEBlockFn(torch.autograd.Function):
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
         t = ctx.saved_tensors
-        (p, a, bb, cc, e, g1, mean1, invstd1, g2, b2, mean2, invstd2, ssum2, pooled, hid, s, fw1, fw2, wpk1d,
-         wpk2d) = t[:20]
+        (p, src, scale1, cc, e, g1, mean1, invstd1, g2, b2, mean2, invstd2, ssum2, pooled, hid, s, fw1, fw2, wpk1d,
+         wpk2d, shift1) = t[:21]
         n, h, w_, cin = p.shape
         c = cc.shape[-1]
-        dc, dr, dg2, db2, dfw1, dfb1, dfw2, dfb2 = ops.se_tail_bwd(_c(de), e, cc, g2, b2, mean2, invstd2, ssum2,
-                                                                   pooled, hid, s, fw1, fw2)
-        dw2 = ops.conv3x3_wgrad(bb, dc, c)
+        de = _c(de)
+        dc, dr, dg2, db2, dfw1, dfb1, dfw2, dfb2 = ops.se_tail_bwd(de, e, cc, g2, b2, mean2, invstd2, ssum2, pooled,
+                                                                   hid, s, fw1, fw2,
+                                                                   want_dr=ctx.has_down or not FUSE_DR)
+        if ctx.fused_affine:
+            a = src
+            dw2 = ops.conv3x3_wgrad(a, dc, c, in_affine=(scale1, shift1))
+        else:
+            dw2 = ops.conv3x3_wgrad(src, dc, c)
+            a = ctx.a_unfused
         dbb = ops.conv3x3(dc, wpk2d, c)
         da, dg1, db1 = ops.bn_bwd(dbb, a, g1, mean1, invstd1, relu_mask=True)
         dw1 = ops.conv3x3_wgrad(p, da, cin)
         dwd = dgd = dbd = None
         if ctx.has_down:
-            q, wd, gd, meand, invstdd = t[20:25]
+            q, wd, gd, meand, invstdd = t[21:26]
             dq, dgd, dbd = ops.bn_bwd(dr, q, gd, meand, invstdd, relu_mask=False)
             rows = n * h * w_
             splits = max(1, min(64, rows // 4096))
@@ -130,7 +177,11 @@ class SEBlockFn(torch.autograd.Function):
             dp_res = ops.gemm(dq, wd, rows, cin, c, c, cin, trans_b=True).view(n, h, w_, cin)
             dp = ops.conv3x3(da, wpk1d, cin, addend=dp_res)
         else:
-            dp = ops.conv3x3(da, wpk1d, cin, addend=dr)
+            # identity shortcut: its gradient de * (e > 0) is formed inside the dgrad epilogue
+            if FUSE_DR:
+                dp = ops.conv3x3(da, wpk1d, cin, addend=de, addend_mask=e)
+            else:
+                dp = ops.conv3x3(da, wpk1d, cin, addend=dr)
         dx = ops.avgpool2_bwd(dp, ctx.in_hw[0], ctx.in_hw[1]) if ctx.pool else dp
         return (dx, None, None, None, dw1, dg1, db1, dw2, dg2, db2, dfw1, dfb1, dfw2, dfb2, dwd, dgd, dbd)
 

@@ -54,17 +54,27 @@ def pack_w3x3(w, cin_pad, want_dgrad=True):
     return wf, wd
 
 
-def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False):
-    """x [N][H][W][Cin] -> [N][H][W][cout];  wpk [cout][9][Cin]."""
-    _chk(x, wpk, bias, addend)
+def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, in_affine=None, want_stats=False):
+    """x [N][H][W][Cin] -> [N][H][W][cout];  wpk [cout][9][Cin].
+
+    in_affine=(scale, shift): the producer's BatchNorm affine is applied while staging x (padding stays 0);
+    addend_mask: addend is multiplied by (mask > 0); want_stats: also return the per-patch channel sums
+    [2][tiles][cout] of the output for ``bn_stats_tiles``."""
+    _chk(x, wpk, bias, addend, addend_mask)
     n, h, w, cin = x.shape
     y = _new(x, n, h, w, cout)
-    _c("adyolo_conv3x3_fwd", _p(x), _p(wpk), _p(bias), _p(addend), _p(y), n, h, w, cin, cout, int(relu), _stream())
-    return y
+    stats = None
+    if want_stats:
+        tiles = _lib.load().adyolo_conv3x3_tiles(n, h, w)
+        stats = _new(x, 2, tiles, cout)
+    sc, sh = in_affine if in_affine is not None else (None, None)
+    _c("adyolo_conv3x3_fwd", _p(x), _p(wpk), _p(bias), _p(addend), _p(addend_mask), _p(sc), _p(sh), _p(y), _p(stats),
+       n, h, w, cin, cout, int(relu), _stream())
+    return (y, stats) if want_stats else y
 
 
-def conv3x3_wgrad(x, dy, cin_real):
-    """x [N][H][W][Cin], dy [N][H][W][Cout] -> dw [Cout][cin_real][3][3]."""
+def conv3x3_wgrad(x, dy, cin_real, in_affine=None):
+    """x [N][H][W][Cin], dy [N][H][W][Cout] -> dw [Cout][cin_real][3][3] (x optionally seen through an affine)."""
     _chk(x, dy)
     n, h, w, cin = x.shape
     cout = dy.shape[3]
@@ -74,7 +84,8 @@ def conv3x3_wgrad(x, dy, cin_real):
     cinp = ((cin + 31) // 32) * 32
     slabs = _new(x, nslab, cout, 9, cinp)
     dw = _new(x, cout, cin_real, 3, 3)
-    _c("adyolo_conv3x3_wgrad", _p(x), _p(dy), _p(slabs), _p(dw), n, h, w, cin, cin_real, cout, _stream())
+    sc, sh = in_affine if in_affine is not None else (None, None)
+    _c("adyolo_conv3x3_wgrad", _p(x), _p(dy), _p(sc), _p(sh), _p(slabs), _p(dw), n, h, w, cin, cin_real, cout, _stream())
     return dw
 
 
@@ -159,6 +170,17 @@ def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
     return ssum, mean, invstd
 
 
+def bn_stats_tiles(tile_stats, n, hw, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    """BatchNorm statistics from the per-patch sums of a convolution epilogue ([2][tiles][C])."""
+    _chk(tile_stats, running_mean, running_var)
+    tiles, c = tile_stats.shape[1], tile_stats.shape[2]
+    ssum, mean, invstd = _new(tile_stats, n, c), _new(tile_stats, c), _new(tile_stats, c)
+    partial = _new(tile_stats, 2 * 1024 * c)
+    _c("adyolo_bn_stats_tiles", _p(tile_stats), _p(ssum), _p(mean), _p(invstd), _p(running_mean), _p(running_var),
+       _p(partial), n, tiles // n, hw, c, momentum, eps, _stream())
+    return ssum, mean, invstd
+
+
 def bn_eval_stats(running_mean, running_var, eps=1e-5):
     _chk(running_mean, running_var)
     c = running_mean.numel()
@@ -216,7 +238,7 @@ def se_tail_fwd(c_t, r_t, scale, shift, s):
     return e
 
 
-def se_tail_bwd(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1, w2):
+def se_tail_bwd(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1, w2, want_dr=True):
     """Backward of  e = relu(bn2(c) * s + r)  incl. the SE FCs.
     -> dc, dr, dgamma, dbeta, dw1, db1, dw2, db2"""
     _chk(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1, w2)
@@ -240,7 +262,8 @@ def se_tail_bwd(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1,
     sdd = packed[o:o + ch]; o += ch
     sddx = packed[o:o + ch]
     dgamma, dbeta = sddx, sdd
-    dc, dr = torch.empty_like(c_t), torch.empty_like(c_t)
+    dc = torch.empty_like(c_t)
+    dr = torch.empty_like(c_t) if want_dr else None
     _c("adyolo_se_tail_bwd_apply", _p(de), _p(e), _p(c_t), _p(gamma), _p(mean), _p(invstd), _p(s), _p(dpool), _p(sdd),
        _p(sddx), _p(dc), _p(dr), n, hw, ch, _stream())
     return dc, dr, dgamma, dbeta, dw1, db1, dw2, db2

@@ -148,7 +148,7 @@ def main():
     timer.wrap(ops, "conv3x3", "conv3x3_fwd_dgrad",
                lambda x, wpk, cout, **kw: 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * cout * 9 * x.shape[3])
     timer.wrap(ops, "conv3x3_wgrad", "conv3x3_wgrad",
-               lambda x, dy, cin_real: 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * dy.shape[3] * 9 * x.shape[3])
+               lambda x, dy, cin_real, **kw: 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * dy.shape[3] * 9 * x.shape[3])
     feat_call = trainer.features.__call__
     k1_rec = []
 

@@ -61,7 +61,11 @@ int adyolo_nchw_to_nhwc8(const float *x, float *y, int B, int C, int H, int W, v
  *   x [N][H][W][Cin]; y [N][H][W][Cout];  Cin in {8, multiples of 32}, Cout multiple of 32.
  *   wpk   packed weights [Cout][9][Cin]  (tap = ky*3+kx, Cin fastest) -- see adyolo_pack_w3x3
  *   bias  [Cout] or NULL;  addend [N][H][W][Cout] or NULL (added before the optional ReLU)
- *   y = relu?( conv(x, w) + bias + addend )
+ *   y = relu?( conv(x', w) + bias + addend' )   with the optional fusions
+ *     x' = x*in_scale[c] + in_shift[c] on in-image pixels (BatchNorm affine of the producer; zero padding stays 0)
+ *     addend' = addend * (addend_mask > 0)  (residual gradient  de * (e > 0)  formed on the fly)
+ *     stats [2][tiles][Cout]: per 256-pixel patch, per channel sum and sum of squares of y -- the BatchNorm
+ *       statistics / SE squeeze of the consumer without a separate read pass (adyolo_bn_stats_tiles finishes).
  * data-gradient = the same call with the dgrad packing (wpk_dgrad, Cin<->Cout swapped).
  * weight-gradient: adyolo_conv3x3_wgrad accumulates into `slabs` ([n_slabs][Cout][9][CinP] float32,
  * n_slabs = adyolo_conv3x3_wgrad_slabs(...)) then reduces them into dw in the reference layout
@@ -70,11 +74,14 @@ int adyolo_nchw_to_nhwc8(const float *x, float *y, int B, int C, int H, int W, v
 int adyolo_pack_w3x3(const float *w /*[Cout][Cin_real][3][3]*/, float *wpk_fwd /*[Cout][9][Cin]*/,
                      float *wpk_dgrad /*[Cin][9][Cout] or NULL*/, int Cout, int Cin_real, int Cin,
                      void *stream);
+int adyolo_conv3x3_tiles(int N, int H, int W);   /* number of 256-pixel patches = rows of `stats` */
 int adyolo_conv3x3_fwd(const float *x, const float *wpk, const float *bias, const float *addend,
-                       float *y, int N, int H, int W, int Cin, int Cout, int relu, void *stream);
+                       const float *addend_mask, const float *in_scale, const float *in_shift, float *y,
+                       float *stats, int N, int H, int W, int Cin, int Cout, int relu, void *stream);
 int adyolo_conv3x3_wgrad_slabs(int N, int H, int W, int Cin, int Cout);
-int adyolo_conv3x3_wgrad(const float *x, const float *dy, float *slabs, float *dw, int N, int H,
-                         int W, int Cin, int Cin_real, int Cout, void *stream);
+int adyolo_conv3x3_wgrad(const float *x, const float *dy, const float *in_scale, const float *in_shift,
+                         float *slabs, float *dw, int N, int H, int W, int Cin, int Cin_real, int Cout,
+                         void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K7  dense GEMM on fp32 MFMA:  C[m][n] = sum_k opA(m,k) * opB(n,k) (+ bias[n])
@@ -110,6 +117,11 @@ int adyolo_colsum(const float *A, float *out, float *partial, int R, int C, int 
 int adyolo_bn_stats(const float *x, float *ssum, float *mean, float *invstd, float *running_mean,
                     float *running_var, float *partial, int N, int HW, int C, float momentum,
                     float eps, void *stream);
+/* same as adyolo_bn_stats but from the per-patch sums a convolution epilogue wrote (tiles = G*N, patch index
+ * n*G + g); partial: workspace of 2*1024*C floats */
+int adyolo_bn_stats_tiles(const float *tile_stats, float *ssum, float *mean, float *invstd, float *running_mean,
+                          float *running_var, float *partial, int N, int G, int HW, int C, float momentum,
+                          float eps, void *stream);
 int adyolo_bn_eval_stats(const float *running_mean, const float *running_var, float *mean,
                          float *invstd, int C, float eps, void *stream);
 int adyolo_bn_scale_shift(const float *gamma, const float *beta, const float *mean,
@@ -133,7 +145,8 @@ int adyolo_bn_bwd_apply(const float *dy, const float *x, const float *gamma, con
  *                     (P words, one workgroup per sample + a deterministic column sum over the batch), the FC
  *                     gradients and the batch sums bn2's backward needs: sdd[c] = sum dd (= dbeta2),
  *                     sddx[c] = sum dd*xhat (= dgamma2)
- *   adyolo_se_tail_bwd_apply: dc = scale*( g*s + dpool/HW - sdd/R - xhat*sddx/R ),  dr = g
+ *   adyolo_se_tail_bwd_apply: dc = scale*( g*s + dpool/HW - sdd/R - xhat*sddx/R ),  dr = g (dr may be NULL: the
+ *                     identity-shortcut gradient is then formed inside the dgrad epilogue via addend_mask)
  * ---------------------------------------------------------------------------------------------- */
 int adyolo_se_fc_fwd(const float *ssum, const float *scale, const float *shift, const float *w1,
                      const float *b1, const float *w2, const float *b2, float *pooled, float *hid,

@@ -101,6 +101,35 @@ def test_conv3x3_dgrad_wgrad(ops, n, h, w, cin, cout):
         assert_close(nchw(dx), x.grad, 2e-5, "conv3x3 dgrad")
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 20, 64, 32, 32), (3, 17, 16, 64, 128), (2, 9, 32, 32, 64)])
+def test_conv3x3_fused_affine_mask_stats(ops, n, h, w, cin, cout):
+    """in_affine (producer BN affine applied while staging; padding stays zero), masked addend, epilogue statistics."""
+    g = torch.Generator().manual_seed(h * 7 + cin)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
+    scale, shift = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g)
+    add, mask = torch.randn(n, cout, h, w, generator=g), torch.randn(n, cout, h, w, generator=g)
+    xa = x * scale[None, :, None, None] + shift[None, :, None, None]
+    ref = F.relu(F.conv2d(xa, wt, None, padding=1) + add * (mask > 0))
+    wpk, _ = ops.pack_w3x3(dev(wt), cin, want_dgrad=False)
+    y, st = ops.conv3x3(dev(nhwc(x)), wpk, cout, addend=dev(nhwc(add)), addend_mask=dev(nhwc(mask)), relu=True,
+                        in_affine=(dev(scale), dev(shift)), want_stats=True)
+    ssum, mean, invstd = ops.bn_stats_tiles(st, n, h * w)
+    torch.cuda.synchronize()
+    assert_close(nchw(y), ref, 2e-5, "fused conv")
+    assert_close(ssum, ref.sum(dim=(2, 3)), 2e-5, "per-sample sums from the conv epilogue")
+    assert_close(mean, ref.mean(dim=(0, 2, 3)), 2e-5, "batch mean from the conv epilogue")
+    assert_close(invstd, 1.0 / torch.sqrt(ref.var(dim=(0, 2, 3), unbiased=False) + 1e-5), 5e-5, "batch invstd")
+    # weight gradient with x seen through the same affine
+    dy = torch.randn(n, cout, h, w, generator=g)
+    xr = xa.clone().requires_grad_(False)
+    wr = wt.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, padding=1).backward(dy)
+    dw = ops.conv3x3_wgrad(dev(nhwc(x)), dev(nhwc(dy)), cin, in_affine=(dev(scale), dev(shift)))
+    torch.cuda.synchronize()
+    assert_close(dw, wr.grad, 2e-5, "wgrad through the fused affine")
+
+
 # ------------------------------------------------------------------------------------------------ gemm
 @pytest.mark.parametrize("m,n,k,ta,tb,bias,splits", [
     (300, 2400, 256, False, False, True, 1),      # head

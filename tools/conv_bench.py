@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--which", default="fwd,wgrad")
     ap.add_argument("--stages", default="1,2,3,4")
+    ap.add_argument("--fused", action="store_true", help="fwd: in_affine + epilogue stats + masked addend; wgrad: in_affine")
     a = ap.parse_args()
     for st in [int(s) for s in a.stages.split(",")]:
         h, w, cin, cout = SHAPES[st]
@@ -28,8 +29,15 @@ def main():
         wpk, _ = ops.pack_w3x3(wt, cin, want_dgrad=False)
         dy = torch.randn(a.batch, h, w, cout, device="cuda:0")
         flops = 2.0 * a.batch * h * w * cout * 9 * cin
+        aff = (torch.rand(cin, device="cuda:0") + 0.5, torch.randn(cin, device="cuda:0")) if (a.fused and cin != 8) else None
         for which in a.which.split(","):
-            fn = (lambda: ops.conv3x3(x, wpk, cout)) if which == "fwd" else (lambda: ops.conv3x3_wgrad(x, dy, wt.shape[1]))
+            if which == "fwd":
+                if a.fused:
+                    fn = lambda: ops.conv3x3(x, wpk, cout, relu=True, in_affine=aff, want_stats=True, addend=dy, addend_mask=dy)  # noqa: E731
+                else:
+                    fn = lambda: ops.conv3x3(x, wpk, cout)  # noqa: E731
+            else:
+                fn = lambda: ops.conv3x3_wgrad(x, dy, wt.shape[1], in_affine=aff)  # noqa: E731
             fn()
             torch.cuda.synchronize()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
