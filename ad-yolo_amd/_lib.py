@@ -19,7 +19,7 @@ U64 = ctypes.c_uint64
 SIGNATURES = {
     "adyolo_abi_version": (I, []),
     "adyolo_last_error": (ctypes.c_char_p, []),
-    "adyolo_feat_stft_mel": (I, [P] * 11 + [I, I, I, P]),
+    "adyolo_feat_stft_mel": (I, [P] * 8 + [I, I] + [P] * 4 + [I, I, I, P]),
     "adyolo_feat_finish": (I, [P] * 4 + [I, I, I, P]),
     "adyolo_nchw_to_nhwc8": (I, [P, P, I, I, I, I, P]),
     "adyolo_pack_w3x3": (I, [P, P, P, I, I, I, P]),
@@ -56,6 +56,10 @@ SIGNATURES = {
     "adyolo_dropout_mask": (I, [P, L, F, U64, U64, P]),
     "adyolo_loss_workspace_words": (L, [I, I, I, I]),
     "adyolo_loss_fwd_bwd": (I, [P] * 6 + [I] * 7 + [P, P, F, F, F, F, P]),
+    "adyolo_act_fwd": (I, [P, P, L, I, I, P]),
+    "adyolo_act_bwd": (I, [P, P, P, L, I, I, P]),
+    "adyolo_seddoa_loss": (I, [P] * 5 + [L, I, I, I, F, F, P]),
+    "adyolo_adpit_loss": (I, [P] * 5 + [L, I, P]),
     "adyolo_adam_step": (I, [P] * 4 + [L, F, F, F, F, F, I, F, P]),
 }
 

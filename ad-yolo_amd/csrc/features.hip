@@ -5,7 +5,8 @@
 //
 // One workgroup walks FR consecutive frames of one clip.  Per frame the four real channels are packed
 // as two complex signals (W + iY, Z + iX), each transformed by a 1200-point mixed-radix Stockham FFT
-// (4 x 4 x 3 x 5 x 5, auto-sorting, ping-pong in LDS, twiddles from an LDS-resident table built in double
+// (10 x 10 x 12 as in-register (5x2),(5x2),(4x3) composite butterflies: 240/240/200 butterflies per frame on 256
+// lanes; auto-sorting, ping-pong in LDS, twiddles from an LDS-resident table built in double
 // on the host), untangled into the four 601-bin spectra, turned into the 7 per-bin quantities
 // (|W|^2,|Y|^2,|Z|^2,|X|^2, Iy/E, Iz/E, Ix/E) in LDS, and contracted with the sparse (1165 non-zero)
 // triangular mel filters.  Audio samples are read once as float4 (all four channels of a sample).
@@ -54,22 +55,71 @@ __device__ __forceinline__ void butterfly<5>(float2 *v) {
     v[2] = cadd(a2, b2); v[3] = csub(a2, b2);
 }
 
-// one Stockham stage over both packed signals (in/out: [2][FN])
+template <>
+__device__ __forceinline__ void butterfly<2>(float2 *v) {
+    const float2 a = v[0], b = v[1];
+    v[0] = cadd(a, b);
+    v[1] = csub(a, b);
+}
+
+// exp(-2 pi i m / R) tables for the in-register composite butterflies (folded to immediates after unrolling)
+__device__ constexpr float RC10[10] = {1.f, 0.809016994f, 0.309016994f, -0.309016994f, -0.809016994f, -1.f, -0.809016994f, -0.309016994f, 0.309016994f, 0.809016994f};
+__device__ constexpr float RS10[10] = {0.f, -0.587785252f, -0.951056516f, -0.951056516f, -0.587785252f, 0.f, 0.587785252f, 0.951056516f, 0.951056516f, 0.587785252f};
+__device__ constexpr float RC12[12] = {1.f, 0.866025404f, 0.5f, 0.f, -0.5f, -0.866025404f, -1.f, -0.866025404f, -0.5f, 0.f, 0.5f, 0.866025404f};
+__device__ constexpr float RS12[12] = {0.f, -0.5f, -0.866025404f, -1.f, -0.866025404f, -0.5f, 0.f, 0.5f, 0.866025404f, 1.f, 0.866025404f, 0.5f};
 template <int R>
+__device__ __forceinline__ float2 root(int m);
+template <>
+__device__ __forceinline__ float2 root<10>(int m) { return make_float2(RC10[m], RS10[m]); }
+template <>
+__device__ __forceinline__ float2 root<12>(int m) { return make_float2(RC12[m], RS12[m]); }
+
+// radix R1*R2 butterfly entirely in registers (Cooley-Tukey: n = n2 + R2 n1, k = k1 + R1 k2)
+template <int R1, int R2>
+__device__ __forceinline__ void butterfly_composite(float2 *v) {
+    constexpr int R = R1 * R2;
+    float2 y[R2][R1];
+#pragma unroll
+    for (int n2 = 0; n2 < R2; ++n2) {
+        float2 t[R1];
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) t[n1] = v[n2 + R2 * n1];
+        butterfly<R1>(t);
+#pragma unroll
+        for (int k1 = 0; k1 < R1; ++k1) y[n2][k1] = (n2 * k1 == 0) ? t[k1] : cmul(t[k1], root<R>((n2 * k1) % R));
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) {
+        float2 t[R2];
+#pragma unroll
+        for (int n2 = 0; n2 < R2; ++n2) t[n2] = y[n2][k1];
+        butterfly<R2>(t);
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) v[k1 + R1 * k2] = t[k2];
+    }
+}
+template <>
+__device__ __forceinline__ void butterfly<10>(float2 *v) { butterfly_composite<5, 2>(v); }
+template <>
+__device__ __forceinline__ void butterfly<12>(float2 *v) { butterfly_composite<4, 3>(v); }
+
+// one Stockham stage over both packed signals (in/out: [2][FN]); one radix-R butterfly per thread and pass
+template <int R, int Ns>
 __device__ __forceinline__ void fft_stage(const float2 *__restrict__ in, float2 *__restrict__ out,
-                                          const float2 *__restrict__ tw, int Ns, int tid) {
+                                          const float2 *__restrict__ tw, int tid) {
     constexpr int T = FN / R;
-    const int tstep = FN / (Ns * R);
+    constexpr int tstep = FN / (Ns * R);
     for (int j2 = tid; j2 < 2 * T; j2 += 256) {
         const int f = j2 >= T ? 1 : 0;
         const int j = j2 - f * T;
         const int k = j % Ns;
-        const float2 *src = in + f * FN;
+        const float2 *src = in + f * FN + j;
         float2 v[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            v[r] = src[j + r * T];
-            if (r > 0) v[r] = cmul(v[r], tw[r * k * tstep]);
+        for (int r = 0; r < R; ++r) v[r] = src[r * T];
+        if (Ns > 1) {
+#pragma unroll
+            for (int r = 1; r < R; ++r) v[r] = cmul(v[r], tw[r * k * tstep]);
         }
         butterfly<R>(v);
         float2 *dst = out + f * FN + (j / Ns) * Ns * R + k;
@@ -83,48 +133,64 @@ __device__ __forceinline__ void atomic_max_float(float *addr, float val) {
     else atomicMin(reinterpret_cast<unsigned *>(addr), __float_as_uint(val));
 }
 
-__global__ __launch_bounds__(256, 2) void feat_stft_mel_kernel(
+constexpr int MAX_MELW = 1280, SPS8 = 8;
+
+__global__ __launch_bounds__(256, 3) void feat_stft_mel_kernel(
     const float *__restrict__ audio, const float *__restrict__ twiddle, const float *__restrict__ window,
-    const int *__restrict__ mel_start, const int *__restrict__ mel_len, const int *__restrict__ mel_off,
-    const float *__restrict__ mel_w, const float *__restrict__ sc_mean, const float *__restrict__ sc_rstd,
-    float *__restrict__ out, float *__restrict__ chan_max, int n_samples, int T, int layout) {
-    __shared__ float2 tw[FN];
-    __shared__ float win[FN];
-    __shared__ float2 bufA[2 * FN];
+    const int *__restrict__ chunk_mel, const int *__restrict__ chunk_start, const int *__restrict__ chunk_len,
+    const int *__restrict__ chunk_off, const float *__restrict__ mel_w, int n_chunks, int n_melw,
+    const float *__restrict__ sc_mean, const float *__restrict__ sc_rstd, float *__restrict__ out,
+    float *__restrict__ chan_max, int n_samples, int T, int layout) {
+    // twiddles and window stay in global memory (14 KB, L1/L2 resident): 46 KB of LDS -> three workgroups per CU
+    const float2 *__restrict__ tw = reinterpret_cast<const float2 *>(twiddle);
+    const float *__restrict__ win = window;
+    __shared__ float2 bufA[2 * FN + 4];          // doubles as the [601][8] per-bin feature table after the last FFT stage
     __shared__ float2 bufB[2 * FN];
-    __shared__ float spec[FBINS * SPS];
+    __shared__ float melw[MAX_MELW];
+    __shared__ float melacc[NMEL * 8];
     __shared__ float cmax[4][4];
+    float *spec = reinterpret_cast<float *>(bufA);
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * FR;
-    for (int i = tid; i < FN; i += 256) {
-        tw[i] = reinterpret_cast<const float2 *>(twiddle)[i];
-        win[i] = window[i];
-    }
-    float lmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int i = tid; i < n_melw; i += 256) melw[i] = mel_w[i];
+    float lmax = -INFINITY;                       // lanes with (tid & 7) < 4 track channel tid & 7 (layout-independent)
     const float4 *aud = reinterpret_cast<const float4 *>(audio) + (size_t)b * n_samples;
+    // audio of the next frame is prefetched into registers while the current frame is transformed
+    float4 av[5];
+    auto load_frame = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int n = tid + i * 256;
+            if (n < FN) {
+                int s = t * FHOP - FHOP + n;
+                if (s < 0) s = -s;                   // np.pad(..., mode='reflect')
+                av[i] = aud[s];
+            }
+        }
+    };
+    if (t0 < T) load_frame(t0);
     __syncthreads();
     for (int fr = 0; fr < FR; ++fr) {
         const int t = t0 + fr;
         if (t >= T) break;
-        for (int n = tid; n < FN; n += 256) {
-            int s = t * FHOP - FHOP + n;
-            if (s < 0) s = -s;                       // np.pad(..., mode='reflect')
-            const float4 a = aud[s];
-            const float w = win[n];
-            bufA[n] = make_float2(a.x * w, a.y * w);
-            bufA[FN + n] = make_float2(a.z * w, a.w * w);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int n = tid + i * 256;
+            if (n < FN) {
+                const float w = win[n];
+                bufA[n] = make_float2(av[i].x * w, av[i].y * w);
+                bufA[FN + n] = make_float2(av[i].z * w, av[i].w * w);
+            }
         }
+        for (int i = tid; i < NMEL * 8; i += 256) melacc[i] = 0.f;
         __syncthreads();
-        fft_stage<4>(bufA, bufB, tw, 1, tid);
+        if (fr + 1 < FR && t + 1 < T) load_frame(t + 1);
+        fft_stage<10, 1>(bufA, bufB, tw, tid);
         __syncthreads();
-        fft_stage<4>(bufB, bufA, tw, 4, tid);
+        fft_stage<10, 10>(bufB, bufA, tw, tid);
         __syncthreads();
-        fft_stage<3>(bufA, bufB, tw, 16, tid);
-        __syncthreads();
-        fft_stage<5>(bufB, bufA, tw, 48, tid);
-        __syncthreads();
-        fft_stage<5>(bufA, bufB, tw, 240, tid);
+        fft_stage<12, 100>(bufA, bufB, tw, tid);
         __syncthreads();
         for (int k = tid; k < FBINS; k += 256) {
             const int kn = k == 0 ? 0 : FN - k;
@@ -135,41 +201,40 @@ __global__ __launch_bounds__(256, 2) void feat_stft_mel_kernel(
             const float pw = W.x * W.x + W.y * W.y, py = Y.x * Y.x + Y.y * Y.y;
             const float pz = Z.x * Z.x + Z.y * Z.y, px = X.x * X.x + X.y * X.y;
             const float e = 1e-8f + (pw + (py + pz + px) / 3.0f);
-            float *sp = &spec[k * SPS];
-            sp[0] = pw; sp[1] = py; sp[2] = pz; sp[3] = px;
-            sp[4] = (W.x * Y.x + W.y * Y.y) / e;
-            sp[5] = (W.x * Z.x + W.y * Z.y) / e;
-            sp[6] = (W.x * X.x + W.y * X.y) / e;
+            const float ie = 1.0f / e;
+            float4 *sp = reinterpret_cast<float4 *>(&spec[k * SPS8]);
+            sp[0] = make_float4(pw, py, pz, px);
+            sp[1] = make_float4((W.x * Y.x + W.y * Y.y) * ie, (W.x * Z.x + W.y * Z.y) * ie, (W.x * X.x + W.y * X.y) * ie, 0.f);
+        }
+        __syncthreads();
+        // sparse mel contraction: work item = (chunk of <= 16 consecutive bins of one filter, feature channel)
+        for (int it = tid; it < n_chunks * 7; it += 256) {
+            const int ck = it / 7, c = it - ck * 7;
+            const int st = chunk_start[ck], ln = chunk_len[ck], of = chunk_off[ck];
+            float s = 0.f;
+#pragma unroll 4
+            for (int i = 0; i < ln; ++i) s += melw[of + i] * spec[(st + i) * SPS8 + c];
+            atomicAdd(&melacc[chunk_mel[ck] * 8 + c], s);
         }
         __syncthreads();
         for (int o = tid; o < 512; o += 256) {
-            int c, m;
-            if (layout == 0) { c = o >> 6; m = o & 63; } else { m = o >> 3; c = o & 7; }
-            if (c == 7) {
-                if (layout == 1) out[(((size_t)b * T + t) * NMEL + m) * 8 + 7] = 0.f;
-                continue;
-            }
-            const int st = mel_start[m], ln = mel_len[m], of = mel_off[m];
-            float s = 0.f;
-            for (int i = 0; i < ln; ++i) s += mel_w[of + i] * spec[(st + i) * SPS + c];
-            float v;
+            const int m = o >> 3, c = o & 7;
+            float v = 0.f;
             if (c < 4) {
-                v = 10.0f * log10f(fmaxf(s, 1e-10f));
-                lmax[c] = fmaxf(lmax[c], v);
-            } else {
-                v = (s - sc_mean[c * NMEL + m]) * sc_rstd[c * NMEL + m];
+                v = 10.0f * log10f(fmaxf(melacc[o], 1e-10f));
+                lmax = fmaxf(lmax, v);
+            } else if (c < 7) {
+                v = (melacc[o] - sc_mean[c * NMEL + m]) * sc_rstd[c * NMEL + m];
             }
-            if (layout == 0) out[(((size_t)b * 7 + c) * T + t) * NMEL + m] = v;
-            else out[(((size_t)b * T + t) * NMEL + m) * 8 + c] = v;
+            if (layout == 1) out[(((size_t)b * T + t) * NMEL + m) * 8 + c] = v;
+            else if (c < 7) out[(((size_t)b * 7 + c) * T + t) * NMEL + m] = v;
         }
         __syncthreads();
     }
+    // per-channel maximum of the un-clipped log-mel: lanes with equal (tid & 7) hold the same channel
+    for (int o = 32; o >= 8; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o, 64));
     const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float v = wave_max(lmax[c]);
-        if (lane == 0) cmax[wave][c] = v;
-    }
+    if (lane < 4) cmax[wave][lane] = lmax;
     __syncthreads();
     if (tid < 4) {
         const float v = fmaxf(fmaxf(cmax[0][tid], cmax[1][tid]), fmaxf(cmax[2][tid], cmax[3][tid]));
@@ -208,14 +273,17 @@ __global__ __launch_bounds__(256) void feat_finish_kernel(float *__restrict__ ou
 using namespace adyolo;
 
 extern "C" int adyolo_feat_stft_mel(const float *audio, const float *twiddle, const float *window,
-                                    const int32_t *mel_start, const int32_t *mel_len, const int32_t *mel_off,
-                                    const float *mel_w, const float *scaler_mean, const float *scaler_rstd, float *out,
-                                    float *chan_max, int B, int n_samples, int layout, void *stream) {
-    ADYOLO_REQUIRE(audio && twiddle && window && mel_start && mel_len && mel_off && mel_w && scaler_mean &&
-                       scaler_rstd && out && chan_max,
+                                    const int32_t *chunk_mel, const int32_t *chunk_start, const int32_t *chunk_len,
+                                    const int32_t *chunk_off, const float *mel_w, int n_chunks, int n_mel_w,
+                                    const float *scaler_mean, const float *scaler_rstd, float *out, float *chan_max,
+                                    int B, int n_samples, int layout, void *stream) {
+    ADYOLO_REQUIRE(audio && twiddle && window && chunk_mel && chunk_start && chunk_len && chunk_off && mel_w &&
+                       scaler_mean && scaler_rstd && out && chan_max,
                    ADYOLO_EINVAL, "feat_stft_mel: null pointer");
     ADYOLO_REQUIRE(B > 0 && n_samples >= 1200 && n_samples % FHOP == 0 && (layout == 0 || layout == 1), ADYOLO_EINVAL,
                    "feat_stft_mel: n_samples=%d must be a multiple of 600 and >= 1200", n_samples);
+    ADYOLO_REQUIRE(n_chunks > 0 && n_mel_w > 0 && n_mel_w <= MAX_MELW, ADYOLO_ENOSUP,
+                   "feat_stft_mel: %d mel weights exceed the LDS table (%d)", n_mel_w, MAX_MELW);
     hipStream_t st = as_stream(stream);
     const int T = n_samples / FHOP;
     hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(chan_max), (int)0xFF800000, (size_t)B * 4, st);
@@ -223,8 +291,9 @@ extern "C" int adyolo_feat_stft_mel(const float *audio, const float *twiddle, co
         set_error("feat_stft_mel: memset failed: %s", hipGetErrorString(e));
         return (int)e;
     }
-    hipLaunchKernelGGL(feat_stft_mel_kernel, dim3(cdiv(T, FR), B), dim3(256), 0, st, audio, twiddle, window, mel_start,
-                       mel_len, mel_off, mel_w, scaler_mean, scaler_rstd, out, chan_max, n_samples, T, layout);
+    hipLaunchKernelGGL(feat_stft_mel_kernel, dim3(cdiv(T, FR), B), dim3(256), 0, st, audio, twiddle, window, chunk_mel,
+                       chunk_start, chunk_len, chunk_off, mel_w, n_chunks, n_mel_w, scaler_mean, scaler_rstd, out,
+                       chan_max, n_samples, T, layout);
     return check_launch("feat_stft_mel");
 }
 

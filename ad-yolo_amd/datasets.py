@@ -103,3 +103,54 @@ def synthetic_targets(batch, nb_label_frames, nb_classes, seed=1234, encoder=Non
     ids = rows[:, 0].astype(np.int64)
     target = np.concatenate([b_ev[ids, None].astype(np.float64), f_ev[ids, None].astype(np.float64), rows[:, 1:]], axis=1)
     return torch.from_numpy(target.astype(np.float32))
+
+
+# ------------------------------------------------------------------------------- other --loss label encoders
+def _polar_to_xyz(az_deg, el_deg):
+    """reference utils/seld_metrics.py:50-65 (convert_output_format_polar_to_cartesian)."""
+    el = el_deg * np.pi / 180.0
+    az = az_deg * np.pi / 180
+    c = np.cos(el)
+    return np.cos(az) * c, np.sin(az) * c, np.sin(el)
+
+
+class ClasswiseLabelEncoder:
+    """SEDDOA / ACCDOA / ADPIT frame labels (reference datasets.py:296-348, :350-455).  label: {frame: [[cls, src, az, el]]}."""
+
+    def __init__(self, nb_classes):
+        self.nb_classes = nb_classes
+
+    def _sexyz(self, label, nb_label_frames):
+        c = self.nb_classes
+        se, x, y, z = (np.zeros((nb_label_frames, c)) for _ in range(4))
+        for frame, events in label.items():
+            if frame < nb_label_frames:
+                for ev in events:                           # later events of the same class overwrite (as upstream)
+                    ex, ey, ez = _polar_to_xyz(ev[2], ev[3])
+                    se[frame, ev[0]], x[frame, ev[0]], y[frame, ev[0]], z[frame, ev[0]] = 1, ex, ey, ez
+        return se, x, y, z
+
+    def get_seddoa_label(self, label, nb_label_frames):
+        se, x, y, z = self._sexyz(label, nb_label_frames)
+        return torch.Tensor(np.concatenate((se, x, y, z), axis=1))
+
+    def get_accdoa_label(self, label, nb_label_frames):
+        se, x, y, z = self._sexyz(label, nb_label_frames)
+        return torch.Tensor(np.tile(se, 3) * np.concatenate((x, y, z), axis=1))
+
+    def get_adpit_label(self, label, nb_label_frames):
+        """(T', 6, 4, C): dummies A0 | B0 B1 | C0 C1 C2 by how many same-class events overlap (1 / 2 / >=3)."""
+        c = self.nb_classes
+        out = np.zeros((nb_label_frames, 6, 4, c))
+        for frame, events in label.items():
+            if frame >= nb_label_frames:
+                continue
+            by_class = {}
+            for ev in sorted(events, key=lambda e: e[0]):   # stable sort by class, like list.sort(key=...)
+                by_class.setdefault(ev[0], []).append(ev)
+            for cls, evs in by_class.items():
+                slots = (0,) if len(evs) == 1 else ((1, 2) if len(evs) == 2 else (3, 4, 5))
+                for slot, ev in zip(slots, evs):            # at most the first three events of a class are kept
+                    ex, ey, ez = _polar_to_xyz(ev[2], ev[3])
+                    out[frame, slot, :, cls] = (1.0, ex, ey, ez)
+        return torch.Tensor(out)

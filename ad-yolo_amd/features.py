@@ -61,13 +61,17 @@ class FeatureExtractor:
         tw = np.stack([np.cos(2.0 * np.pi * n / N_FFT), -np.sin(2.0 * np.pi * n / N_FFT)], axis=1)
         win = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / N_FFT)
         mel = slaney_mel_matrix()
-        start, length, offs, weights = [], [], [], []
+        # non-zero weights filter after filter, each (contiguous, triangular) filter cut into pieces of <= 16 bins so
+        # that the kernel's work items are balanced (filters span 2 .. ~70 bins)
+        ck_mel, ck_start, ck_len, ck_off, weights = [], [], [], [], []
         for m in range(N_MELS):
             nz = np.nonzero(mel[m])[0]
             s, e = int(nz[0]), int(nz[-1]) + 1
-            start.append(s)
-            length.append(e - s)
-            offs.append(len(weights))
+            for c0 in range(s, e, 16):
+                ck_mel.append(m)
+                ck_start.append(c0)
+                ck_len.append(min(16, e - c0))
+                ck_off.append(len(weights) + (c0 - s))
             weights.extend(mel[m, s:e].tolist())
         mean = np.zeros((7, N_MELS), dtype=np.float64)
         std = np.ones((7, N_MELS), dtype=np.float64)
@@ -80,7 +84,8 @@ class FeatureExtractor:
         f32 = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev).contiguous()   # noqa: E731
         i32 = lambda a: torch.tensor(np.asarray(a, dtype=np.int32), device=dev).contiguous()     # noqa: E731
         self.twiddle, self.window = f32(tw), f32(win)
-        self.mel_start, self.mel_len, self.mel_off = i32(start), i32(length), i32(offs)
+        self.ck_mel, self.ck_start, self.ck_len, self.ck_off = i32(ck_mel), i32(ck_start), i32(ck_len), i32(ck_off)
+        self.n_chunks = len(ck_mel)
         self.mel_w = f32(weights)
         self.sc_mean, self.sc_rstd = f32(mean), f32(1.0 / std)
         self.mel_nnz = len(weights)
@@ -99,9 +104,9 @@ class FeatureExtractor:
                           device=audio.device)
         chan_max = torch.empty(b * 4, dtype=torch.float32, device=audio.device)
         st = _stream()
-        _lib.call("adyolo_feat_stft_mel", _p(audio), _p(self.twiddle), _p(self.window), _p(self.mel_start),
-                  _p(self.mel_len), _p(self.mel_off), _p(self.mel_w), _p(self.sc_mean), _p(self.sc_rstd), _p(out),
-                  _p(chan_max), b, n, layout, st)
+        _lib.call("adyolo_feat_stft_mel", _p(audio), _p(self.twiddle), _p(self.window), _p(self.ck_mel),
+                  _p(self.ck_start), _p(self.ck_len), _p(self.ck_off), _p(self.mel_w), self.n_chunks, self.mel_nnz,
+                  _p(self.sc_mean), _p(self.sc_rstd), _p(out), _p(chan_max), b, n, layout, st)
         _lib.call("adyolo_feat_finish", _p(out), _p(chan_max), _p(self.sc_mean), _p(self.sc_rstd), b, t, layout, st)
         return out
 

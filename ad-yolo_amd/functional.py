@@ -315,3 +315,44 @@ class ADYOLOLossFn(torch.autograd.Function):
     def backward(ctx, dloss):
         (dlogit,) = ctx.saved_tensors
         return ops.scale_dev(dlogit, _c(dloss).view(1)), None, None
+
+
+class ActFn(torch.autograd.Function):
+    """Head activation: sigmoid on the first ``n_sig`` columns, tanh on the rest (reference linearheads.py:44-47,65,83)."""
+
+    @staticmethod
+    def forward(ctx, x, n_sig):
+        k = x.shape[-1]
+        y = ops.act_fwd(_c(x).view(-1, k), n_sig)
+        ctx.n_sig = n_sig
+        ctx.save_for_backward(y)
+        return y.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.act_bwd(_c(dy).view(-1, y.shape[-1]), y, ctx.n_sig).view_as(dy), None
+
+
+class _FusedLossFn(torch.autograd.Function):
+    """Losses whose gradient w.r.t. the network output is produced by the same launch as the value."""
+
+    @staticmethod
+    def forward(ctx, output, target, kind, cfg):
+        k = output.shape[-1]
+        need = ctx.needs_input_grad[0]
+        out2d = _c(output).view(-1, k)
+        if kind == "adpit":
+            loss, dout = ops.adpit_loss(out2d, _c(target), cfg["nb_classes"], need)
+        else:
+            loss, dout = ops.seddoa_loss(out2d, _c(target).view(-1, k), cfg["nsed"], cfg["masked"], cfg["w_bce"],
+                                         cfg["w_mse"], need)
+        if dout is not None:
+            ctx.save_for_backward(dout)
+        ctx.shape = output.shape
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dout,) = ctx.saved_tensors
+        return ops.scale_dev(dout, _c(dloss).view(1)).view(ctx.shape), None, None, None

@@ -53,7 +53,7 @@ class ACCDOAhead(nn.Module):
         _init_head(self.accdoa_head)
 
     def forward(self, x):
-        return torch.tanh(self.accdoa_head(x))
+        return Fn.ActFn.apply(self.accdoa_head(x), 0)
 
 
 class ADPIThead(nn.Module):
@@ -63,7 +63,7 @@ class ADPIThead(nn.Module):
         _init_head(self.adpit_head)
 
     def forward(self, x):
-        return torch.tanh(self.adpit_head(x))
+        return Fn.ActFn.apply(self.adpit_head(x), 0)
 
 
 class SEDDOAhead(nn.Module):
@@ -75,4 +75,6 @@ class SEDDOAhead(nn.Module):
         _init_head(self.doa_head)
 
     def forward(self, x):
-        return torch.cat([torch.sigmoid(self.sed_head(x)), torch.tanh(self.doa_head(x))], dim=-1)
+        # cat is a copy (plumbing); the activations run in one HIP pass: sigmoid on the SED columns, tanh on the DOA ones
+        raw = torch.cat([self.sed_head(x), self.doa_head(x)], dim=-1)
+        return Fn.ActFn.apply(raw, self.sed_head[1].weight.shape[0])

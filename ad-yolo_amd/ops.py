@@ -370,6 +370,41 @@ def adyolo_loss(logit, target, nb_classes, grid=(8, 4), anchors=5, thr=(45.0, 25
     return loss, dlogit, dist
 
 
+def act_fwd(x2d, n_sigmoid_cols):
+    """columns [0, n_sigmoid_cols) -> sigmoid, the rest -> tanh."""
+    _chk(x2d)
+    y = torch.empty_like(x2d)
+    _c("adyolo_act_fwd", _p(x2d), _p(y), x2d.shape[0], x2d.shape[1], int(n_sigmoid_cols), _stream())
+    return y
+
+
+def act_bwd(dy2d, y2d, n_sigmoid_cols):
+    _chk(dy2d, y2d)
+    dx = torch.empty_like(y2d)
+    _c("adyolo_act_bwd", _p(dy2d), _p(y2d), _p(dx), y2d.shape[0], y2d.shape[1], int(n_sigmoid_cols), _stream())
+    return dx
+
+
+def seddoa_loss(out2d, tgt2d, nsed, masked, w_bce, w_mse, need_grad=True):
+    _chk(out2d, tgt2d)
+    loss = _new(out2d, 1)
+    dout = torch.empty_like(out2d) if need_grad else None
+    partial = _new(out2d, 2 * 1024)
+    _c("adyolo_seddoa_loss", _p(out2d), _p(tgt2d), _p(loss), _p(dout), _p(partial), out2d.shape[0], out2d.shape[1],
+       int(nsed), int(masked), float(w_bce), float(w_mse), _stream())
+    return loss, dout
+
+
+def adpit_loss(out2d, tgt, nb_classes, need_grad=True):
+    """out2d [rows][9*C], tgt [rows][6][4][C]."""
+    _chk(out2d, tgt)
+    loss = _new(out2d, 1)
+    dout = torch.empty_like(out2d) if need_grad else None
+    partial = _new(out2d, 1024)
+    _c("adyolo_adpit_loss", _p(out2d), _p(tgt), _p(loss), _p(dout), _p(partial), out2d.shape[0], int(nb_classes), _stream())
+    return loss, dout
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
               grad_scale=1.0):
     _chk(param, grad, exp_avg, exp_avg_sq)

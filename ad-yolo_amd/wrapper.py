@@ -1,14 +1,14 @@
 """Plugin surface: name-keyed dispatch of encoder / head / loss.  Mirror of /root/reference/src/wrapper.py
 (WrapperModel :10-57, WrapperCriterion :62-88): same constructor arguments, same attribute names
 (``encoder``, ``head`` -> state_dict prefixes), same NotImplementedError behaviour for unknown names.
-``--encoder se-resnet34 --loss adyolo`` is the MI355X hot path; the remaining names of the reference's
-CLI (resnet-conformer, seddoa/masked-seddoa/accdoa/adpit losses) are outside SURVEY.md section 8's first rows
-and raise NotImplementedError naming what is missing rather than silently falling back."""
+``--encoder se-resnet34`` with every ``--loss`` of the reference's CLI (adyolo, adpit, accdoa, seddoa,
+masked-seddoa) runs on the gfx950 kernels; ``resnet-conformer`` is not built yet and raises NotImplementedError
+naming what is missing rather than silently falling back."""
 import torch.nn as nn
 
 from .models.backbones.resnet import SEResnet34
 from .models.linearheads import ADYOLOhead, ACCDOAhead, ADPIThead, SEDDOAhead
-from .models.loss import ADYOLOloss
+from .models.loss import ADYOLOloss, SEDDOAloss, ACCDOAloss, ADPITloss
 
 
 class WrapperModel(nn.Module):
@@ -48,9 +48,14 @@ class WrapperCriterion(object):
         self.loss_nm = params["args"]["loss"]
         if self.loss_nm == "adyolo":
             self.loss = ADYOLOloss(params)
-        elif self.loss_nm in ("seddoa", "masked-seddoa", "accdoa", "adpit"):
-            raise NotImplementedError("loss: {} is not built yet on the gfx950 path (SURVEY 8a25 / section 2 #15)"
-                                      .format(self.loss_nm))
+        elif self.loss_nm == "seddoa":
+            self.loss = SEDDOAloss(self.nb_classes, masked_mse=False)
+        elif self.loss_nm == "masked-seddoa":
+            self.loss = SEDDOAloss(self.nb_classes, masked_mse=True)
+        elif self.loss_nm == "accdoa":
+            self.loss = ACCDOAloss(self.nb_classes)
+        elif self.loss_nm == "adpit":
+            self.loss = ADPITloss(self.nb_classes)
         else:
             raise NotImplementedError("loss: {}".format(self.loss_nm))
 

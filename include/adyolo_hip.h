@@ -36,8 +36,9 @@ const char *adyolo_last_error(void);
  *     scaler :289-290) and the tensorise/concat step :158-160.
  *   audio   [B][n_samples][4] float32, already int16/32768 + 1e-8 (datasets.py:147), channels W,Y,Z,X
  *   twiddle [1200][2]  exp(-2 pi i n/1200) (re,im);  window [1200];
- *   mel_start/mel_len [64] int32: first FFT bin and number of bins of each (contiguous) mel filter;
- *   mel_w   [sum(mel_len)] float32 weights, filter after filter (mel_off[m] = prefix sum, [64] int32)
+ *   mel_w   [n_mel_w <= 1280] float32 non-zero weights of the 64 (contiguous, triangular) mel filters, filter
+ *           after filter; the filters are cut into n_chunks pieces of <= 16 bins for load balance:
+ *           chunk_mel[i] = filter index, chunk_start[i] = first FFT bin, chunk_len[i], chunk_off[i] = offset in mel_w
  *   scaler_mean/scaler_rstd [7][64]: (x-mean)*rstd per (feature channel, mel bin)
  *   out     layout 0: [B][7][T][64]  (reference order, datasets.py:160)
  *           layout 1: [B][T][64][8]  (channels-last, 8th channel zero) -- what the encoder consumes
@@ -47,9 +48,10 @@ const char *adyolo_last_error(void);
  * adyolo_feat_finish (top_db clip relative to chan_max + z-score of the 4 log-mel channels).
  * ---------------------------------------------------------------------------------------------- */
 int adyolo_feat_stft_mel(const float *audio, const float *twiddle, const float *window,
-                         const int32_t *mel_start, const int32_t *mel_len, const int32_t *mel_off,
-                         const float *mel_w, const float *scaler_mean, const float *scaler_rstd,
-                         float *out, float *chan_max, int B, int n_samples, int layout, void *stream);
+                         const int32_t *chunk_mel, const int32_t *chunk_start, const int32_t *chunk_len,
+                         const int32_t *chunk_off, const float *mel_w, int n_chunks, int n_mel_w,
+                         const float *scaler_mean, const float *scaler_rstd, float *out, float *chan_max, int B,
+                         int n_samples, int layout, void *stream);
 int adyolo_feat_finish(float *out, const float *chan_max, const float *scaler_mean,
                        const float *scaler_rstd, int B, int T, int layout, void *stream);
 /* [B][C][H][W] (C<=8) -> [B][H][W][8] zero padded; entry of WrapperModel.forward (wrapper.py:52-57) */
@@ -223,6 +225,23 @@ int  adyolo_loss_fwd_bwd(const float *logit, const float *target, float *ws, flo
                          float *dlogit, float *dist, int B, int T, int Gaz, int Gel, int A, int C,
                          int M, const float *thr_host, const float *gains_host, float grid_az,
                          float grid_el, float g_overlap, float grad_scale, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K10 the other heads / losses behind the reference's --loss switch (src/main.py:43)
+ *   adyolo_act_fwd/bwd : y[r][c] = c < n_sigmoid_cols ? sigmoid(x) : tanh(x)   (linearheads.py:44-47,65,83)
+ *   adyolo_seddoa_loss : w_bce * mean BCE(out[:, :nsed], tgt[:, :nsed]) + w_mse * mean((out[:, nsed:] * m - tgt[:, nsed:])^2),
+ *                        m = tgt activity of the column's class when `masked` (SEDDOAloss loss.py:32-54: w = 1, 1000;
+ *                        ACCDOAloss loss.py:57-67: nsed = 0, w_mse = 1).  partial: 2*1024 floats.  dout may be NULL.
+ *   adyolo_adpit_loss  : ADPITloss (loss.py:70-153): out [rows][9][C], tgt [rows][6][4][C]; 13-permutation min-MSE.
+ *                        partial: 1024 floats.
+ * ---------------------------------------------------------------------------------------------- */
+int adyolo_act_fwd(const float *x, float *y, long rows, int cols, int n_sigmoid_cols, void *stream);
+int adyolo_act_bwd(const float *dy, const float *y, float *dx, long rows, int cols, int n_sigmoid_cols,
+                   void *stream);
+int adyolo_seddoa_loss(const float *out, const float *tgt, float *loss, float *dout, float *partial, long rows,
+                       int cols, int nsed, int masked, float w_bce, float w_mse, void *stream);
+int adyolo_adpit_loss(const float *out, const float *tgt, float *loss, float *dout, float *partial, long rows,
+                      int C, void *stream);
 
 /* K11 fused Adam over one flat parameter buffer (torch.optim.Adam at src/train.py:31,55; no amsgrad) */
 int adyolo_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long n,

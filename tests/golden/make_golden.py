@@ -216,6 +216,46 @@ def gen_init():
     print("init_seed100.npz", len(names))
 
 
+def gen_other_losses():
+    """SEDDOA / masked-SEDDOA / ACCDOA / ADPIT: labels from the reference encoders, loss + gradient from the reference losses."""
+    from datasets import FeatureLabelProcessor
+    from models.loss import SEDDOAloss, ACCDOAloss, ADPITloss
+    from models.linearheads import SEDDOAhead, ADPIThead
+    out = {}
+    events = {0: [[3, 0, 10.0, 5.0]], 1: [[3, 0, 10.0, 5.0], [7, 1, -170.0, 40.0]],
+              2: [[0, 0, 180.0, -30.0], [0, 1, 175.0, -35.0]], 3: [[5, 0, 44.9, -90.0], [5, 1, 50.0, -80.0], [5, 2, 47.0, -85.0]],
+              4: [[2, 0, 1.0, 2.0], [2, 1, 3.0, 4.0], [2, 2, 5.0, 6.0], [2, 3, 7.0, 8.0], [9, 4, -60.0, 30.0]],
+              6: [[11, 0, -90.0, 0.0], [4, 1, 90.0, 0.0], [11, 2, 0.0, 45.0]], 9: [[6, 0, 20.0, 20.0]]}
+    g = torch.Generator().manual_seed(41)
+    for name in ("seddoa", "accdoa", "adpit"):
+        prm = make_params()
+        prm["args"]["loss"] = name
+        flp = FeatureLabelProcessor(prm)
+        lab = flp.get_label(copy.deepcopy(events), 8)
+        out["label_" + name] = lab.numpy()
+    c = 12
+    tgt_sed = torch.stack([torch.from_numpy(out["label_seddoa"]), torch.from_numpy(out["label_seddoa"]).flip(0)])
+    o_sed = torch.cat([torch.rand(2, 8, c, generator=g), torch.rand(2, 8, 3 * c, generator=g) * 2 - 1], -1).requires_grad_(True)
+    for tag, masked in (("seddoa", False), ("masked", True)):
+        o = o_sed.detach().clone().requires_grad_(True)
+        loss = SEDDOAloss(c, masked_mse=masked)(o, tgt_sed)
+        loss.backward()
+        out[tag + "_out"], out[tag + "_loss"], out[tag + "_dout"] = o.detach().numpy(), loss.detach().numpy(), o.grad.numpy()
+    out["sed_target"] = tgt_sed.numpy()
+    tgt_acc = torch.stack([torch.from_numpy(out["label_accdoa"]), torch.from_numpy(out["label_accdoa"]).flip(0)])
+    o = (torch.rand(2, 8, 3 * c, generator=g) * 2 - 1).requires_grad_(True)
+    loss = ACCDOAloss(c)(o, tgt_acc)
+    loss.backward()
+    out["accdoa_out"], out["accdoa_target"], out["accdoa_loss"], out["accdoa_dout"] = o.detach().numpy(), tgt_acc.numpy(), loss.detach().numpy(), o.grad.numpy()
+    tgt_ad = torch.stack([torch.from_numpy(out["label_adpit"]), torch.from_numpy(out["label_adpit"]).flip(0)])
+    o = (torch.rand(2, 8, 9 * c, generator=g) * 2 - 1).requires_grad_(True)
+    loss = ADPITloss(c)(o, tgt_ad)
+    loss.backward()
+    out["adpit_out"], out["adpit_target"], out["adpit_loss"], out["adpit_dout"] = o.detach().numpy(), tgt_ad.numpy(), loss.detach().numpy(), o.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "other_losses.npz"), **out)
+    print("other_losses.npz", {k: float(out[k]) for k in out if k.endswith("_loss")})
+
+
 def gen_scaler():
     import pickle
     for d in ("DCASE2021", "DCASE2022"):
@@ -234,4 +274,5 @@ if __name__ == "__main__":
     gen_loss(flp)
     gen_encoder()
     gen_init()
+    gen_other_losses()
     gen_scaler()

@@ -374,6 +374,60 @@ def test_loss_large_random_vs_oracle(ops):
     assert err < 2e-7 + 1e-3 * float(lo.grad.abs().max()), "dlogit abs err %.3e" % err
 
 
+def test_other_losses_and_heads_match_reference_golden(ops):
+    """SEDDOA / masked-SEDDOA / ACCDOA / ADPIT losses (value + gradient) and the head activations."""
+    from adyolo_amd.models.loss import SEDDOAloss, ACCDOAloss, ADPITloss
+    from adyolo_amd import functional as Fn
+    from oracle import other_losses as ool
+    g = np.load(os.path.join(G, "other_losses.npz"))
+    cases = [("seddoa", SEDDOAloss(12, masked_mse=False), "sed_target"), ("masked", SEDDOAloss(12, masked_mse=True), "sed_target"),
+             ("accdoa", ACCDOAloss(12), "accdoa_target"), ("adpit", ADPITloss(12), "adpit_target")]
+    for tag, crit, tkey in cases:
+        o = dev(torch.from_numpy(g[tag + "_out"])).requires_grad_(True)
+        loss = crit(o, torch.from_numpy(g[tkey]))
+        (loss * 1.0).backward()
+        torch.cuda.synchronize()
+        assert_close(loss, torch.from_numpy(g[tag + "_loss"]), 1e-5, tag + " loss")
+        gold = torch.from_numpy(g[tag + "_dout"])
+        err = float((o.grad.cpu() - gold).abs().max())
+        assert err <= 1e-4 * float(gold.abs().max()) + 1e-9, "%s dout err %.3e (absmax %.3e)" % (tag, err, float(gold.abs().max()))
+    gen = torch.Generator().manual_seed(8)
+    raw = torch.randn(3, 5, 48, generator=gen)
+    probe = torch.randn(3, 5, 48, generator=gen)
+    ro = raw.clone().requires_grad_(True)
+    (ool.head_activation(ro, 12) * probe).sum().backward()
+    rg = dev(raw).requires_grad_(True)
+    yg = Fn.ActFn.apply(rg, 12)
+    (yg * dev(probe)).sum().backward()
+    assert_close(yg, ool.head_activation(raw, 12), 1e-6, "head activation")
+    assert_close(rg.grad, ro.grad, 1e-6, "head activation grad")
+
+
+@pytest.mark.parametrize("loss_nm", ["adpit", "accdoa", "masked-seddoa"])
+def test_other_loss_plugins_train_end_to_end(ops, loss_nm):
+    from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
+    from adyolo_amd.datasets import ClasswiseLabelEncoder
+    torch.manual_seed(100)
+    prm = _params()
+    prm["args"]["loss"] = loss_nm
+    model = WrapperModel((1, 7, 32, 64), (), prm).to("cuda:0")
+    crit = WrapperCriterion(prm)
+    enc = ClasswiseLabelEncoder(12)
+    events = {0: [[3, 0, 10.0, 5.0]], 2: [[3, 0, 10.0, 5.0], [3, 1, -170.0, 40.0]], 5: [[1, 0, 0.0, 0.0], [2, 1, 90.0, 10.0]]}
+    lab = {"adpit": enc.get_adpit_label, "accdoa": enc.get_accdoa_label, "masked-seddoa": enc.get_seddoa_label}[loss_nm]
+    target = torch.stack([lab(events, 8), lab({}, 8)])
+    x = torch.randn(2, 7, 32, 64).to("cuda:0")
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        loss = crit(model(x), target)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
 # ------------------------------------------------------------------------------------------------ features
 def test_features_match_oracle(ops):
     from oracle import features as ofeat

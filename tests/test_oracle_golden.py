@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+import adyolo_amd  # noqa: F401
 from oracle import adyolo_loss as oloss
 from oracle import features as ofeat
 from oracle import labels as olab
@@ -181,3 +182,40 @@ def test_feature_shapes_and_topdb():
         assert feat[ch].max() - feat[ch].min() <= 80.0 + 1e-4
     g = np.load(os.path.join(G, "scaler_DCASE2021.npz"))
     assert g["mel_mean"].shape == (1, 64, 4) and g["iv_std"].shape == (1, 64, 3)
+
+
+# ---- the other --loss plugins (SEDDOA / masked-SEDDOA / ACCDOA / ADPIT) -------------------------------------
+OTHER_EVENTS = {0: [[3, 0, 10.0, 5.0]], 1: [[3, 0, 10.0, 5.0], [7, 1, -170.0, 40.0]],
+                2: [[0, 0, 180.0, -30.0], [0, 1, 175.0, -35.0]],
+                3: [[5, 0, 44.9, -90.0], [5, 1, 50.0, -80.0], [5, 2, 47.0, -85.0]],
+                4: [[2, 0, 1.0, 2.0], [2, 1, 3.0, 4.0], [2, 2, 5.0, 6.0], [2, 3, 7.0, 8.0], [9, 4, -60.0, 30.0]],
+                6: [[11, 0, -90.0, 0.0], [4, 1, 90.0, 0.0], [11, 2, 0.0, 45.0]], 9: [[6, 0, 20.0, 20.0]]}
+
+
+def test_other_label_encoders_match_reference():
+    from oracle import other_losses as ool
+    from adyolo_amd.datasets import ClasswiseLabelEncoder
+    g = np.load(os.path.join(G, "other_losses.npz"))
+    ev = lambda: {k: [list(e) for e in v] for k, v in OTHER_EVENTS.items()}   # noqa: E731
+    np.testing.assert_array_equal(ool.seddoa_label(ev(), 8, 12), g["label_seddoa"])
+    np.testing.assert_array_equal(ool.accdoa_label(ev(), 8, 12), g["label_accdoa"])
+    np.testing.assert_array_equal(ool.adpit_label(ev(), 8, 12), g["label_adpit"])
+    enc = ClasswiseLabelEncoder(12)
+    np.testing.assert_array_equal(enc.get_seddoa_label(ev(), 8).numpy(), g["label_seddoa"])
+    np.testing.assert_array_equal(enc.get_accdoa_label(ev(), 8).numpy(), g["label_accdoa"])
+    np.testing.assert_array_equal(enc.get_adpit_label(ev(), 8).numpy(), g["label_adpit"])
+
+
+def test_other_losses_match_reference():
+    from oracle import other_losses as ool
+    g = np.load(os.path.join(G, "other_losses.npz"))
+    cases = [("seddoa", lambda o: ool.seddoa_loss(o, torch.from_numpy(g["sed_target"]), 12, False)),
+             ("masked", lambda o: ool.seddoa_loss(o, torch.from_numpy(g["sed_target"]), 12, True)),
+             ("accdoa", lambda o: ool.accdoa_loss(o, torch.from_numpy(g["accdoa_target"]))),
+             ("adpit", lambda o: ool.adpit_loss(o, torch.from_numpy(g["adpit_target"]), 12))]
+    for tag, fn in cases:
+        o = torch.from_numpy(g[tag + "_out"]).requires_grad_(True)
+        loss = fn(o)
+        loss.backward()
+        np.testing.assert_allclose(loss.detach().numpy(), g[tag + "_loss"], rtol=1e-5, atol=1e-6, err_msg=tag)
+        np.testing.assert_allclose(o.grad.numpy(), g[tag + "_dout"], rtol=1e-4, atol=1e-7, err_msg=tag)
