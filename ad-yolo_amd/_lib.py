@@ -28,6 +28,7 @@ SIGNATURES = {
     "adyolo_conv3x3_wgrad_slabs": (I, [I] * 5),
     "adyolo_conv3x3_wgrad": (I, [P] * 6 + [I] * 6 + [P]),
     "adyolo_gemm": (I, [P] * 5 + [I] * 10 + [P]),
+    "adyolo_gemm_batched": (I, [P] * 3 + [I] * 10 + [L] * 6 + [F, I, P]),
     "adyolo_colsum": (I, [P, P, P, I, I, I, I, P]),
     "adyolo_bn_stats": (I, [P] * 7 + [I, I, I, F, F, P]),
     "adyolo_bn_stats_tiles": (I, [P] * 7 + [I, I, I, I, F, F, P]),
@@ -60,6 +61,26 @@ SIGNATURES = {
     "adyolo_act_bwd": (I, [P, P, P, L, I, I, P]),
     "adyolo_seddoa_loss": (I, [P] * 5 + [L, I, I, I, F, F, P]),
     "adyolo_adpit_loss": (I, [P] * 5 + [L, I, P]),
+    "adyolo_im2col": (I, [P, P] + [I] * 10 + [P]),
+    "adyolo_col2im": (I, [P, P] + [I] * 10 + [P]),
+    "adyolo_pack_wk": (I, [P, P, I, I, I, I, I, P]),
+    "adyolo_maxpool3_fwd": (I, [P, P, P, I, I, I, I, P]),
+    "adyolo_maxpool3_bwd": (I, [P, P, P, I, I, I, I, P]),
+    "adyolo_affine_relu_nhwc": (I, [P] * 4 + [L, I, P]),
+    "adyolo_relu_bwd": (I, [P, P, P, L, P]),
+    "adyolo_axpby": (I, [P, P, P, F, F, L, P]),
+    "adyolo_swish_fwd": (I, [P, P, L, P]),
+    "adyolo_swish_bwd": (I, [P, P, P, L, P]),
+    "adyolo_glu_fwd": (I, [P, P, L, I, P]),
+    "adyolo_glu_bwd": (I, [P, P, P, L, I, P]),
+    "adyolo_dwconv3_fwd": (I, [P] * 4 + [I, I, I, I, I, P]),
+    "adyolo_dwconv3_wgrad": (I, [P] * 6 + [I, I, I, I, P]),
+    "adyolo_softmax_fwd": (I, [P, P, L, I, F, P]),
+    "adyolo_softmax_bwd": (I, [P, P, P, L, I, F, P]),
+    "adyolo_avgpool1d_fwd": (I, [P, P, I, I, I, I, F, P]),
+    "adyolo_avgpool1d_bwd": (I, [P, P, I, I, I, I, F, P]),
+    "adyolo_ln_fwd": (I, [P] * 4 + [L, I, F, P]),
+    "adyolo_ln_bwd": (I, [P] * 7 + [L, I, F, P]),
     "adyolo_adam_step": (I, [P] * 4 + [L, F, F, F, F, F, I, F, P]),
 }
 

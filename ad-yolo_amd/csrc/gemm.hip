@@ -10,11 +10,18 @@ namespace adyolo {
 
 constexpr int GBM = 128, GBN = 64, GBK = 32;
 
+// batched mode: blockIdx.z = outer * inner_count + inner; operand offsets = outer * o? + inner * i? (floats)
+struct GemmBatch {
+    int inner;                 // 0 = not batched (blockIdx.z is then the split-K slice)
+    long oA, iA, oB, iB, oC, iC;
+    float alpha;
+};
+
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                       const float *__restrict__ bias, float *__restrict__ C,
                                                       int M, int N, int K, int lda, int ldb, int ldc, int klen,
-                                                      size_t slab_stride, int slab_ld, int accumulate) {
+                                                      size_t slab_stride, int slab_ld, int accumulate, GemmBatch bt) {
     constexpr int A_LD = TA ? (GBM + 4) : (GBK + 4);
     constexpr int B_LD = TB ? (GBN + 4) : (GBK + 4);
     __shared__ __attribute__((aligned(16))) float As[TA ? GBK * (GBM + 4) : GBM * (GBK + 4)];
@@ -22,7 +29,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
-    const int z = blockIdx.z;
+    int z = blockIdx.z;
+    if (bt.inner > 0) {
+        const long zo = z / bt.inner, zi = z - zo * bt.inner;
+        A += zo * bt.oA + zi * bt.iA;
+        B += zo * bt.oB + zi * bt.iB;
+        C += zo * bt.oC + zi * bt.iC;
+        z = 0;
+    }
     const int kbeg = z * klen;
     const int kend = min(K, kbeg + klen);
 
@@ -114,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ 
                 if (slab_stride) {
                     C[(size_t)z * slab_stride + (size_t)m * slab_ld + nn] = acc[nt][r];
                 } else {
-                    float v = acc[nt][r];
+                    float v = acc[nt][r] * bt.alpha;
                     if (bias) v += bias[nn];
                     const size_t o = (size_t)m * ldc + nn;
                     if (accumulate) v += C[o];
@@ -217,9 +231,10 @@ extern "C" int adyolo_gemm(const float *A, const float *B, const float *bias, fl
     dim3 grid((unsigned)cdiv(N, GBN), (unsigned)cdiv(M, GBM), (unsigned)splits);
     const size_t slab_stride = splits > 1 ? (size_t)M * N : 0;
     float *out = splits > 1 ? slabs : C;
+    GemmBatch bt{0, 0, 0, 0, 0, 0, 0, 1.0f};
 #define LAUNCH(TA_, TB_)                                                                                       \
     hipLaunchKernelGGL((gemm_kernel<TA_, TB_>), grid, dim3(256), 0, st, A, B, bias, out, M, N, K, lda, ldb, ldc, \
-                       klen, slab_stride, N, accumulate)
+                       klen, slab_stride, N, accumulate, bt)
     if (transA && transB) LAUNCH(true, true);
     else if (transA) LAUNCH(true, false);
     else if (transB) LAUNCH(false, true);
@@ -231,6 +246,33 @@ extern "C" int adyolo_gemm(const float *A, const float *B, const float *bias, fl
     hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3(cdiv((long)total, 256)), dim3(256), 0, st, slabs, bias, C, M,
                        N, ldc, splits, accumulate);
     return check_launch("gemm_slab_reduce");
+}
+
+// batched GEMM for attention: batch = outer * inner problems, operand (o, i) at base + o*outer_stride + i*inner_stride;
+// C = alpha * opA opB^T-style product as in adyolo_gemm (no bias, no split-K)
+extern "C" int adyolo_gemm_batched(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb,
+                                   int ldc, int transA, int transB, int outer, int inner, long oA, long iA, long oB,
+                                   long iB, long oC, long iC, float alpha, int accumulate, void *stream) {
+    ADYOLO_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && outer > 0 && inner > 0, ADYOLO_EINVAL, "gemm_batched: bad arguments");
+    ADYOLO_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && (transA ? M : K) % 4 == 0 && (transB ? N : K) % 4 == 0 &&
+                       oA % 4 == 0 && iA % 4 == 0 && oB % 4 == 0 && iB % 4 == 0,
+                   ADYOLO_ENOSUP, "gemm_batched: contiguous axes, leading dimensions and batch strides must be multiples of 4");
+    ADYOLO_REQUIRE((long)outer * inner <= 65535, ADYOLO_ENOSUP, "gemm_batched: more than 65535 problems");
+    hipStream_t st = as_stream(stream);
+    const int klen = cdiv(K, GBK) * GBK;
+    dim3 grid((unsigned)cdiv(N, GBN), (unsigned)cdiv(M, GBM), (unsigned)(outer * inner));
+    GemmBatch bt{inner, oA, iA, oB, iB, oC, iC, alpha};
+    const float *bias = nullptr;
+    const size_t slab_stride = 0;
+#define LAUNCHB(TA_, TB_)                                                                                     \
+    hipLaunchKernelGGL((gemm_kernel<TA_, TB_>), grid, dim3(256), 0, st, A, B, bias, C, M, N, K, lda, ldb, ldc, \
+                       klen, slab_stride, N, accumulate, bt)
+    if (transA && transB) LAUNCHB(true, true);
+    else if (transA) LAUNCHB(true, false);
+    else if (transB) LAUNCHB(false, true);
+    else LAUNCHB(false, false);
+#undef LAUNCHB
+    return check_launch("gemm_batched");
 }
 
 extern "C" int adyolo_colsum(const float *A, float *out, float *partial, int R, int C, int lda, int accumulate,

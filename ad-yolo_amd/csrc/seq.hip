@@ -229,6 +229,7 @@ __global__ __launch_bounds__(384) void gru_bwd_kernel(const float *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------- LayerNorm + tanh (C = 256)
+template <bool TANH>
 __global__ __launch_bounds__(256) void ln_tanh_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, float *__restrict__ y,
                                                           long R, float eps) {
@@ -243,13 +244,15 @@ __global__ __launch_bounds__(256) void ln_tanh_fwd_kernel(const float *__restric
     const float4 g = reinterpret_cast<const float4 *>(gamma)[lane];
     const float4 bt = reinterpret_cast<const float4 *>(beta)[lane];
     float4 o;
-    o.x = tanhf(d.x * is * g.x + bt.x);
-    o.y = tanhf(d.y * is * g.y + bt.y);
-    o.z = tanhf(d.z * is * g.z + bt.z);
-    o.w = tanhf(d.w * is * g.w + bt.w);
+    o.x = d.x * is * g.x + bt.x;
+    o.y = d.y * is * g.y + bt.y;
+    o.z = d.z * is * g.z + bt.z;
+    o.w = d.w * is * g.w + bt.w;
+    if (TANH) o = make_float4(tanhf(o.x), tanhf(o.y), tanhf(o.z), tanhf(o.w));
     reinterpret_cast<float4 *>(y + (size_t)row * 256)[lane] = o;
 }
 
+template <bool TANH>
 __global__ __launch_bounds__(256) void ln_tanh_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                           const float *__restrict__ y, const float *__restrict__ gamma,
                                                           float *__restrict__ dx, float *__restrict__ partial, long R,
@@ -262,8 +265,9 @@ __global__ __launch_bounds__(256) void ln_tanh_bwd_kernel(const float *__restric
     const long rend = rbeg + rows_per_block < R ? rbeg + rows_per_block : R;
     for (long row = rbeg + wave; row < rend; row += 4) {
         const float4 v = reinterpret_cast<const float4 *>(x + (size_t)row * 256)[lane];
-        const float4 yo = reinterpret_cast<const float4 *>(y + (size_t)row * 256)[lane];
         const float4 go = reinterpret_cast<const float4 *>(dy + (size_t)row * 256)[lane];
+        float4 yo = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (TANH) yo = reinterpret_cast<const float4 *>(y + (size_t)row * 256)[lane];
         const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / 256.f);
         const float4 d = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
         const float var = wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * (1.0f / 256.f);
@@ -371,7 +375,7 @@ extern "C" int adyolo_ln_tanh_fwd(const float *x, const float *gamma, const floa
                                   float eps, void *stream) {
     ADYOLO_REQUIRE(x && gamma && beta && y && R > 0, ADYOLO_EINVAL, "ln_tanh_fwd: bad arguments");
     ADYOLO_REQUIRE(C == 256, ADYOLO_ENOSUP, "ln_tanh_fwd: C must be 256 (got %d)", C);
-    hipLaunchKernelGGL(ln_tanh_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, as_stream(stream), x, gamma, beta, y, R, eps);
+    hipLaunchKernelGGL(ln_tanh_fwd_kernel<true>, dim3(cdiv(R, 4)), dim3(256), 0, as_stream(stream), x, gamma, beta, y, R, eps);
     return check_launch("ln_tanh_fwd");
 }
 extern "C" int adyolo_ln_tanh_bwd(const float *dy, const float *x, const float *y, const float *gamma, float *dx,
@@ -383,8 +387,33 @@ extern "C" int adyolo_ln_tanh_bwd(const float *dy, const float *x, const float *
     if (nblk > 1024) nblk = 1024;
     const int rpb = cdiv(R, nblk);
     nblk = cdiv(R, rpb);
-    hipLaunchKernelGGL(ln_tanh_bwd_kernel, dim3(nblk), dim3(256), 0, st, dy, x, y, gamma, dx, partial, R, rpb, eps);
+    hipLaunchKernelGGL(ln_tanh_bwd_kernel<true>, dim3(nblk), dim3(256), 0, st, dy, x, y, gamma, dx, partial, R, rpb, eps);
     int rc = check_launch("ln_tanh_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(ln_bwd_final_kernel, dim3(16), dim3(256), 0, st, partial, dgamma, dbeta, nblk);
+    return check_launch("ln_bwd_final");
+}
+
+// plain LayerNorm(256) (Conformer: resnet_conformer.py:160,211,236,262,290)
+extern "C" int adyolo_ln_fwd(const float *x, const float *gamma, const float *beta, float *y, long R, int C, float eps,
+                             void *stream) {
+    ADYOLO_REQUIRE(x && gamma && beta && y && R > 0, ADYOLO_EINVAL, "ln_fwd: bad arguments");
+    ADYOLO_REQUIRE(C == 256, ADYOLO_ENOSUP, "ln_fwd: C must be 256 (got %d)", C);
+    hipLaunchKernelGGL(ln_tanh_fwd_kernel<false>, dim3(cdiv(R, 4)), dim3(256), 0, as_stream(stream), x, gamma, beta, y, R, eps);
+    return check_launch("ln_fwd");
+}
+extern "C" int adyolo_ln_bwd(const float *dy, const float *x, const float *gamma, float *dx, float *dgamma,
+                             float *dbeta, float *partial, long R, int C, float eps, void *stream) {
+    ADYOLO_REQUIRE(dy && x && gamma && dx && dgamma && dbeta && partial && R > 0, ADYOLO_EINVAL, "ln_bwd: bad arguments");
+    ADYOLO_REQUIRE(C == 256, ADYOLO_ENOSUP, "ln_bwd: C must be 256 (got %d)", C);
+    hipStream_t st = as_stream(stream);
+    int nblk = cdiv(R, 4);
+    if (nblk > 1024) nblk = 1024;
+    const int rpb = cdiv(R, nblk);
+    nblk = cdiv(R, rpb);
+    hipLaunchKernelGGL(ln_tanh_bwd_kernel<false>, dim3(nblk), dim3(256), 0, st, dy, x, (const float *)nullptr, gamma, dx,
+                       partial, R, rpb, eps);
+    int rc = check_launch("ln_bwd");
     if (rc) return rc;
     hipLaunchKernelGGL(ln_bwd_final_kernel, dim3(16), dim3(256), 0, st, partial, dgamma, dbeta, nblk);
     return check_launch("ln_bwd_final");

@@ -272,6 +272,7 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
         k = x.shape[-1]
+        x = _c(x)
         y = ops.linear(x.view(-1, k), w, b)
         ctx.save_for_backward(x, w)
         return y.view(*x.shape[:-1], w.shape[0])
@@ -281,7 +282,7 @@ class LinearFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         k = x.shape[-1]
         dx, dw, db = ops.linear_bwd(x.view(-1, k), w, _c(dy).view(-1, w.shape[0]), need_dx=ctx.needs_input_grad[0])
-        return (dx.view_as(x) if dx is not None else None), dw, db
+        return (dx.view_as(x) if dx is not None else None), dw, (db if ctx.needs_input_grad[2] else None)
 
 
 class DropoutFn(torch.autograd.Function):
@@ -356,3 +357,251 @@ class _FusedLossFn(torch.autograd.Function):
     def backward(ctx, dloss):
         (dout,) = ctx.saved_tensors
         return ops.scale_dev(dout, _c(dloss).view(1)).view(ctx.shape), None, None, None
+
+
+# ============================================================================================== conformer nodes
+class ConvFn(torch.autograd.Function):
+    """General strided convolution (channels-last) = im2col + fp32-MFMA GEMM.  x [N][H][W][Cin], w [Cout][Cin][KH][KW]
+    (reference resnet_conformer.py:347 7x7 s(1,2); torchvision BasicBlock 3x3 / 1x1 s(1,2) at :353-393).
+    The column matrix is recomputed in backward instead of being kept alive."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, padding):
+        kh, kw = w.shape[2], w.shape[3]
+        col, ho, wo = ops.im2col(x, kh, kw, stride[0], stride[1], padding[0], padding[1])
+        wk = ops.pack_wk(w)
+        kp = wk.shape[1]
+        y = ops.gemm(col, wk, col.shape[0], w.shape[0], kp, kp, kp)
+        ctx.geom = (kh, kw, stride, padding)
+        ctx.save_for_backward(x, w)
+        return y.view(x.shape[0], ho, wo, w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        kh, kw, stride, padding = ctx.geom
+        n, h, ww, cin = x.shape
+        cout = w.shape[0]
+        dy2 = _c(dy).view(-1, cout)
+        rows = dy2.shape[0]
+        col, _, _ = ops.im2col(x, kh, kw, stride[0], stride[1], padding[0], padding[1])
+        kp = col.shape[1]
+        splits = max(1, min(64, rows // 4096))
+        dwk = ops.gemm(dy2, col, cout, kp, rows, cout, kp, trans_a=True, trans_b=True, splits=splits)
+        dw = ops.unpack_wk(dwk, cout, cin, kh, kw)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wk = ops.pack_wk(w)
+            dcol = ops.gemm(dy2, wk, rows, kp, cout, cout, kp, trans_b=True)
+            dx = ops.col2im(dcol, n, h, ww, cin, kh, kw, stride[0], stride[1], padding[0], padding[1])
+        return dx, dw, None, None
+
+
+class Conv3x3S1Fn(torch.autograd.Function):
+    """Stride-1 3x3 convolution on the implicit-GEMM kernel (K2), no fusion."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        cin = x.shape[-1]
+        wpk, wpkd = ops.pack_w3x3(w, cin)
+        ctx.save_for_backward(x, wpkd)
+        ctx.cin = w.shape[1]
+        return ops.conv3x3(x, wpk, w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wpkd = ctx.saved_tensors
+        dy = _c(dy)
+        dw = ops.conv3x3_wgrad(x, dy, ctx.cin)
+        dx = ops.conv3x3(dy, wpkd, x.shape[-1]) if ctx.needs_input_grad[0] else None
+        return dx, dw
+
+
+class ReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        c = x.shape[-1]
+        one = torch.ones(c, dtype=torch.float32, device=x.device)
+        y = ops.affine_relu(x, one, torch.zeros_like(one))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.relu_bwd(_c(dy), y)
+
+
+class BatchNormFn(torch.autograd.Function):
+    """BatchNorm over the last (channel) axis of a channels-last tensor [N][...][C], optional fused ReLU on the output,
+    optional residual: y = act(bn(x) + r)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, training, relu, residual=None):
+        _, mean, invstd = _BNState(bn).stats(x, training)
+        scale, shift = ops.bn_scale_shift(gamma, beta, mean, invstd)
+        if residual is not None:
+            n, c = x.shape[0], x.shape[-1]
+            ones = torch.ones(n, c, dtype=torch.float32, device=x.device)
+            y = ops.se_tail_fwd(x, residual, scale, shift, ones)            # relu(bn(x) * 1 + r)
+        elif relu:
+            y = ops.affine_relu(x, scale, shift)
+        else:
+            y = ops.affine(x, scale, shift)
+        ctx.training, ctx.relu, ctx.has_res = training, relu or residual is not None, residual is not None
+        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        g = ops.relu_bwd(_c(dy), y) if ctx.relu else _c(dy)
+        dx, dgamma, dbeta = ops.bn_bwd(g, x, gamma, mean, invstd, relu_mask=False)
+        return dx, dgamma, dbeta, None, None, None, (g if ctx.has_res else None)
+
+
+class MaxPool3Fn(torch.autograd.Function):
+    """MaxPool2d(3, stride (1,2), padding 1) (reference resnet_conformer.py:350)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y, arg = ops.maxpool3_fwd(x)
+        ctx.w = x.shape[2]
+        ctx.save_for_backward(arg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        return ops.maxpool3_bwd(_c(dy), arg, ctx.w)
+
+
+class LNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        c = x.shape[-1]
+        y = ops.ln_fwd(_c(x).view(-1, c), gamma, beta, eps)
+        ctx.eps = eps
+        ctx.save_for_backward(x, gamma)
+        return y.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        c = x.shape[-1]
+        dx, dg, db = ops.ln_bwd(_c(dy).view(-1, c), _c(x).view(-1, c), gamma, ctx.eps)
+        return dx.view_as(x), dg, db, None
+
+
+class SwishFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.swish_fwd(_c(x))
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.swish_bwd(_c(dy), _c(x))
+
+
+class GLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        c2 = x.shape[-1]
+        ctx.save_for_backward(x)
+        return ops.glu_fwd(_c(x).view(-1, c2)).view(*x.shape[:-1], c2 // 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        c2 = x.shape[-1]
+        return ops.glu_bwd(_c(dy).view(-1, c2 // 2), _c(x).view(-1, c2)).view_as(x)
+
+
+class DWConv3Fn(torch.autograd.Function):
+    """Depthwise Conv1d(k=3, dilation d, padding d) over time, channels-last (reference resnet_conformer.py:169)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, dilation):
+        ctx.dilation = dilation
+        ctx.save_for_backward(x, w)
+        return ops.dwconv3(_c(x), w.view(-1, 3), bias, dilation)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        dx = ops.dwconv3(dy, w.view(-1, 3), None, ctx.dilation, flip=True)
+        dw, db = ops.dwconv3_wgrad(dy, _c(x), ctx.dilation)
+        return dx, dw.view_as(w), db, None
+
+
+class AxpbyFn(torch.autograd.Function):
+    """a * x + b * z  (ResidualConnectionModule, reference resnet_conformer.py:98)."""
+
+    @staticmethod
+    def forward(ctx, x, z, a, b):
+        ctx.ab = (a, b)
+        return ops.axpby(_c(x), _c(z), a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.ab
+        dy = _c(dy)
+        return ops.axpby(dy, dy, a, 0.0), ops.axpby(dy, dy, b, 0.0), None, None
+
+
+class AvgPool1dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, fac):
+        ctx.meta = (x.shape[1], k, fac)
+        return ops.avgpool1d(_c(x), k, fac)
+
+    @staticmethod
+    def backward(ctx, dy):
+        t, k, fac = ctx.meta
+        return ops.avgpool1d_bwd(_c(dy), t, k, fac), None, None
+
+
+class AttentionCoreFn(torch.autograd.Function):
+    """softmax(scale * Q K^T) [* dropout mask] V per head; q, k, v: [B][T][heads*d] (reference resnet_conformer.py:57-85).
+    The T x T score matrices are materialised (B*heads*T*T floats); all products run on the batched fp32-MFMA GEMM."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale, mask):
+        b, t, e = q.shape
+        d = e // heads
+        q, k, v = _c(q), _c(k), _c(v)
+        s = torch.empty(b, heads, t, t, dtype=torch.float32, device=q.device)
+        ops.gemm_batched(q, k, s, t, t, d, e, e, t, False, False, b, heads, t * e, d, t * e, d, heads * t * t, t * t)
+        p = ops.softmax_fwd(s.view(-1, t), scale).view(b, heads, t, t)
+        pd = ops.mul(p, mask) if mask is not None else p
+        ctxv = torch.empty(b, t, e, dtype=torch.float32, device=q.device)
+        ops.gemm_batched(pd, v, ctxv, t, d, t, t, e, e, False, True, b, heads, heads * t * t, t * t, t * e, d, t * e, d)
+        ctx.meta = (heads, scale)
+        ctx.save_for_backward(q, k, v, p, mask if mask is not None else torch.empty(0, device=q.device))
+        return ctxv
+
+    @staticmethod
+    def backward(ctx, dctx):
+        q, k, v, p, mask = ctx.saved_tensors
+        heads, scale = ctx.meta
+        b, t, e = q.shape
+        d = e // heads
+        dctx = _c(dctx)
+        has_mask = mask.numel() > 0
+        pd = ops.mul(p, mask) if has_mask else p
+        dpd = torch.empty_like(p)
+        ops.gemm_batched(dctx, v, dpd, t, t, d, e, e, t, False, False, b, heads, t * e, d, t * e, d, heads * t * t, t * t)
+        dv = torch.empty_like(v)
+        ops.gemm_batched(pd, dctx, dv, t, d, t, t, e, e, True, True, b, heads, heads * t * t, t * t, t * e, d, t * e, d)
+        dp = ops.mul(dpd, mask) if has_mask else dpd
+        ds = ops.softmax_bwd(dp.view(-1, t), p.view(-1, t), scale).view(b, heads, t, t)
+        dq = torch.empty_like(q)
+        ops.gemm_batched(ds, k, dq, t, d, t, t, e, e, False, True, b, heads, heads * t * t, t * t, t * e, d, t * e, d)
+        dk = torch.empty_like(k)
+        ops.gemm_batched(ds, q, dk, t, d, t, t, e, e, True, True, b, heads, heads * t * t, t * t, t * e, d, t * e, d)
+        return dq, dk, dv, None, None, None

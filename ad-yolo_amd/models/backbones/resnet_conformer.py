@@ -1,0 +1,252 @@
+"""ResNet-Conformer encoder (BASELINE config 4) on the gfx950 kernels.
+
+Host-side mirror of ``ResnetConformer`` (/root/reference/src/models/backbones/resnet_conformer.py:342-447) with its
+building blocks ``MultiHeadAttention`` :25-85, ``ConformerConvModule`` :154-178, ``FeedForwardModule`` :181-212,
+``ConformerBlock`` :215-282, ``PoolingModule`` :285-297 and torchvision's ``BasicBlock`` (conv3x3(stride)-BN-ReLU-conv3x3-BN
++ identity/downsample -> ReLU; torchvision==0.11 is not vendored in the reference: "parity unpinned" for that block).
+Same constructor ``(in_feat_shape, out_shape, params)``, ``enc_out_dim`` attribute, forward ``(B,7,T,F) -> (B,T//4,256)``
+and the same 549 ``state_dict`` keys.  Quirks kept: ReLU *before* BatchNorm after the 7x7 stem (:423-425), layer3 has 5
+blocks (:373-384), ``PoolingModule.max_pool`` is an average pool (:289) so pooling is 2 x avg, attention ``mask`` path dead.
+
+This is the correctness-first version of the row: strided convolutions run as im2col + the fp32-MFMA GEMM, stride-1 3x3
+convolutions on the implicit-GEMM kernel, attention as batched GEMM + softmax kernels with materialised scores.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from ... import functional as Fn
+from ... import ops
+from .resnet import BatchNormParams, ConvParams, LayerNormParams, LinearParams
+
+
+class _Counter:
+    """Counter-based dropout stream shared by the encoder (seed, running offset)."""
+
+    def __init__(self, seed=0xC0F0):
+        self.seed, self.offset = seed, 0
+
+    def mask(self, like, p):
+        m = ops.dropout_mask(like, p, self.seed, self.offset)
+        self.offset += like.numel()
+        return m
+
+
+def _dropout(x, p, training, rng):
+    if not training or p <= 0.0:
+        return x
+    return Fn.DropoutFn.apply(x, rng.mask(x, p))
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, inplanes, planes, stride=(1, 1), downsample=None):
+        super().__init__()
+        self.stride = tuple(stride)
+        self.conv1 = ConvParams(inplanes, planes, 3, bias=False)
+        self.bn1 = BatchNormParams(planes)
+        self.conv2 = ConvParams(planes, planes, 3, bias=False)
+        self.bn2 = BatchNormParams(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        if self.stride == (1, 1):
+            out = Fn.Conv3x3S1Fn.apply(x, self.conv1.weight)
+        else:
+            out = Fn.ConvFn.apply(x, self.conv1.weight, self.stride, (1, 1))
+        out = Fn.BatchNormFn.apply(out, self.bn1.weight, self.bn1.bias, self.bn1, self.training, True, None)
+        out = Fn.Conv3x3S1Fn.apply(out, self.conv2.weight)
+        if self.downsample is not None:
+            idn = Fn.ConvFn.apply(x, self.downsample["0"].weight, self.stride, (0, 0))
+            d = self.downsample["1"]
+            idn = Fn.BatchNormFn.apply(idn, d.weight, d.bias, d, self.training, False, None)
+        else:
+            idn = x
+        return Fn.BatchNormFn.apply(out, self.bn2.weight, self.bn2.bias, self.bn2, self.training, True, idn)
+
+
+def _make_layer(inplanes, planes, nblocks):
+    down = nn.ModuleDict({"0": ConvParams(inplanes, planes, 1, bias=False), "1": BatchNormParams(planes)})
+    blocks = [BasicBlock(inplanes, planes, (1, 2), down)]
+    blocks += [BasicBlock(planes, planes) for _ in range(1, nblocks)]
+    return nn.ModuleList(blocks)
+
+
+class Conv1dParams(nn.Module):
+    """weight (Cout, Cin/groups, k) + bias, initialised like nn.Conv1d."""
+
+    def __init__(self, cin, cout, k, groups=1):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin // groups, k))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        self.bias = nn.Parameter(torch.empty(cout))
+        nn.init.uniform_(self.bias, -1.0 / math.sqrt(cin // groups * k), 1.0 / math.sqrt(cin // groups * k))
+
+
+class FeedForwardModule(nn.Module):
+    """LN -> Linear(d, 4d) -> Swish -> Dropout -> Linear(4d, d) -> Dropout; keys sequential.{0,1,4}."""
+
+    def __init__(self, dim, expansion, p):
+        super().__init__()
+        self.p = p
+        self.sequential = nn.ModuleDict({"0": LayerNormParams(dim), "1": LinearParams(dim, dim * expansion),
+                                         "4": LinearParams(dim * expansion, dim)})
+
+    def forward(self, x, rng):
+        s = self.sequential
+        y = Fn.LNFn.apply(x, s["0"].weight, s["0"].bias, s["0"].eps)
+        y = Fn.LinearFn.apply(y, s["1"].weight, s["1"].bias)
+        y = _dropout(Fn.SwishFn.apply(y), self.p, self.training, rng)
+        y = Fn.LinearFn.apply(y, s["4"].weight, s["4"].bias)
+        return _dropout(y, self.p, self.training, rng)
+
+
+class MultiHeadAttention(nn.Module):
+    def __init__(self, emb_dim, num_heads, p):
+        super().__init__()
+        self.emb_dim, self.num_heads, self.p = emb_dim, num_heads, p
+        self.scaling = (emb_dim // num_heads) ** -0.5
+        self.value = LinearParams(emb_dim, emb_dim)
+        self.key = LinearParams(emb_dim, emb_dim)
+        self.query = LinearParams(emb_dim, emb_dim)
+        self.linear = LinearParams(emb_dim, emb_dim)
+
+    def forward(self, x, rng):
+        q = Fn.LinearFn.apply(x, self.query.weight, self.query.bias)
+        k = Fn.LinearFn.apply(x, self.key.weight, self.key.bias)
+        v = Fn.LinearFn.apply(x, self.value.weight, self.value.bias)
+        mask = None
+        if self.training and self.p > 0.0:
+            b, t, _ = x.shape
+            mask = rng.mask(torch.empty(b, self.num_heads, t, t, dtype=torch.float32, device=x.device), self.p)
+        ctx = Fn.AttentionCoreFn.apply(q, k, v, self.num_heads, self.scaling, mask)
+        return Fn.LinearFn.apply(ctx, self.linear.weight, self.linear.bias)
+
+
+class ConformerConvModule(nn.Module):
+    """LN -> pw conv (d -> 2d) -> BN -> GLU -> depthwise conv k3 dil -> BN -> Swish -> pw conv -> Dropout;
+    keys conv.{0,2,3,5,6,8}."""
+
+    def __init__(self, dim, dilation, p=0.2):
+        super().__init__()
+        self.dilation, self.p = dilation, p
+        self.conv = nn.ModuleDict({"0": LayerNormParams(dim), "2": Conv1dParams(dim, 2 * dim, 1),
+                                   "3": BatchNormParams(2 * dim), "5": Conv1dParams(dim, dim, 3, groups=dim),
+                                   "6": BatchNormParams(dim), "8": Conv1dParams(dim, dim, 1)})
+
+    def forward(self, x, rng):
+        c = self.conv
+        y = Fn.LNFn.apply(x, c["0"].weight, c["0"].bias, c["0"].eps)
+        y = Fn.LinearFn.apply(y, c["2"].weight.view(c["2"].weight.shape[0], -1), c["2"].bias)
+        y = Fn.BatchNormFn.apply(y, c["3"].weight, c["3"].bias, c["3"], self.training, False, None)
+        y = Fn.GLUFn.apply(y)
+        y = Fn.DWConv3Fn.apply(y, c["5"].weight, c["5"].bias, self.dilation)
+        y = Fn.BatchNormFn.apply(y, c["6"].weight, c["6"].bias, c["6"], self.training, False, None)
+        y = Fn.SwishFn.apply(y)
+        y = Fn.LinearFn.apply(y, c["8"].weight.view(c["8"].weight.shape[0], -1), c["8"].bias)
+        return _dropout(y, self.p, self.training, rng)
+
+
+class _Residual(nn.Module):
+    """keys ``<idx>.module.*`` like the reference's ResidualConnectionModule."""
+
+    def __init__(self, module, factor):
+        super().__init__()
+        self.module = module
+        self.factor = factor
+
+
+class _AttnBranch(nn.ModuleDict):
+    pass
+
+
+class ConformerBlock(nn.Module):
+    def __init__(self, dim, heads, expansion, p1, p2, dilation):
+        super().__init__()
+        self.p2 = p2
+        self.sequential = nn.ModuleList([
+            _Residual(FeedForwardModule(dim, expansion, p1), 0.5),
+            _Residual(_AttnBranch({"0": LayerNormParams(dim), "1": MultiHeadAttention(dim, heads, p1)}), 0.5),
+            _Residual(ConformerConvModule(dim, dilation), 1.0),
+            _Residual(FeedForwardModule(dim, expansion, p1), 0.5),
+            LayerNormParams(dim),
+        ])
+
+    def forward(self, x, rng):
+        s = self.sequential
+        x = Fn.AxpbyFn.apply(s[0].module(x, rng), x, s[0].factor, 1.0)
+        a = s[1].module
+        y = Fn.LNFn.apply(x, a["0"].weight, a["0"].bias, a["0"].eps)
+        y = _dropout(a["1"](y, rng), self.p2, self.training, rng)
+        x = Fn.AxpbyFn.apply(y, x, s[1].factor, 1.0)
+        x = Fn.AxpbyFn.apply(s[2].module(x, rng), x, s[2].factor, 1.0)
+        x = Fn.AxpbyFn.apply(s[3].module(x, rng), x, s[3].factor, 1.0)
+        return Fn.LNFn.apply(x, s[4].weight, s[4].bias, s[4].eps)
+
+
+class ConformerEncoder(nn.Module):
+    def __init__(self, n_layers, dim, heads, expansion, p1, p2):
+        super().__init__()
+        self.encoder_module = nn.ModuleList([ConformerBlock(dim, heads, expansion, p1, p2, 2 ** i)
+                                             for i in range(n_layers)])
+
+    def forward(self, x, rng):
+        for blk in self.encoder_module:
+            x = blk(x, rng)
+        return x
+
+
+class PoolingModule(nn.Module):
+    """avg_pool(k) + "max_pool"(k) where both are AvgPool1d in the reference (:288-289) -> 2 x mean, then LayerNorm."""
+
+    def __init__(self, pool, dim):
+        super().__init__()
+        self.pool = pool
+        self.norm = LayerNormParams(dim)
+
+    def forward(self, x):
+        y = Fn.AvgPool1dFn.apply(x, self.pool, 2.0)
+        return Fn.LNFn.apply(y, self.norm.weight, self.norm.bias, self.norm.eps)
+
+
+class ResnetConformer(nn.Module):
+    def __init__(self, in_feat_shape, out_shape, params):
+        super().__init__()
+        self.in_channels = in_feat_shape[1]
+        self.conv1 = ConvParams(self.in_channels, 64, 7, bias=False)
+        self.bn1 = BatchNormParams(64)
+        self.layer1 = _make_layer(64, 64, 3)
+        self.layer2 = _make_layer(64, 128, 4)
+        self.layer3 = _make_layer(128, 256, 5)
+        self.layer4 = _make_layer(256, 512, 3)
+        self.bottleneck = nn.Module()
+        self.bottleneck.weight = nn.Parameter(torch.empty(256, 512))
+        nn.init.kaiming_uniform_(self.bottleneck.weight, a=math.sqrt(5))
+        self.emb_dim = 256
+        self.conformer = ConformerEncoder(8, 256, 4, 4, 0.2, 0.2)
+        self.t_pooling = PoolingModule(4, 256)
+        self.enc_out_dim = 256
+        self._rng = _Counter()
+
+    def forward(self, x, channels_last8=False):
+        """x: (B, 7, T, F) float32 on the GPU (reference layout), or (B, T, F, 8) when ``channels_last8``."""
+        if not x.is_cuda:
+            raise RuntimeError("ResnetConformer (adyolo_amd) runs on MI355X only; move the model/input to a HIP device")
+        x8 = x if channels_last8 else ops.nchw_to_nhwc8(x.contiguous().float())
+        w = self.conv1.weight
+        if w.shape[1] < 8:          # activations are padded 7 -> 8 channels: pad the weight with zero planes (copy only)
+            w = torch.cat([w, torch.zeros(w.shape[0], 8 - w.shape[1], 7, 7, dtype=w.dtype, device=w.device)], dim=1)
+        y = Fn.ConvFn.apply(x8, w, (1, 2), (3, 3))
+        y = Fn.ReluFn.apply(y)                                   # ReLU BEFORE BatchNorm (reference :423-425)
+        y = Fn.BatchNormFn.apply(y, self.bn1.weight, self.bn1.bias, self.bn1, self.training, False, None)
+        y = Fn.MaxPool3Fn.apply(y)
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                y = blk(y)
+        b, t, f, c = y.shape
+        if f != 1:
+            raise RuntimeError("ResnetConformer expects 64 mel bins (frequency axis must collapse to 1, got %d)" % f)
+        y = y.view(b, t, c)
+        y = Fn.LinearFn.apply(y, self.bottleneck.weight, None)
+        y = self.conformer(y, self._rng)
+        return self.t_pooling(y)

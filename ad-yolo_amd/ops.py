@@ -418,3 +418,183 @@ def nchw_to_nhwc8(x):
     y = _new(x, b, h, w, 8)
     _c("adyolo_nchw_to_nhwc8", _p(x), _p(y), b, c, h, w, _stream())
     return y
+
+
+# ---------------------------------------------------------------------------------------------- conformer pieces
+def _kp(kh, kw, c):
+    return (kh * kw * c + 3) // 4 * 4
+
+
+def conv_out_hw(h, w, kh, kw, sh, sw, ph, pw):
+    return (h + 2 * ph - kh) // sh + 1, (w + 2 * pw - kw) // sw + 1
+
+
+def im2col(x, kh, kw, sh, sw, ph, pw):
+    _chk(x)
+    n, h, w, c = x.shape
+    ho, wo = conv_out_hw(h, w, kh, kw, sh, sw, ph, pw)
+    col = _new(x, n * ho * wo, _kp(kh, kw, c))
+    _c("adyolo_im2col", _p(x), _p(col), n, h, w, c, kh, kw, sh, sw, ph, pw, _stream())
+    return col, ho, wo
+
+
+def col2im(dcol, n, h, w, c, kh, kw, sh, sw, ph, pw):
+    dx = _new(dcol, n, h, w, c)
+    _c("adyolo_col2im", _p(dcol), _p(dx), n, h, w, c, kh, kw, sh, sw, ph, pw, _stream())
+    return dx
+
+
+def pack_wk(w):
+    """w [Cout][Cin][KH][KW] -> [Cout][Kp] with k = (kh*KW+kw)*Cin + ci."""
+    _chk(w)
+    cout, cin, kh, kw = w.shape
+    wk = _new(w, cout, _kp(kh, kw, cin))
+    _c("adyolo_pack_wk", _p(w), _p(wk), cout, cin, kh, kw, 1, _stream())
+    return wk
+
+
+def unpack_wk(wk, cout, cin, kh, kw):
+    w = _new(wk, cout, cin, kh, kw)
+    _c("adyolo_pack_wk", _p(w), _p(wk), cout, cin, kh, kw, 0, _stream())
+    return w
+
+
+def maxpool3_fwd(x):
+    _chk(x)
+    n, h, w, c = x.shape
+    wo = (w + 2 - 3) // 2 + 1
+    y = _new(x, n, h, wo, c)
+    arg = torch.empty((n, h, wo, c), dtype=torch.uint8, device=x.device)
+    _c("adyolo_maxpool3_fwd", _p(x), _p(y), _p(arg), n, h, w, c, _stream())
+    return y, arg
+
+
+def maxpool3_bwd(dy, arg, w):
+    _chk(dy)
+    n, h, _, c = dy.shape
+    dx = _zeros(dy, n, h, w, c)
+    _c("adyolo_maxpool3_bwd", _p(dy), _p(arg), _p(dx), n, h, w, c, _stream())
+    return dx
+
+
+def affine_relu(x, scale, shift):
+    _chk(x, scale, shift)
+    c = x.shape[-1]
+    y = torch.empty_like(x)
+    _c("adyolo_affine_relu_nhwc", _p(x), _p(scale), _p(shift), _p(y), x.numel() // c, c, _stream())
+    return y
+
+
+def relu_bwd(dy, y):
+    _chk(dy, y)
+    dx = torch.empty_like(y)
+    _c("adyolo_relu_bwd", _p(dy), _p(y), _p(dx), y.numel(), _stream())
+    return dx
+
+
+def axpby(x, z, a, b):
+    _chk(x, z)
+    y = torch.empty_like(x)
+    _c("adyolo_axpby", _p(x), _p(z), _p(y), float(a), float(b), x.numel(), _stream())
+    return y
+
+
+def swish_fwd(x):
+    _chk(x)
+    y = torch.empty_like(x)
+    _c("adyolo_swish_fwd", _p(x), _p(y), x.numel(), _stream())
+    return y
+
+
+def swish_bwd(dy, x):
+    _chk(dy, x)
+    dx = torch.empty_like(x)
+    _c("adyolo_swish_bwd", _p(dy), _p(x), _p(dx), x.numel(), _stream())
+    return dx
+
+
+def glu_fwd(x2d):
+    _chk(x2d)
+    r, c2 = x2d.shape
+    y = _new(x2d, r, c2 // 2)
+    _c("adyolo_glu_fwd", _p(x2d), _p(y), r, c2 // 2, _stream())
+    return y
+
+
+def glu_bwd(dy2d, x2d):
+    _chk(dy2d, x2d)
+    dx = torch.empty_like(x2d)
+    _c("adyolo_glu_bwd", _p(dy2d), _p(x2d), _p(dx), x2d.shape[0], x2d.shape[1] // 2, _stream())
+    return dx
+
+
+def dwconv3(x, w, bias, dilation, flip=False):
+    """x [B][T][C], w [C][3] (or [C][1][3]), bias [C] or None."""
+    _chk(x, w, bias)
+    b, t, c = x.shape
+    y = torch.empty_like(x)
+    _c("adyolo_dwconv3_fwd", _p(x), _p(w), _p(bias), _p(y), b, t, c, int(dilation), int(flip), _stream())
+    return y
+
+
+def dwconv3_wgrad(dy, x, dilation):
+    _chk(dy, x)
+    b, t, c = x.shape
+    dw, db = _new(x, c, 3), _new(x, c)
+    partial, cws = _new(x, 1024, 4 * c), _new(x, 1024, 3 * c)
+    _c("adyolo_dwconv3_wgrad", _p(dy), _p(x), _p(dw), _p(db), _p(partial), _p(cws), b, t, c, int(dilation), _stream())
+    return dw, db
+
+
+def softmax_fwd(s2d, scale):
+    _chk(s2d)
+    p = torch.empty_like(s2d)
+    _c("adyolo_softmax_fwd", _p(s2d), _p(p), s2d.shape[0], s2d.shape[1], float(scale), _stream())
+    return p
+
+
+def softmax_bwd(dp2d, p2d, scale):
+    _chk(dp2d, p2d)
+    ds = torch.empty_like(p2d)
+    _c("adyolo_softmax_bwd", _p(dp2d), _p(p2d), _p(ds), p2d.shape[0], p2d.shape[1], float(scale), _stream())
+    return ds
+
+
+def avgpool1d(x, k, fac):
+    _chk(x)
+    b, t, c = x.shape
+    y = _new(x, b, t // k, c)
+    _c("adyolo_avgpool1d_fwd", _p(x), _p(y), b, t, c, k, float(fac), _stream())
+    return y
+
+
+def avgpool1d_bwd(dy, t, k, fac):
+    _chk(dy)
+    b, _, c = dy.shape
+    dx = _new(dy, b, t, c)
+    _c("adyolo_avgpool1d_bwd", _p(dy), _p(dx), b, t, c, k, float(fac), _stream())
+    return dx
+
+
+def ln_fwd(x2d, gamma, beta, eps=1e-5):
+    _chk(x2d, gamma, beta)
+    y = torch.empty_like(x2d)
+    _c("adyolo_ln_fwd", _p(x2d), _p(gamma), _p(beta), _p(y), x2d.shape[0], x2d.shape[1], eps, _stream())
+    return y
+
+
+def ln_bwd(dy2d, x2d, gamma, eps=1e-5):
+    _chk(dy2d, x2d, gamma)
+    r, c = x2d.shape
+    dx = torch.empty_like(x2d)
+    dgamma, dbeta = _zeros(x2d, c), _zeros(x2d, c)
+    partial = _new(x2d, 1024 * 512)
+    _c("adyolo_ln_bwd", _p(dy2d), _p(x2d), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), _p(partial), r, c, eps, _stream())
+    return dx, dgamma, dbeta
+
+
+def gemm_batched(a, b, c, m, n, k, lda, ldb, ldc, trans_a, trans_b, outer, inner, oa, ia, ob, ib, oc, ic, alpha=1.0,
+                 accumulate=False):
+    _c("adyolo_gemm_batched", _p(a), _p(b), _p(c), m, n, k, lda, ldb, ldc, int(trans_a), int(trans_b), outer, inner,
+       oa, ia, ob, ib, oc, ic, float(alpha), int(accumulate), _stream())
+    return c

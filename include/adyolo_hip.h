@@ -98,6 +98,11 @@ int adyolo_conv3x3_wgrad(const float *x, const float *dy, const float *in_scale,
 int adyolo_gemm(const float *A, const float *B, const float *bias, float *C, float *slabs, int M,
                 int N, int K, int lda, int ldb, int ldc, int transA, int transB, int splits,
                 int accumulate, void *stream);
+/* batched variant (attention, resnet_conformer.py:57-85): problem (o, i), o < outer, i < inner, uses the operand
+ * bases A + o*oA + i*iA etc. (strides in floats, multiples of 4);  C = alpha * product (+ C when accumulate). */
+int adyolo_gemm_batched(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc,
+                        int transA, int transB, int outer, int inner, long oA, long iA, long oB, long iB, long oC,
+                        long iC, float alpha, int accumulate, void *stream);
 /* out[c] (+)= sum_r A[r*lda + c], deterministic two-stage; partial: [1024][C] workspace */
 int adyolo_colsum(const float *A, float *out, float *partial, int R, int C, int lda, int accumulate,
                   void *stream);
@@ -242,6 +247,47 @@ int adyolo_seddoa_loss(const float *out, const float *tgt, float *loss, float *d
                        int cols, int nsed, int masked, float w_bce, float w_mse, void *stream);
 int adyolo_adpit_loss(const float *out, const float *tgt, float *loss, float *dout, float *partial, long rows,
                       int C, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K9  ResNet-Conformer encoder pieces (src/models/backbones/resnet_conformer.py), channels-last fp32
+ *   im2col / col2im / pack_wk : general strided convolution = im2col + adyolo_gemm; rows of `col` / `wk` are
+ *       (kh, kw, c)-ordered and padded to a multiple of 4 floats (Kp).  Used for the 7x7 s(1,2) stem (:347) and the
+ *       torchvision BasicBlock 3x3 / 1x1 s(1,2) convolutions (:353-393).
+ *   maxpool3 : MaxPool2d(3, stride (1,2), padding 1) (:350); arg = arg-max tap per output (uint8); bwd atomically
+ *       adds into a ZEROED dx.
+ *   affine_relu, relu_bwd, axpby : BN->ReLU of BasicBlock, residual mixing a*x + b*z (:98)
+ *   swish (:142-150), glu over the channel axis (:167), dwconv3: depthwise Conv1d k=3, dilation d, padding d (:169)
+ *       (flip = 1 gives the data gradient), softmax rows with a pre-scale (:73-76), avgpool1d(k) * fac (:288-294),
+ *   ln : LayerNorm(256).
+ * ---------------------------------------------------------------------------------------------- */
+int adyolo_im2col(const float *x, float *col, int N, int H, int W, int C, int KH, int KW, int SH, int SW, int PH,
+                  int PW, void *stream);
+int adyolo_col2im(const float *dcol, float *dx, int N, int H, int W, int C, int KH, int KW, int SH, int SW, int PH,
+                  int PW, void *stream);
+int adyolo_pack_wk(float *w, float *wk, int Cout, int Cin, int KH, int KW, int to_packed, void *stream);
+int adyolo_maxpool3_fwd(const float *x, float *y, unsigned char *arg, int N, int H, int W, int C, void *stream);
+int adyolo_maxpool3_bwd(const float *dy, const unsigned char *arg, float *dx_zeroed, int N, int H, int W, int C,
+                        void *stream);
+int adyolo_affine_relu_nhwc(const float *x, const float *scale, const float *shift, float *y, long rows, int C,
+                            void *stream);
+int adyolo_relu_bwd(const float *dy, const float *y, float *dx, long n, void *stream);
+int adyolo_axpby(const float *x, const float *z, float *y, float a, float b, long n, void *stream);
+int adyolo_swish_fwd(const float *x, float *y, long n, void *stream);
+int adyolo_swish_bwd(const float *dy, const float *x, float *dx, long n, void *stream);
+int adyolo_glu_fwd(const float *x, float *y, long rows, int C, void *stream);
+int adyolo_glu_bwd(const float *dy, const float *x, float *dx, long rows, int C, void *stream);
+int adyolo_dwconv3_fwd(const float *x, const float *w, const float *bias, float *y, int B, int T, int C,
+                       int dilation, int flip, void *stream);
+int adyolo_dwconv3_wgrad(const float *dy, const float *x, float *dw, float *db, float *partial, float *colsum_ws,
+                         int B, int T, int C, int dilation, void *stream);
+int adyolo_softmax_fwd(const float *s, float *p, long rows, int L, float scale, void *stream);
+int adyolo_softmax_bwd(const float *dp, const float *p, float *ds, long rows, int L, float scale, void *stream);
+int adyolo_avgpool1d_fwd(const float *x, float *y, int B, int T, int C, int k, float fac, void *stream);
+int adyolo_avgpool1d_bwd(const float *dy, float *dx, int B, int T, int C, int k, float fac, void *stream);
+int adyolo_ln_fwd(const float *x, const float *gamma, const float *beta, float *y, long R, int C, float eps,
+                  void *stream);
+int adyolo_ln_bwd(const float *dy, const float *x, const float *gamma, float *dx, float *dgamma, float *dbeta,
+                  float *partial, long R, int C, float eps, void *stream);
 
 /* K11 fused Adam over one flat parameter buffer (torch.optim.Adam at src/train.py:31,55; no amsgrad) */
 int adyolo_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long n,

@@ -256,6 +256,79 @@ def gen_other_losses():
     print("other_losses.npz", {k: float(out[k]) for k in out if k.endswith("_loss")})
 
 
+def _install_torchvision_stub():
+    """torchvision==0.11 is not installed: BasicBlock per its published definition."""
+    import torch.nn as nn
+    tv, tvm, tvr = types.ModuleType("torchvision"), types.ModuleType("torchvision.models"), types.ModuleType("torchvision.models.resnet")
+
+    class BasicBlock(nn.Module):
+        expansion = 1
+
+        def __init__(self, inplanes, planes, stride=1, downsample=None):
+            super().__init__()
+            self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=False)
+            self.bn1 = nn.BatchNorm2d(planes)
+            self.relu = nn.ReLU(inplace=True)
+            self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+            self.bn2 = nn.BatchNorm2d(planes)
+            self.downsample = downsample
+
+        def forward(self, x):
+            idn = x
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.bn2(self.conv2(out))
+            if self.downsample is not None:
+                idn = self.downsample(x)
+            return self.relu(out + idn)
+    tvr.BasicBlock = BasicBlock
+    tvm.resnet = tvr
+    tv.models = tvm
+    sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "torchvision.models.resnet": tvr})
+
+
+def gen_conformer():
+    _install_torchvision_stub()
+    from models.backbones.resnet_conformer import ResnetConformer
+    # init fingerprints under seed 100
+    torch.manual_seed(100)
+    m = ResnetConformer((1, 7, 64, 64), (), make_params())
+    sd = m.state_dict()
+    names = sorted(k for k, v in sd.items() if v.is_floating_point())
+    out = {"names": np.asarray(names), "shapes": np.asarray([str(tuple(sd[k].shape)) for k in names]),
+           "sums": np.asarray([float(sd[k].double().sum()) for k in names]),
+           "first": np.asarray([float(sd[k].reshape(-1)[0]) for k in names]),
+           "all_keys": np.asarray(list(sd.keys()))}
+    # forward / backward with the name-seeded filler, dropout disabled
+    fill_module_(_Wrap(m, torch.nn.Identity()))
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    g = torch.Generator().manual_seed(51)
+    x = torch.randn(2, 7, 32, 64, generator=g)
+    probe = torch.randn(2, 8, 256, generator=g)
+    m.eval()
+    with torch.no_grad():
+        out["y_eval"] = m(x).numpy()
+    m.train()
+    xg = x.clone().requires_grad_(True)
+    y = m(xg)
+    (y * probe).sum().backward()
+    out.update(x=x.numpy(), probe=probe.numpy(), y_train=y.detach().numpy(), dx_train=xg.grad.numpy())
+    named = dict(m.named_parameters())
+    for k in ("conv1.weight", "bn1.weight", "layer1.0.conv1.weight", "layer1.0.downsample.0.weight", "layer2.1.conv2.weight",
+              "layer4.2.bn2.bias", "bottleneck.weight", "conformer.encoder_module.0.sequential.0.module.sequential.1.weight",
+              "conformer.encoder_module.0.sequential.1.module.1.query.weight",
+              "conformer.encoder_module.0.sequential.1.module.1.value.bias",
+              "conformer.encoder_module.3.sequential.2.module.conv.5.weight",
+              "conformer.encoder_module.3.sequential.2.module.conv.3.weight",
+              "conformer.encoder_module.7.sequential.2.module.conv.8.weight",
+              "conformer.encoder_module.7.sequential.4.weight", "t_pooling.norm.bias"):
+        gk = named[k].grad.numpy()
+        out["grad_" + k] = gk if gk.size <= 40000 else gk.reshape(-1)[:40000]
+    np.savez_compressed(os.path.join(HERE, "conformer.npz"), **out)
+    print("conformer.npz keys", len(sd), "y_eval", out["y_eval"].shape, float(np.abs(out["y_eval"]).mean()))
+
+
 def gen_scaler():
     import pickle
     for d in ("DCASE2021", "DCASE2022"):
@@ -275,4 +348,5 @@ if __name__ == "__main__":
     gen_encoder()
     gen_init()
     gen_other_losses()
+    gen_conformer()
     gen_scaler()

@@ -520,6 +520,125 @@ def test_wrapper_model_matches_reference_golden(ops):
     print("worst gradient deviation from fp64: %.2e of absmax" % worst)
 
 
+def test_conformer_pieces_match_torch(ops):
+    """im2col convolution (7x7 s(1,2), 3x3 s(1,2), 1x1 s(1,2)), max-pool, attention core, conv module pieces."""
+    from adyolo_amd import functional as Fn
+    g = torch.Generator().manual_seed(61)
+    for (cin, cout, k, stride, pad, h, w) in [(8, 64, 7, (1, 2), (3, 3), 12, 64), (64, 128, 3, (1, 2), (1, 1), 10, 16),
+                                              (128, 256, 1, (1, 2), (0, 0), 9, 8), (256, 512, 3, (1, 2), (1, 1), 6, 2)]:
+        x = torch.randn(2, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+        xo, wo = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+        yo = F.conv2d(xo, wo, None, stride=stride, padding=pad)
+        probe = torch.randn_like(yo)
+        (yo * probe).sum().backward()
+        xg, wg = dev(nhwc(x)).requires_grad_(True), dev(wt).requires_grad_(True)
+        yg = Fn.ConvFn.apply(xg, wg, stride, pad)
+        (yg * dev(nhwc(probe))).sum().backward()
+        assert_close(nchw(yg), yo, 3e-5, "strided conv fwd k=%d" % k)
+        assert_close(nchw(xg.grad), xo.grad, 3e-5, "strided conv dx k=%d" % k)
+        assert_close(wg.grad, wo.grad, 3e-5, "strided conv dw k=%d" % k)
+    # max-pool 3x3 s(1,2) p1
+    x = torch.randn(2, 64, 9, 32, generator=g)
+    xo = x.clone().requires_grad_(True)
+    yo = F.max_pool2d(xo, 3, stride=(1, 2), padding=1)
+    probe = torch.randn_like(yo)
+    (yo * probe).sum().backward()
+    xg = dev(nhwc(x)).requires_grad_(True)
+    yg = Fn.MaxPool3Fn.apply(xg)
+    (yg * dev(nhwc(probe))).sum().backward()
+    assert_close(nchw(yg), yo, 1e-6, "maxpool fwd")
+    assert_close(nchw(xg.grad), xo.grad, 1e-6, "maxpool bwd")
+    # attention core
+    b, t, heads, d = 2, 36, 4, 64
+    q, k, v = (torch.randn(b, t, heads * d, generator=g) for _ in range(3))
+    qo, ko, vo = (z.clone().requires_grad_(True) for z in (q, k, v))
+    qh, kh, vh = (z.view(b, t, heads, d).transpose(1, 2) for z in (qo, ko, vo))
+    ctx_o = (torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, -1) @ vh).transpose(1, 2).reshape(b, t, heads * d)
+    probe = torch.randn(b, t, heads * d, generator=g)
+    (ctx_o * probe).sum().backward()
+    qg, kg, vg = (dev(z).requires_grad_(True) for z in (q, k, v))
+    ctx_g = Fn.AttentionCoreFn.apply(qg, kg, vg, heads, d ** -0.5, None)
+    (ctx_g * dev(probe)).sum().backward()
+    assert_close(ctx_g, ctx_o, 2e-5, "attention fwd")
+    for name, a_, b_ in (("dq", qg, qo), ("dk", kg, ko), ("dv", vg, vo)):
+        assert_close(a_.grad, b_.grad, 5e-5, "attention " + name)
+    # GLU, Swish, depthwise conv, avg-pool, LayerNorm
+    x = torch.randn(3, 20, 512, generator=g)
+    xo = x.clone().requires_grad_(True)
+    yo = F.glu(xo, dim=-1)
+    probe = torch.randn_like(yo)
+    (yo * probe).sum().backward()
+    xg = dev(x).requires_grad_(True)
+    yg = Fn.GLUFn.apply(xg)
+    (yg * dev(probe)).sum().backward()
+    assert_close(yg, yo, 1e-6, "glu fwd")
+    assert_close(xg.grad, xo.grad, 1e-6, "glu bwd")
+    for dil in (1, 4, 16):
+        x = torch.randn(2, 40, 256, generator=g)
+        w = torch.randn(256, 1, 3, generator=g)
+        bias = torch.randn(256, generator=g)
+        xo, wo, bo = (z.clone().requires_grad_(True) for z in (x, w, bias))
+        yo = F.conv1d(xo.transpose(1, 2), wo, bo, padding=dil, dilation=dil, groups=256).transpose(1, 2)
+        probe = torch.randn(2, 40, 256, generator=g)
+        (yo * probe).sum().backward()
+        xg, wg, bg = (dev(z).requires_grad_(True) for z in (x, w, bias))
+        yg = Fn.DWConv3Fn.apply(xg, wg, bg, dil)
+        (yg * dev(probe)).sum().backward()
+        assert_close(yg, yo, 1e-5, "dwconv fwd")
+        assert_close(xg.grad, xo.grad, 1e-5, "dwconv dx")
+        assert_close(wg.grad, wo.grad, 1e-4, "dwconv dw")
+        assert_close(bg.grad, bo.grad, 1e-4, "dwconv db")
+    x = torch.randn(2, 40, 256, generator=g)
+    xo = x.clone().requires_grad_(True)
+    gam, bet = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+    go, bo = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    yo = F.layer_norm(xo * torch.sigmoid(xo), (256,), go, bo, 1e-5)
+    yo = (F.avg_pool1d(yo.transpose(1, 2), 4) * 2).transpose(1, 2)
+    probe = torch.randn_like(yo)
+    (yo * probe).sum().backward()
+    xg, gg, bg = dev(x).requires_grad_(True), dev(gam).requires_grad_(True), dev(bet).requires_grad_(True)
+    yg = Fn.AvgPool1dFn.apply(Fn.LNFn.apply(Fn.SwishFn.apply(xg), gg, bg, 1e-5), 4, 2.0)
+    (yg * dev(probe)).sum().backward()
+    assert_close(yg, yo, 1e-5, "swish+ln+avgpool fwd")
+    assert_close(xg.grad, xo.grad, 1e-4, "swish+ln+avgpool dx")
+    assert_close(gg.grad, go.grad, 1e-4, "ln dgamma")
+    assert_close(bg.grad, bo.grad, 1e-4, "ln dbeta")
+
+
+def test_resnet_conformer_matches_reference_golden(ops):
+    from oracle.filler import fill_module_
+    from adyolo_amd.wrapper import WrapperModel
+    g = np.load(os.path.join(G, "conformer.npz"))
+    prm = _params()
+    prm["args"]["encoder"] = "resnet-conformer"
+    model = WrapperModel((1, 7, 32, 64), (), prm)
+    fill_module_(model)
+    enc = model.encoder.to("cuda:0")
+    x = torch.from_numpy(g["x"])
+    enc.eval()
+    with torch.no_grad():
+        y = enc(dev(x))
+    torch.cuda.synchronize()
+    assert_close(y, torch.from_numpy(g["y_eval"]), 1e-3, "conformer eval output vs reference")
+    enc.train()
+    for m in enc.modules():
+        if hasattr(m, "p") and isinstance(getattr(m, "p"), float):
+            m.p = 0.0
+        if hasattr(m, "p2"):
+            m.p2 = 0.0
+    y = enc(dev(x))
+    (y * dev(torch.from_numpy(g["probe"]))).sum().backward()
+    torch.cuda.synchronize()
+    assert_close(y, torch.from_numpy(g["y_train"]), 1e-3, "conformer train output vs reference")
+    named = dict(enc.named_parameters())
+    for key in g.files:
+        if key.startswith("grad_"):
+            ref = torch.from_numpy(g[key].reshape(-1))
+            got = named[key[5:]].grad.reshape(-1)[:ref.numel()]
+            assert_close(got, ref, 1e-2, key + " vs reference golden")
+
+
 def test_adam_matches_torch(ops):
     g = torch.Generator().manual_seed(2)
     p0 = torch.randn(10001 + 3, generator=g)

@@ -117,3 +117,19 @@ def test_wrapper_rejects_unknown_names():
     p["args"]["loss"] = "nope"
     with pytest.raises(NotImplementedError):
         WrapperCriterion(p)
+
+
+def test_conformer_state_dict_and_init_match_reference():
+    """549 keys / shapes of the reference ResnetConformer, and bit-identical default init under seed 100."""
+    from adyolo_amd.models.backbones.resnet_conformer import ResnetConformer
+    g = np.load(os.path.join(G, "conformer.npz"))
+    torch.manual_seed(100)
+    m = ResnetConformer((1, 7, 64, 64), (), {"data_config": {"nb_classes": 12}})
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["all_keys"]] or set(sd.keys()) == set(str(k) for k in g["all_keys"])
+    assert len(sd) == 549 and sum(p.numel() for p in m.parameters()) == 32386752
+    for name, shp, s, f in zip(g["names"], g["shapes"], g["sums"], g["first"]):
+        v = sd[str(name)]
+        assert str(tuple(v.shape)) == str(shp), name
+        assert float(v.reshape(-1)[0]) == float(f), name
+        assert float(v.double().sum()) == pytest.approx(float(s), rel=1e-12, abs=1e-12), name

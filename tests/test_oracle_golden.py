@@ -219,3 +219,35 @@ def test_other_losses_match_reference():
         loss.backward()
         np.testing.assert_allclose(loss.detach().numpy(), g[tag + "_loss"], rtol=1e-5, atol=1e-6, err_msg=tag)
         np.testing.assert_allclose(o.grad.numpy(), g[tag + "_dout"], rtol=1e-4, atol=1e-7, err_msg=tag)
+
+
+# ---- ResNet-Conformer (config 4) -------------------------------------------------------------------------------
+def _conformer_sd():
+    g = np.load(os.path.join(G, "conformer.npz"))
+    import ast
+    from oracle.filler import fill_value
+    sd = {}
+    for k, shp in zip(g["names"], g["shapes"]):
+        sd[str(k)] = fill_value("encoder." + str(k), ast.literal_eval(str(shp)))
+    return g, sd
+
+
+def test_conformer_oracle_matches_reference():
+    from oracle import conformer as ocf
+    g, sd = _conformer_sd()
+    x = torch.from_numpy(g["x"])
+    with torch.no_grad():
+        y = ocf.encoder_forward(sd, x, training=False)
+    np.testing.assert_allclose(y.numpy(), g["y_eval"], rtol=1e-4, atol=5e-5)
+    for k, v in sd.items():
+        if "running" not in k:
+            v.requires_grad_(True)
+    xg = x.clone().requires_grad_(True)
+    yt = ocf.encoder_forward(sd, xg, training=True)
+    (yt * torch.from_numpy(g["probe"])).sum().backward()
+    np.testing.assert_allclose(yt.detach().numpy(), g["y_train"], rtol=1e-4, atol=5e-5)
+    for key in g.files:
+        if key.startswith("grad_"):
+            got = sd[key[5:]].grad.numpy().reshape(-1)[:g[key].size]
+            ref = g[key].reshape(-1)
+            np.testing.assert_allclose(got, ref, rtol=5e-3, atol=5e-3 * max(1e-3, float(np.abs(ref).max())), err_msg=key)
