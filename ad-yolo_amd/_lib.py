@@ -57,6 +57,7 @@ SIGNATURES = {
     "adyolo_dropout_mask": (I, [P, L, F, U64, U64, P]),
     "adyolo_loss_workspace_words": (L, [I, I, I, I]),
     "adyolo_loss_fwd_bwd": (I, [P] * 6 + [I] * 7 + [P, P, F, F, F, F, P]),
+    "adyolo_yolo_decode": (I, [P, P, L, I, I, I, I, F, F, F, P]),
     "adyolo_act_fwd": (I, [P, P, L, I, I, P]),
     "adyolo_act_bwd": (I, [P, P, P, L, I, I, P]),
     "adyolo_seddoa_loss": (I, [P] * 5 + [L, I, I, I, F, F, P]),

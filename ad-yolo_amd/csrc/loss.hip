@@ -276,3 +276,41 @@ extern "C" int adyolo_loss_fwd_bwd(const float *logit, const float *target, floa
                        loss);
     return check_launch("loss_final");
 }
+
+// ---- K8b: AD-YOLO decode for inference (reference datasets.py:752-771, LabelPostProcessor.get_yolo_output) ----
+// out[anchor][0] = sigmoid(obj); out[anchor][1..C] = sigmoid(cls) * sigmoid(obj) (class-confidence score);
+// out[anchor][C+1] = U (deg, wrapped to [-180,180)), out[anchor][C+2] = V (deg, clamped to [-90, 90 - 1e-7])
+namespace adyolo {
+__global__ __launch_bounds__(256) void yolo_decode_kernel(const float *__restrict__ logit, float *__restrict__ out,
+                                                          long n_anchor, int Gaz, int Gel, int A, int C, float grid_az,
+                                                          float grid_el, float span) {
+    const int CH = C + 3;
+    for (long a = (long)blockIdx.x * blockDim.x + threadIdx.x; a < n_anchor; a += (long)gridDim.x * blockDim.x) {
+        const long cell = a / A;
+        const int gj = (int)(cell % Gel), gi = (int)((cell / Gel) % Gaz);
+        const float *lp = logit + (size_t)a * CH;
+        float *op = out + (size_t)a * CH;
+        const float conf = sigmoidf_(lp[0]);
+        op[0] = conf;
+        for (int c = 1; c <= C; ++c) op[c] = sigmoidf_(lp[c]) * conf;
+        float u = tanhf(lp[C + 1]) * span * grid_az + (gi * grid_az - 180.f + 0.5f * grid_az);
+        float v = tanhf(lp[C + 2]) * span * grid_el + (gj * grid_el - 90.f + 0.5f * grid_el);
+        v = fminf(fmaxf(v, -90.f), 90.f - 1e-7f);
+        if (u >= 180.f) u -= 360.f;
+        if (u < -180.f) u += 360.f;
+        op[C + 1] = u;
+        op[C + 2] = v;
+    }
+}
+}  // namespace adyolo
+
+extern "C" int adyolo_yolo_decode(const float *logit, float *out, long n_frames, int Gaz, int Gel, int A, int C,
+                                  float grid_az, float grid_el, float g_overlap, void *stream) {
+    ADYOLO_REQUIRE(logit && out && n_frames > 0 && Gaz > 0 && Gel > 0 && A > 0 && C > 0, ADYOLO_EINVAL, "yolo_decode: bad arguments");
+    const long n_anchor = n_frames * Gaz * Gel * A;
+    long g = (n_anchor + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(adyolo::yolo_decode_kernel, dim3((unsigned)g), dim3(256), 0, adyolo::as_stream(stream), logit, out,
+                       n_anchor, Gaz, Gel, A, C, grid_az, grid_el, 0.5f + g_overlap);
+    return adyolo::check_launch("yolo_decode");
+}

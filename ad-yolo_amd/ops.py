@@ -405,6 +405,17 @@ def adpit_loss(out2d, tgt, nb_classes, need_grad=True):
     return loss, dout
 
 
+def yolo_decode(logit, nb_classes, grid=(8, 4), anchors=5, grid_size=(45.0, 45.0), g_overlap=0.5):
+    """logit [...][G*A*(C+3)] -> decoded [frames][Gaz][Gel][A][C+3] (conf, class-confidence scores, U, V)."""
+    _chk(logit)
+    ch = nb_classes + 3
+    frames = logit.numel() // (grid[0] * grid[1] * anchors * ch)
+    out = _new(logit, frames, grid[0], grid[1], anchors, ch)
+    _c("adyolo_yolo_decode", _p(logit), _p(out), frames, grid[0], grid[1], anchors, nb_classes, float(grid_size[0]),
+       float(grid_size[1]), float(g_overlap), _stream())
+    return out
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
               grad_scale=1.0):
     _chk(param, grad, exp_avg, exp_avg_sq)

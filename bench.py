@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--seconds", type=int, default=60, help="clip length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--encoder", default="se-resnet34", choices=["se-resnet34", "resnet-conformer"],
+                    help="se-resnet34 = the headline workload (BASELINE configs[1]); resnet-conformer = config 4")
     args = ap.parse_args()
 
     import adyolo_amd  # noqa: F401
@@ -139,6 +141,7 @@ def main():
     T = n_samples // 600
     torch.manual_seed(100)
     prm = params(device)
+    prm["args"]["encoder"] = args.encoder
     model = WrapperModel((1, 7, T, 64), (), prm).to(device)
     trainer = TrainStep(model, WrapperCriterion(prm), FeatureExtractor(None, device), prm)
     audio = synthetic_audio(B, n_samples, seed=1234 + rank).to(device)
@@ -196,7 +199,7 @@ def main():
             "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "se-resnet34 + adyolo loss, synthetic 4ch 24kHz %ds clips, bs=%d per GPU, "
+            "config": {"workload": args.encoder + " + adyolo loss, synthetic 4ch 24kHz %ds clips, bs=%d per GPU, "
                                    "12 classes, features+fwd+loss+bwd+allreduce+Adam" % (args.seconds, B),
                        "global_batch": world * B, "clip_seconds": args.seconds, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_fwd_kernel (forward + data-gradient launches)",

@@ -231,6 +231,12 @@ int  adyolo_loss_fwd_bwd(const float *logit, const float *target, float *ws, flo
                          int M, const float *thr_host, const float *gains_host, float grid_az,
                          float grid_el, float g_overlap, float grad_scale, void *stream);
 
+/* K8b inference decode (LabelPostProcessor.get_yolo_output, src/datasets.py:752-771): per anchor
+ *   out = [sigmoid(obj), sigmoid(cls_c)*sigmoid(obj) x C, U deg in [-180,180), V deg in [-90, 90-1e-7]];
+ *   thresholding and the (tiny, data-dependent) NMS stay on the host (ad-yolo_amd/postprocess.py). */
+int adyolo_yolo_decode(const float *logit, float *out, long n_frames, int Gaz, int Gel, int A, int C,
+                       float grid_az, float grid_el, float g_overlap, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K10 the other heads / losses behind the reference's --loss switch (src/main.py:43)
  *   adyolo_act_fwd/bwd : y[r][c] = c < n_sigmoid_cols ? sigmoid(x) : tanh(x)   (linearheads.py:44-47,65,83)

@@ -256,6 +256,35 @@ def gen_other_losses():
     print("other_losses.npz", {k: float(out[k]) for k in out if k.endswith("_loss")})
 
 
+def gen_postprocess():
+    """Reference LabelPostProcessor.get_yolo_output for the three NMS modes on seeded logits with planted detections."""
+    from datasets import LabelPostProcessor
+    out = {}
+    g = torch.Generator().manual_seed(71)
+    t, c = 6, 12
+    logit = torch.randn(1, t, 8 * 4 * 5 * (c + 3), generator=g) * 1.5 - 2.0
+    lv = logit.view(t, 8, 4, 5, c + 3)
+    # plant confident, partly overlapping detections (same class in neighbouring cells / anchors, different classes)
+    for (fr, gi, gj, a, cls, u, v) in [(0, 3, 1, 0, 2, 0.1, 0.2), (0, 3, 1, 1, 2, 0.15, 0.25), (0, 4, 1, 2, 2, -0.8, 0.2),
+                                       (0, 6, 2, 0, 7, 0.0, 0.0), (1, 0, 0, 4, 5, -0.9, -0.5), (1, 7, 0, 3, 5, 0.9, -0.5),
+                                       (2, 2, 3, 1, 1, 0.3, 0.9), (2, 2, 3, 2, 1, 0.31, 0.88), (2, 2, 3, 3, 1, 0.5, 0.1),
+                                       (2, 2, 2, 0, 1, 0.3, 0.95), (4, 5, 2, 2, 9, 0.0, 0.3), (4, 5, 2, 2, 10, 0.0, 0.3)]:
+        lv[fr, gi, gj, a, 0] = 4.0
+        lv[fr, gi, gj, a, 1 + cls] = 3.5 + 0.1 * a
+        lv[fr, gi, gj, a, -2] = float(np.arctanh(u))
+        lv[fr, gi, gj, a, -1] = float(np.arctanh(v))
+    out["logit"] = logit.numpy()
+    for nms in ("conn-merge", "soft-merge", "default"):
+        prm = make_params()
+        prm["train_config"]["nms"] = nms
+        pp = LabelPostProcessor(prm)
+        res = pp.postprocess(logit.clone())
+        rows = [[fr] + [float(x) for x in d] for fr, dets in res.items() for d in dets]
+        out["rows_" + nms] = np.asarray(rows, dtype=np.float64)
+        print("postprocess", nms, len(rows), "detections in frames", sorted(res.keys()))
+    np.savez_compressed(os.path.join(HERE, "postprocess.npz"), **out)
+
+
 def _install_torchvision_stub():
     """torchvision==0.11 is not installed: BasicBlock per its published definition."""
     import torch.nn as nn
@@ -348,5 +377,6 @@ if __name__ == "__main__":
     gen_encoder()
     gen_init()
     gen_other_losses()
+    gen_postprocess()
     gen_conformer()
     gen_scaler()

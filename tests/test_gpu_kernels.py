@@ -639,6 +639,28 @@ def test_resnet_conformer_matches_reference_golden(ops):
             assert_close(got, ref, 1e-2, key + " vs reference golden")
 
 
+@pytest.mark.parametrize("nms", ["conn-merge", "soft-merge", "default"])
+def test_postprocess_matches_reference_golden(ops, nms, tmp_path):
+    from adyolo_amd.postprocess import LabelPostProcessor, write_seld_output_file
+    from oracle import postprocess as opp
+    g = np.load(os.path.join(G, "postprocess.npz"))
+    prm = _params()
+    prm["train_config"].update(conf_thresh=0.5, clss_thresh=0.5, unify_thresh=15.0, nms=nms)
+    pp = LabelPostProcessor(prm)
+    logit = dev(torch.from_numpy(g["logit"]))
+    dec = ops.yolo_decode(logit, 12)
+    assert_close(dec, torch.from_numpy(opp.decode(g["logit"], 12)), 1e-5, "decode vs oracle")
+    res = pp.postprocess(logit)
+    rows = np.asarray([[fr] + [float(x) for x in d] for fr, dets in res.items() for d in dets], dtype=np.float64)
+    ref = g["rows_" + nms]
+    assert rows.shape == ref.shape
+    np.testing.assert_array_equal(rows[:, :2], ref[:, :2])
+    np.testing.assert_allclose(rows[:, 2:], ref[:, 2:], rtol=0, atol=5e-5)
+    f = tmp_path / "out.csv"
+    write_seld_output_file(f, res)
+    assert len(open(f).read().strip().splitlines()) == len(rows)
+
+
 def test_adam_matches_torch(ops):
     g = torch.Generator().manual_seed(2)
     p0 = torch.randn(10001 + 3, generator=g)

@@ -251,3 +251,18 @@ def test_conformer_oracle_matches_reference():
             got = sd[key[5:]].grad.numpy().reshape(-1)[:g[key].size]
             ref = g[key].reshape(-1)
             np.testing.assert_allclose(got, ref, rtol=5e-3, atol=5e-3 * max(1e-3, float(np.abs(ref).max())), err_msg=key)
+
+
+# ---- inference post-processing (decode + NMS) ------------------------------------------------------------------
+@pytest.mark.parametrize("nms", ["conn-merge", "soft-merge", "default"])
+def test_postprocess_decode_and_nms_match_reference(nms):
+    from oracle import postprocess as opp
+    from adyolo_amd.postprocess import nms_decoded
+    g = np.load(os.path.join(G, "postprocess.npz"))
+    dec = opp.decode(g["logit"], 12)
+    res = nms_decoded(dec, 12, 0.5, 0.5, 15.0, nms)
+    rows = np.asarray([[fr] + [float(x) for x in d] for fr, dets in res.items() for d in dets], dtype=np.float64)
+    ref = g["rows_" + nms]
+    assert rows.shape == ref.shape
+    np.testing.assert_array_equal(rows[:, :2], ref[:, :2])          # frame, class: exact
+    np.testing.assert_allclose(rows[:, 2:], ref[:, 2:], rtol=0, atol=2e-5)
