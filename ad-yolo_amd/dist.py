@@ -23,7 +23,7 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("ADYOLO_FORCE_DP_HOOKS") == "1") and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -73,6 +73,8 @@ class BucketedAllReduce:
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # ADYOLO_FORCE_DP_HOOKS=1 exercises the bucketed RCCL path even with one rank (1-GPU smoke test of the N>1 code)
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("ADYOLO_FORCE_DP_HOOKS") == "1")
         total = flat.numel
         target = max(1, (total + n_buckets - 1) // n_buckets)
         self.buckets = []           # (start, end, [param indices])
@@ -90,7 +92,7 @@ class BucketedAllReduce:
         self._pending = [0] * len(self.buckets)
         self._works = []
         self._hooks = []
-        if self.world > 1:
+        if self.active:
             for i, p in enumerate(flat.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         self.reset()
@@ -115,7 +117,7 @@ class BucketedAllReduce:
     def finish(self):
         """Wait for all bucket reductions (launching any that never fired, e.g. unused parameters) and return
         the factor the optimizer must apply to the summed gradients (1/world)."""
-        if self.world > 1:
+        if self.active:
             for b, left in enumerate(self._pending):
                 if left > 0:
                     self._pending[b] = 0

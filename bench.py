@@ -195,7 +195,7 @@ def main():
         achieved = fl_f / (ms_f * 1e-3) / 1e12 if ms_f > 0 else 0.0
         value = world * B * args.seconds * args.steps / dt
         line = {
-            "metric": "train-step audio-sec/s (4ch, se-resnet34+adyolo)",
+            "metric": "train-step audio-sec/s (4ch, %s+adyolo)" % args.encoder,
             "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -221,7 +221,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
