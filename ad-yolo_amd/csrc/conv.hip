@@ -16,6 +16,7 @@
 //   every tap (9 accumulator tiles per wave) and walks pixel patches; the 4 waves split each patch's
 //   rows and are summed through LDS at the end; each workgroup writes one slab, slabs are reduced
 //   deterministically into the reference layout [Cout][Cin][3][3].
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace adyolo {
@@ -387,6 +388,9 @@ template <int KC, int BN, int TW>
 static int launch_fwd(const float *x, const float *wpk, const float *bias, const float *addend,
                       const float *addend_mask, const float *in_scale, const float *in_shift, float *y, float *stats,
                       int N, int H, int W, int Cin, int Cout, int relu, hipStream_t st) {
+    // (a variant that walks several patches per workgroup and prefetches the next halo patch into registers under
+    //  the current patch's MFMAs was measured 6-9 % SLOWER at every stage on MI355X -- 252 VGPRs, no gain over the
+    //  overlap two resident workgroups per CU already give -- and was removed; see DESIGN.md "Tried and rejected")
     constexpr int TH = 256 / TW;
     const int tilesW = cdiv(W, TW), tilesH = cdiv(H, TH);
     dim3 grid((unsigned)(N * tilesH * tilesW), (unsigned)(Cout / BN));
