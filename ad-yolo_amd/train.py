@@ -85,3 +85,26 @@ class TrainStep:
         scale = self.reducer.finish()
         self.optimizer.step(grad_scale=scale)
         return loss.detach()
+
+
+def train_one_epoch(params: dict, dataloader, model, optimizer, criterion, device):
+    """Mirror of ``train_one_epoch`` (/root/reference/src/train.py:40-62) for loaders that yield pre-computed features:
+    ``for feat (B,7,T,64), label in dataloader`` -> forward, zero_grad, loss, backward, step; returns the mean loss.
+    Works with ``torch.optim.Adam`` or ``FusedAdam`` (``TrainStep`` is the faster raw-audio + flat-buffer path).
+    The per-step ``loss.item()`` of the reference (a device sync every iteration, train.py:57) is replaced by one
+    device-side accumulation and a single sync at the end of the epoch."""
+    model.train()
+    total = None
+    n = 0
+    for i, (feat, label) in enumerate(dataloader):
+        feat = feat.to(device).float()
+        output = model(feat)
+        optimizer.zero_grad()
+        loss = criterion(output, label)
+        loss.backward()
+        optimizer.step()
+        total = loss.detach().reshape(-1)[:1].clone() if total is None else total + loss.detach().reshape(-1)[:1]
+        n = i + 1
+        if params.get("args", {}).get("quick_test") and i == 4:
+            break
+    return float(total) / max(n, 1) if total is not None else 0.0

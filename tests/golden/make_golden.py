@@ -285,6 +285,53 @@ def gen_postprocess():
     np.savez_compressed(os.path.join(HERE, "postprocess.npz"), **out)
 
 
+def gen_metrics():
+    """Reference ComputeSELDResults on small synthetic reference / prediction CSV folders."""
+    import tempfile
+    from utils.seld_metrics import ComputeSELDResults
+    rng = np.random.default_rng(81)
+    prm = make_params()
+    files = {}
+    with tempfile.TemporaryDirectory() as td:
+        ref_dir, pred_dir = os.path.join(td, "ref"), os.path.join(td, "pred")
+        os.makedirs(ref_dir); os.makedirs(pred_dir)
+        for fi in range(3):
+            name = "fold6_room1_mix%03d.csv" % fi
+            ref_rows, pred_rows = [], []
+            for frame in range(0, 57 + 10 * fi):
+                k = rng.choice(4, p=[0.35, 0.35, 0.2, 0.1])
+                for src in range(k):
+                    cls = int(rng.integers(0, 4)) if fi < 2 else int(rng.integers(0, 12))
+                    az, el = float(rng.integers(-180, 180)), float(rng.integers(-60, 60))
+                    ref_rows.append([frame, cls, src, az, el])
+                    u = rng.random()
+                    if u < 0.7:       # detected, with a localisation error that is sometimes > 20 degrees
+                        err = rng.normal(0, 6 if rng.random() < 0.8 else 30, size=2)
+                        a2, e2 = np.deg2rad(az + err[0]), np.deg2rad(np.clip(el + err[1], -89, 89))
+                        pred_rows.append([frame, cls, 0, np.cos(a2) * np.cos(e2), np.sin(a2) * np.cos(e2), np.sin(e2)])
+                    elif u < 0.8:     # wrong class
+                        a2, e2 = np.deg2rad(az), np.deg2rad(el)
+                        pred_rows.append([frame, (cls + 1) % 12, 0, np.cos(a2) * np.cos(e2), np.sin(a2) * np.cos(e2), np.sin(e2)])
+                if rng.random() < 0.1:  # spurious detection
+                    a2, e2 = rng.uniform(-np.pi, np.pi), rng.uniform(-1, 1)
+                    pred_rows.append([frame, int(rng.integers(0, 12)), 0, np.cos(a2) * np.cos(e2), np.sin(a2) * np.cos(e2), np.sin(e2)])
+            with open(os.path.join(ref_dir, name), "w") as f:
+                for r in ref_rows:
+                    f.write("%d,%d,%d,%d,%d\n" % (r[0], r[1], r[2], r[3], r[4]))
+            with open(os.path.join(pred_dir, name), "w") as f:
+                for r in pred_rows:
+                    f.write("{},{},{},{},{},{}\n".format(int(r[0]), int(r[1]), 0, float(r[3]), float(r[4]), float(r[5])))
+            files[name] = (np.asarray(ref_rows, dtype=np.float64), np.asarray(pred_rows, dtype=np.float64))
+        prm["data_config"]["sr"], prm["data_config"]["label_hop_len_s"] = 24000, 0.1
+        res = ComputeSELDResults(prm, ref_dir).get_SELD_Results(pred_dir)
+    out = {"scores": np.asarray([float(v) for v in res[:5]]), "classwise": np.asarray(res[5], dtype=np.float64),
+           "names": np.asarray(list(files.keys()))}
+    for i, (name, (r, p)) in enumerate(files.items()):
+        out["ref_%d" % i], out["pred_%d" % i] = r, p
+    np.savez_compressed(os.path.join(HERE, "metrics.npz"), **out)
+    print("metrics.npz ER F LE LR SELD =", out["scores"])
+
+
 def _install_torchvision_stub():
     """torchvision==0.11 is not installed: BasicBlock per its published definition."""
     import torch.nn as nn
@@ -378,5 +425,6 @@ if __name__ == "__main__":
     gen_init()
     gen_other_losses()
     gen_postprocess()
+    gen_metrics()
     gen_conformer()
     gen_scaler()

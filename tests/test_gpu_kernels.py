@@ -661,6 +661,41 @@ def test_postprocess_matches_reference_golden(ops, nms, tmp_path):
     assert len(open(f).read().strip().splitlines()) == len(rows)
 
 
+def test_train_one_epoch_and_test_epoch_entry_points(ops, tmp_path):
+    """train_one_epoch / test_epoch mirrors on a tiny in-memory loader; CSVs are scored by the SELD evaluator."""
+    from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
+    from adyolo_amd.train import train_one_epoch
+    from adyolo_amd.test import test_epoch
+    from adyolo_amd.postprocess import LabelPostProcessor
+    from adyolo_amd.seld_metrics import ComputeSELDResults
+    from adyolo_amd.datasets import synthetic_targets
+    torch.manual_seed(100)
+    prm = _params()
+    prm["args"]["quick_test"] = False
+    prm["data_config"].update(sr=24000, label_hop_len_s=0.1)
+    prm["train_config"].update(conf_thresh=0.3, clss_thresh=0.3, unify_thresh=15.0, nms="conn-merge")
+    model = WrapperModel((1, 7, 40, 64), (), prm).to("cuda:0")
+    crit = WrapperCriterion(prm)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(5)
+    loader = [(torch.randn(2, 7, 40, 64, generator=g), synthetic_targets(2, 10, 12, seed=s)) for s in range(3)]
+    l1 = train_one_epoch(prm, loader, model, opt, crit, "cuda:0")
+    l2 = train_one_epoch(prm, loader, model, opt, crit, "cuda:0")
+    assert np.isfinite(l1) and np.isfinite(l2) and l2 < l1
+    files = ["fold6_room1_mix001", "fold6_room1_mix002"]
+    eval_loader = [(torch.randn(1, 7, 40, 64, generator=g), synthetic_targets(1, 10, 12, seed=9 + i)) for i in range(2)]
+    out_dir, ref_dir = tmp_path / "output_val", tmp_path / "ref"
+    ref_dir.mkdir()
+    for name in files:
+        with open(ref_dir / (name + ".csv"), "w") as f:
+            for fr in range(10):
+                f.write("%d,%d,0,%d,%d\n" % (fr, fr % 12, 10 * fr - 40, 5))
+    loss = test_epoch(eval_loader, files, model, crit, LabelPostProcessor(prm), "cuda:0", str(out_dir))
+    assert np.isfinite(loss) and sorted(os.listdir(out_dir)) == [n + ".csv" for n in files]
+    er, f1, le, lr, seld, cw = ComputeSELDResults(prm, str(ref_dir)).get_SELD_Results(str(out_dir))
+    assert 0.0 <= seld <= 1.5 and cw.shape == (5, 12)
+
+
 def test_adam_matches_torch(ops):
     g = torch.Generator().manual_seed(2)
     p0 = torch.randn(10001 + 3, generator=g)

@@ -133,3 +133,22 @@ def test_conformer_state_dict_and_init_match_reference():
         assert str(tuple(v.shape)) == str(shp), name
         assert float(v.reshape(-1)[0]) == float(f), name
         assert float(v.double().sum()) == pytest.approx(float(s), rel=1e-12, abs=1e-12), name
+
+
+def test_seld_metrics_match_reference(tmp_path):
+    """ER / F / LE / LR / SELD and the class-wise table vs the reference evaluator on the same CSV folders."""
+    from adyolo_amd.seld_metrics import ComputeSELDResults
+    g = np.load(os.path.join(G, "metrics.npz"))
+    ref_dir, pred_dir = tmp_path / "ref", tmp_path / "pred"
+    ref_dir.mkdir(); pred_dir.mkdir()
+    for i, name in enumerate(g["names"]):
+        with open(ref_dir / str(name), "w") as f:
+            for r in g["ref_%d" % i]:
+                f.write("%d,%d,%d,%d,%d\n" % tuple(int(v) for v in r))
+        with open(pred_dir / str(name), "w") as f:
+            for r in g["pred_%d" % i]:
+                f.write("{},{},{},{},{},{}\n".format(int(r[0]), int(r[1]), 0, float(r[3]), float(r[4]), float(r[5])))
+    prm = {"data_config": {"nb_classes": 12, "sr": 24000, "label_hop_len_s": 0.1}}
+    res = ComputeSELDResults(prm, str(ref_dir)).get_SELD_Results(str(pred_dir))
+    np.testing.assert_allclose(np.asarray([float(v) for v in res[:5]]), g["scores"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(res[5], g["classwise"], rtol=1e-9, atol=1e-9)
