@@ -82,6 +82,7 @@ SIGNATURES = {
     "adyolo_avgpool1d_bwd": (I, [P, P, I, I, I, I, F, P]),
     "adyolo_ln_fwd": (I, [P] * 4 + [L, I, F, P]),
     "adyolo_ln_bwd": (I, [P] * 7 + [L, I, F, P]),
+    "adyolo_foa_rotate": (I, [P, P, P, I, L, P]),
     "adyolo_adam_step": (I, [P] * 4 + [L, F, F, F, F, F, I, F, P]),
 }
 

@@ -1,0 +1,66 @@
+"""FOA rotation augmentation.  Mirror of ``RotationAug`` (/root/reference/src/utils/augmentations.py:36-111): 16
+combinations of channel sign flips / X-Y swap with the matching azimuth / elevation remapping of the labels.
+``rotate_labels`` is the host half (label dict); ``rotate_audio`` applies the channel transform to a whole batch of raw
+audio on the GPU (csrc/optim.hip ``foa_rotate_kernel``).  SpecAug (torchaudio 0.10 masking, augmentations.py:6-33) is
+not built: its arithmetic lives in torchaudio which is absent here (parity unpinned)."""
+import random
+
+import torch
+
+from . import _lib
+from .ops import _p, _stream
+
+# (yzx sign weights, xy swap, azimuth weight, azimuth offset, elevation weight) -- augmentations.py:45-68
+COMBINATIONS = [
+    ((1, 1, 1), False, 1, 0, 1), ((1, -1, 1), False, 1, 0, -1),
+    ((-1, 1, 1), False, -1, 0, 1), ((-1, -1, 1), False, -1, 0, -1),
+    ((-1, 1, -1), False, 1, 180, 1), ((-1, -1, -1), False, 1, 180, -1),
+    ((1, 1, -1), False, -1, 180, 1), ((1, -1, -1), False, -1, 180, -1),
+    ((-1, 1, 1), True, 1, 90, 1), ((-1, -1, 1), True, 1, 90, -1),
+    ((1, 1, 1), True, -1, 90, 1), ((1, -1, 1), True, -1, 90, -1),
+    ((1, 1, -1), True, 1, -90, 1), ((1, -1, -1), True, 1, -90, -1),
+    ((-1, 1, -1), True, -1, -90, 1), ((-1, -1, -1), True, -1, -90, -1),
+]
+
+
+def rotate_labels(label: dict, comb_no: int):
+    """label {frame: [[cls, src, az, el], ...]} -> rotated copy (augmentations.py:98-109)."""
+    _, _, pw, dpi, tw = COMBINATIONS[int(comb_no)]
+    out = {}
+    for frame, events in label.items():
+        rows = []
+        for ev in events:
+            pi = ev[-2] * pw + dpi
+            if pi < -180:
+                pi += 360
+            elif pi > 180:
+                pi -= 360
+            rows.append(list(ev[:-2]) + [pi, ev[-1] * tw])
+        out[frame] = rows
+    return out
+
+
+def rotate_audio(audio, comb_nos):
+    """audio (B, n_samples, 4) float32 on the GPU, comb_nos: B combination indices -> rotated audio (new tensor)."""
+    if not audio.is_cuda or audio.dtype != torch.float32 or not audio.is_contiguous():
+        raise _lib.AdyoloHipError("rotate_audio needs contiguous float32 audio (B, n_samples, 4) on the GPU")
+    b, n, _ = audio.shape
+    cfg = torch.tensor([[*COMBINATIONS[int(c)][0], float(COMBINATIONS[int(c)][1])] for c in comb_nos],
+                       dtype=torch.float32).to(audio.device)
+    out = torch.empty_like(audio)
+    _lib.call("adyolo_foa_rotate", _p(audio), _p(out), _p(cfg), b, n, _stream())
+    return out
+
+
+class RotationAug:
+    """Same surface as the reference class: ``augment(audio (T,4) on the GPU as (1,T,4) or labels only, label)``."""
+
+    def __init__(self, params: dict, is_valid: bool):
+        self.apply_augment = bool(params["aug_config"]["rotation_augment"]) and not is_valid
+
+    def augment(self, audio, label, comb_no=None):
+        if not self.apply_augment:
+            return audio, label
+        if comb_no is None:
+            comb_no = int(random.uniform(0, 16))
+        return rotate_audio(audio.view(1, -1, 4), [comb_no]).view_as(audio), rotate_labels(label, comb_no)

@@ -17,7 +17,7 @@
 
 namespace adyolo {
 
-constexpr int FN = 1200, FBINS = 601, FHOP = 600, NMEL = 64, FR = 8, SPS = 9;
+constexpr int FN = 1200, FBINS = 601, FHOP = 600, NMEL = 64, FR = 8;
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);

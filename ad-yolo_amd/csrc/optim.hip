@@ -79,3 +79,30 @@ extern "C" int adyolo_nchw_to_nhwc8(const float *x, float *y, int B, int C, int 
                        y, C, HW, total);
     return check_launch("nchw_to_nhwc8");
 }
+
+// ---- FOA rotation augmentation on raw audio (reference src/utils/augmentations.py:81-96): per clip a sign for each of
+// the Y, Z, X channels and an optional X <-> Y swap;  audio [B][n][4] (W, Y, Z, X), cfg[b] = {sy, sz, sx, swap}
+namespace adyolo {
+__global__ __launch_bounds__(256) void foa_rotate_kernel(const float4 *__restrict__ x, float4 *__restrict__ y,
+                                                         const float *__restrict__ cfg, long n_per_clip) {
+    const int b = blockIdx.y;
+    const float sy = cfg[b * 4 + 0], sz = cfg[b * 4 + 1], sx = cfg[b * 4 + 2];
+    const bool swap = cfg[b * 4 + 3] != 0.f;
+    const float4 *src = x + (size_t)b * n_per_clip;
+    float4 *dst = y + (size_t)b * n_per_clip;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_per_clip; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = src[i];
+        const float yy = v.y * sy, zz = v.z * sz, xx = v.w * sx;
+        dst[i] = swap ? make_float4(v.x, xx, zz, yy) : make_float4(v.x, yy, zz, xx);
+    }
+}
+}  // namespace adyolo
+
+extern "C" int adyolo_foa_rotate(const float *audio, float *out, const float *cfg, int B, long n_samples, void *stream) {
+    ADYOLO_REQUIRE(audio && out && cfg && B > 0 && n_samples > 0, ADYOLO_EINVAL, "foa_rotate: bad arguments");
+    long g = (n_samples + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(adyolo::foa_rotate_kernel, dim3((unsigned)g, B), dim3(256), 0, adyolo::as_stream(stream),
+                       (const float4 *)audio, (float4 *)out, cfg, n_samples);
+    return adyolo::check_launch("foa_rotate");
+}

@@ -295,6 +295,10 @@ int adyolo_ln_fwd(const float *x, const float *gamma, const float *beta, float *
 int adyolo_ln_bwd(const float *dy, const float *x, const float *gamma, float *dx, float *dgamma, float *dbeta,
                   float *partial, long R, int C, float eps, void *stream);
 
+/* FOA rotation augmentation on raw audio (src/utils/augmentations.py:81-96): audio/out [B][n_samples][4] (W,Y,Z,X),
+ * cfg [B][4] = {sign_y, sign_z, sign_x, swap_xy}.  Label angles are remapped on the host (augmentations.RotationAug). */
+int adyolo_foa_rotate(const float *audio, float *out, const float *cfg, int B, long n_samples, void *stream);
+
 /* K11 fused Adam over one flat parameter buffer (torch.optim.Adam at src/train.py:31,55; no amsgrad) */
 int adyolo_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long n,
                      float lr, float beta1, float beta2, float eps, float weight_decay, int step,

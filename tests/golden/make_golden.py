@@ -285,6 +285,25 @@ def gen_postprocess():
     np.savez_compressed(os.path.join(HERE, "postprocess.npz"), **out)
 
 
+def gen_rotation():
+    """Reference RotationAug for all 16 combinations on a small int16 clip + labels."""
+    from utils.augmentations import RotationAug
+    prm = make_params()
+    prm["aug_config"]["rotation_augment"] = True
+    aug = RotationAug(prm, is_valid=False)
+    rng = np.random.default_rng(91)
+    audio = rng.integers(-3000, 3000, size=(64, 4)).astype(np.int16)
+    label = {0: [[3, 0, 10.0, 5.0]], 4: [[1, 0, -170.0, 40.0], [2, 1, 180.0, -30.0]], 7: [[5, 0, -95.0, -60.0], [5, 1, 135.0, 0.0]]}
+    outs_a, outs_l = [], []
+    for c in range(16):
+        a, l = aug.augment(audio.copy(), copy.deepcopy(label), comb_no=c)
+        outs_a.append(np.asarray(a))
+        outs_l.append([[fr] + [float(v) for v in ev] for fr, evs in l.items() for ev in evs])
+    np.savez_compressed(os.path.join(HERE, "rotation.npz"), audio=audio, audio_rot=np.stack(outs_a),
+                        label_rot=np.asarray(outs_l, dtype=np.float64))
+    print("rotation.npz", np.stack(outs_a).shape, np.asarray(outs_l).shape)
+
+
 def gen_metrics():
     """Reference ComputeSELDResults on small synthetic reference / prediction CSV folders."""
     import tempfile
@@ -426,5 +445,6 @@ if __name__ == "__main__":
     gen_other_losses()
     gen_postprocess()
     gen_metrics()
+    gen_rotation()
     gen_conformer()
     gen_scaler()

@@ -696,6 +696,15 @@ def test_train_one_epoch_and_test_epoch_entry_points(ops, tmp_path):
     assert 0.0 <= seld <= 1.5 and cw.shape == (5, 12)
 
 
+def test_rotation_audio_matches_reference(ops):
+    from adyolo_amd.augmentations import rotate_audio
+    g = np.load(os.path.join(G, "rotation.npz"))
+    audio = torch.from_numpy(g["audio"].astype(np.float32))
+    batch = dev(audio[None].repeat(16, 1, 1))
+    out = rotate_audio(batch, list(range(16))).cpu().numpy()
+    np.testing.assert_array_equal(out, g["audio_rot"].astype(np.float32))
+
+
 def test_adam_matches_torch(ops):
     g = torch.Generator().manual_seed(2)
     p0 = torch.randn(10001 + 3, generator=g)

@@ -152,3 +152,14 @@ def test_seld_metrics_match_reference(tmp_path):
     res = ComputeSELDResults(prm, str(ref_dir)).get_SELD_Results(str(pred_dir))
     np.testing.assert_allclose(np.asarray([float(v) for v in res[:5]]), g["scores"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(res[5], g["classwise"], rtol=1e-9, atol=1e-9)
+
+
+def test_rotation_labels_match_reference():
+    from adyolo_amd.augmentations import rotate_labels
+    g = np.load(os.path.join(G, "rotation.npz"))
+    label = {0: [[3, 0, 10.0, 5.0]], 4: [[1, 0, -170.0, 40.0], [2, 1, 180.0, -30.0]],
+             7: [[5, 0, -95.0, -60.0], [5, 1, 135.0, 0.0]]}
+    for c in range(16):
+        lab = rotate_labels(label, c)
+        rows = np.asarray([[fr] + [float(v) for v in ev] for fr, evs in lab.items() for ev in evs])
+        np.testing.assert_array_equal(rows, g["label_rot"][c])
