@@ -24,7 +24,7 @@ SIGNATURES = {
     "adyolo_nchw_to_nhwc8": (I, [P, P, I, I, I, I, P]),
     "adyolo_pack_w3x3": (I, [P, P, P, I, I, I, P]),
     "adyolo_conv3x3_tiles": (I, [I] * 3),
-    "adyolo_conv3x3_fwd": (I, [P] * 9 + [I] * 6 + [P]),
+    "adyolo_conv3x3_fwd": (I, [P] * 12 + [I] * 6 + [P]),
     "adyolo_conv3x3_wgrad_slabs": (I, [I] * 5),
     "adyolo_conv3x3_wgrad": (I, [P] * 6 + [I] * 6 + [P]),
     "adyolo_gemm": (I, [P] * 5 + [I] * 10 + [P]),
@@ -36,6 +36,7 @@ SIGNATURES = {
     "adyolo_bn_scale_shift": (I, [P] * 6 + [I, P]),
     "adyolo_affine_nhwc": (I, [P] * 4 + [L, I, P]),
     "adyolo_bn_bwd_reduce": (I, [P] * 7 + [L, I, P]),
+    "adyolo_bn_bwd_tiles": (I, [P, P, P, I, I, P]),
     "adyolo_bn_bwd_apply": (I, [P] * 10 + [L, I, I, P]),
     "adyolo_se_fc_fwd": (I, [P] * 10 + [I, I, I, I, P]),
     "adyolo_se_tail_fwd": (I, [P] * 6 + [I, I, I, P]),

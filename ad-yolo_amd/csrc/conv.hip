@@ -39,8 +39,9 @@ template <int KC, int BN, int TW>
 __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(
     const float *__restrict__ x, const float *__restrict__ wpk, const float *__restrict__ bias,
     const float *__restrict__ addend, const float *__restrict__ addend_mask, const float *__restrict__ in_scale,
-    const float *__restrict__ in_shift, float *__restrict__ y, float *__restrict__ stats, int H, int W, int Cin,
-    int Cout, int tilesW, int tilesH, int relu) {
+    const float *__restrict__ in_shift, float *__restrict__ y, float *__restrict__ stats,
+    const float *__restrict__ stat_aux, const float *__restrict__ stat_mean, const float *__restrict__ stat_invstd,
+    int H, int W, int Cin, int Cout, int tilesW, int tilesH, int relu) {
     using Cfg = ConvCfg<KC, BN, TW>;
     constexpr int TH = Cfg::TH, HW_ = Cfg::HW_, NPIX = Cfg::NPIX, AS = Cfg::AS, NT = Cfg::NT, Q = Cfg::Q;
     constexpr int WPT = Cfg::WPT;
@@ -189,7 +190,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(
                     if (relu) v = fmaxf(v, 0.f);
                     y[o] = v;
                     ssum[nt] += v;
-                    ssq[nt] += v * v;
+                    // second statistic: v^2 (BatchNorm forward of the consumer) or v * xhat(aux) (BatchNorm backward:
+                    // sum dy * xhat, with aux = the BatchNorm input living at the same positions as this output)
+                    ssq[nt] += stat_aux ? v * (stat_aux[o] - stat_mean[co]) * stat_invstd[co] : v * v;
                 }
             }
         }
@@ -358,18 +361,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(
     }
 }
 
-__global__ void conv3x3_wgrad_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ dw,
-                                            int nslab, int Cout, int CinP, int Cin_real) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // over [Cout][9][CinP]
+// slabs [nslab][Cout][9][CinP] -> dw [Cout][Cin_real][3][3]: 32 outputs x 8 slab-groups per workgroup (coalesced 128-byte
+// rows, partial sums in double), deterministic
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float *__restrict__ slabs,
+                                                                   float *__restrict__ dw, int nslab, int Cout,
+                                                                   int CinP, int Cin_real) {
+    __shared__ double red[256];
     const int total = Cout * 9 * CinP;
-    if (idx >= total) return;
+    const double sum = block_colsum32(slabs, nslab, (size_t)total, blockIdx.x * 32, total, red);
+    const int idx = blockIdx.x * 32 + (threadIdx.x & 31);
+    if ((threadIdx.x >> 5) != 0 || idx >= total) return;
     const int ci = idx % CinP;
     const int tap = (idx / CinP) % 9;
     const int co = idx / (CinP * 9);
-    if (ci >= Cin_real) return;
-    float s = 0.f;
-    for (int k = 0; k < nslab; ++k) s += slabs[(size_t)k * total + idx];
-    dw[((size_t)co * Cin_real + ci) * 9 + tap] = s;
+    if (ci < Cin_real) dw[((size_t)co * Cin_real + ci) * 9 + tap] = (float)sum;
 }
 
 __global__ void pack_w3x3_kernel(const float *__restrict__ w, float *__restrict__ wf,
@@ -387,7 +392,8 @@ __global__ void pack_w3x3_kernel(const float *__restrict__ w, float *__restrict_
 template <int KC, int BN, int TW>
 static int launch_fwd(const float *x, const float *wpk, const float *bias, const float *addend,
                       const float *addend_mask, const float *in_scale, const float *in_shift, float *y, float *stats,
-                      int N, int H, int W, int Cin, int Cout, int relu, hipStream_t st) {
+                      const float *stat_aux, const float *stat_mean, const float *stat_invstd, int N, int H, int W,
+                      int Cin, int Cout, int relu, hipStream_t st) {
     // (a variant that walks several patches per workgroup and prefetches the next halo patch into registers under
     //  the current patch's MFMAs was measured 6-9 % SLOWER at every stage on MI355X -- 252 VGPRs, no gain over the
     //  overlap two resident workgroups per CU already give -- and was removed; see DESIGN.md "Tried and rejected")
@@ -395,7 +401,8 @@ static int launch_fwd(const float *x, const float *wpk, const float *bias, const
     const int tilesW = cdiv(W, TW), tilesH = cdiv(H, TH);
     dim3 grid((unsigned)(N * tilesH * tilesW), (unsigned)(Cout / BN));
     hipLaunchKernelGGL((conv3x3_fwd_kernel<KC, BN, TW>), grid, dim3(256), 0, st, x, wpk, bias, addend, addend_mask,
-                       in_scale, in_shift, y, stats, H, W, Cin, Cout, tilesW, tilesH, relu);
+                       in_scale, in_shift, y, stats, stat_aux, stat_mean, stat_invstd, H, W, Cin, Cout, tilesW, tilesH,
+                       relu);
     return check_launch("conv3x3_fwd");
 }
 
@@ -432,16 +439,21 @@ extern "C" int adyolo_conv3x3_tiles(int N, int H, int W) {
 
 extern "C" int adyolo_conv3x3_fwd(const float *x, const float *wpk, const float *bias, const float *addend,
                                   const float *addend_mask, const float *in_scale, const float *in_shift, float *y,
-                                  float *stats, int N, int H, int W, int Cin, int Cout, int relu, void *stream) {
+                                  float *stats, const float *stat_aux, const float *stat_mean,
+                                  const float *stat_invstd, int N, int H, int W, int Cin, int Cout, int relu,
+                                  void *stream) {
     ADYOLO_REQUIRE(x && wpk && y && N > 0 && H > 0 && W > 0, ADYOLO_EINVAL, "conv3x3_fwd: bad arguments");
     ADYOLO_REQUIRE((Cin == 8 || Cin % 32 == 0) && Cout % 32 == 0, ADYOLO_ENOSUP,
                    "conv3x3_fwd: Cin=%d must be 8 or a multiple of 32, Cout=%d a multiple of 32", Cin, Cout);
     ADYOLO_REQUIRE((in_scale == nullptr) == (in_shift == nullptr) && (!addend_mask || addend), ADYOLO_EINVAL,
                    "conv3x3_fwd: in_scale/in_shift come together; addend_mask needs addend");
+    ADYOLO_REQUIRE(!stat_aux || (stats && stat_mean && stat_invstd), ADYOLO_EINVAL,
+                   "conv3x3_fwd: stat_aux needs stats, stat_mean and stat_invstd");
     hipStream_t st = as_stream(stream);
     const bool wide = W >= 32;
 #define ADYOLO_FWD(KC_, BN_, TW_) \
-    launch_fwd<KC_, BN_, TW_>(x, wpk, bias, addend, addend_mask, in_scale, in_shift, y, stats, N, H, W, Cin, Cout, relu, st)
+    launch_fwd<KC_, BN_, TW_>(x, wpk, bias, addend, addend_mask, in_scale, in_shift, y, stats, stat_aux, stat_mean, \
+                              stat_invstd, N, H, W, Cin, Cout, relu, st)
     if (Cin == 8) return wide ? ADYOLO_FWD(8, 32, 32) : ADYOLO_FWD(8, 32, 16);
     if (Cout % 64 == 0) return wide ? ADYOLO_FWD(32, 64, 32) : ADYOLO_FWD(32, 64, 16);
     return wide ? ADYOLO_FWD(32, 32, 32) : ADYOLO_FWD(32, 32, 16);
@@ -477,7 +489,7 @@ extern "C" int adyolo_conv3x3_wgrad(const float *x, const float *dy, const float
     if (rc) return rc;
     const int CinP = cinBlocks * 32;
     const int total = Cout * 9 * CinP;
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, slabs, dw, nsplit,
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, slabs, dw, nsplit,
                        Cout, CinP, Cin_real);
     return check_launch("conv3x3_wgrad_reduce");
 }

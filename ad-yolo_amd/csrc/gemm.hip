@@ -46,17 +46,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
-    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
-        __syncthreads();
+    // software pipeline: the next K tile is fetched into registers while the current one feeds the matrix cores
+    float4 ra[4], rb[2];
+    auto fetch = [&](int k0) {
         if (!TA) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int idx = tid + i * 256;
                 const int row = idx >> 3, q = idx & 7;
                 const int m = m0 + row, k = k0 + q * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < M && k < kend) v = *reinterpret_cast<const float4 *>(A + (size_t)m * lda + k);
-                *reinterpret_cast<float4 *>(&As[row * A_LD + q * 4]) = v;
+                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < M && k < kend) ra[i] = *reinterpret_cast<const float4 *>(A + (size_t)m * lda + k);
             }
         } else {
 #pragma unroll
@@ -64,9 +64,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ 
                 const int idx = tid + i * 256;
                 const int kk = idx >> 5, q = idx & 31;
                 const int k = k0 + kk, m = m0 + q * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < kend && m < M) v = *reinterpret_cast<const float4 *>(A + (size_t)k * lda + m);
-                *reinterpret_cast<float4 *>(&As[kk * A_LD + q * 4]) = v;
+                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < kend && m < M) ra[i] = *reinterpret_cast<const float4 *>(A + (size_t)k * lda + m);
             }
         }
         if (!TB) {
@@ -75,9 +74,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ 
                 const int idx = tid + i * 256;
                 const int row = idx >> 3, q = idx & 7;
                 const int nn = n0 + row, k = k0 + q * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (nn < N && k < kend) v = *reinterpret_cast<const float4 *>(B + (size_t)nn * ldb + k);
-                *reinterpret_cast<float4 *>(&Bs[row * B_LD + q * 4]) = v;
+                rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (nn < N && k < kend) rb[i] = *reinterpret_cast<const float4 *>(B + (size_t)nn * ldb + k);
             }
         } else {
 #pragma unroll
@@ -85,12 +83,28 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ 
                 const int idx = tid + i * 256;
                 const int kk = idx >> 4, q = idx & 15;
                 const int k = k0 + kk, nn = n0 + q * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < kend && nn < N) v = *reinterpret_cast<const float4 *>(B + (size_t)k * ldb + nn);
-                *reinterpret_cast<float4 *>(&Bs[kk * B_LD + q * 4]) = v;
+                rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < kend && nn < N) rb[i] = *reinterpret_cast<const float4 *>(B + (size_t)k * ldb + nn);
             }
         }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
         __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * 256;
+            if (!TA) *reinterpret_cast<float4 *>(&As[(idx >> 3) * A_LD + (idx & 7) * 4]) = ra[i];
+            else *reinterpret_cast<float4 *>(&As[(idx >> 5) * A_LD + (idx & 31) * 4]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 256;
+            if (!TB) *reinterpret_cast<float4 *>(&Bs[(idx >> 3) * B_LD + (idx & 7) * 4]) = rb[i];
+            else *reinterpret_cast<float4 *>(&Bs[(idx >> 4) * B_LD + (idx & 15) * 4]) = rb[i];
+        }
+        __syncthreads();
+        if (k0 + GBK < kend) fetch(k0 + GBK);
 #pragma unroll
         for (int s = 0; s < GBK / 8; ++s) {
             float a[4], b[2][4];

@@ -468,6 +468,13 @@ extern "C" int adyolo_bn_bwd_reduce(const float *dy, const float *x, const float
     return check_launch("bn_bwd_reduce_final");
 }
 
+extern "C" int adyolo_bn_bwd_tiles(const float *tile_stats, float *sdy, float *sdyx, int tiles, int C, void *stream) {
+    ADYOLO_REQUIRE(tile_stats && sdy && sdyx && tiles > 0 && C > 0, ADYOLO_EINVAL, "bn_bwd_tiles: bad arguments");
+    hipLaunchKernelGGL(persample_reduce_kernel, dim3(cdiv(C, 32), 1), dim3(256), 0, as_stream(stream), tile_stats, sdy,
+                       sdyx, 1, tiles, C);
+    return check_launch("bn_bwd_tiles");
+}
+
 extern "C" int adyolo_bn_bwd_apply(const float *dy, const float *x, const float *gamma, const float *mean,
                                    const float *invstd, const float *sdy, const float *sdyx, float *dx, float *dgamma,
                                    float *dbeta, long rows, int C, int relu_mask, void *stream) {

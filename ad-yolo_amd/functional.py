@@ -15,6 +15,9 @@ from . import ops
 FUSE_AFFINE = os.environ.get("ADYOLO_FUSE_AFFINE", "1") != "0"   # BN1 affine applied while conv2 stages its input
 FUSE_STATS = os.environ.get("ADYOLO_FUSE_STATS", "1") != "0"     # BN statistics from the conv epilogue
 FUSE_DR = os.environ.get("ADYOLO_FUSE_DR", "1") != "0"           # identity-shortcut gradient formed in the dgrad epilogue
+# BN1 backward sums from the dgrad(conv2) epilogue: measured 7 % SLOWER per step (the epilogue's extra strided reads of
+# the BatchNorm input are not hidden), so it is off by default and kept only as an A/B switch
+FUSE_BNBWD = os.environ.get("ADYOLO_FUSE_BNBWD", "0") != "0"
 
 
 def _c(t):
@@ -164,8 +167,12 @@ class SEBlockFn(torch.autograd.Function):
         else:
             dw2 = ops.conv3x3_wgrad(src, dc, c)
             a = ctx.a_unfused
-        dbb = ops.conv3x3(dc, wpk2d, c)
-        da, dg1, db1 = ops.bn_bwd(dbb, a, g1, mean1, invstd1, relu_mask=True)
+        if FUSE_BNBWD:
+            dbb, st = ops.conv3x3(dc, wpk2d, c, want_stats=True, stat_bn=(a, mean1, invstd1))
+            da, dg1, db1 = ops.bn_bwd(dbb, a, g1, mean1, invstd1, relu_mask=True, tile_stats=st)
+        else:
+            dbb = ops.conv3x3(dc, wpk2d, c)
+            da, dg1, db1 = ops.bn_bwd(dbb, a, g1, mean1, invstd1, relu_mask=True)
         dw1 = ops.conv3x3_wgrad(p, da, cin)
         dwd = dgd = dbd = None
         if ctx.has_down:

@@ -54,12 +54,14 @@ def pack_w3x3(w, cin_pad, want_dgrad=True):
     return wf, wd
 
 
-def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, in_affine=None, want_stats=False):
+def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, in_affine=None, want_stats=False,
+            stat_bn=None):
     """x [N][H][W][Cin] -> [N][H][W][cout];  wpk [cout][9][Cin].
 
     in_affine=(scale, shift): the producer's BatchNorm affine is applied while staging x (padding stays 0);
     addend_mask: addend is multiplied by (mask > 0); want_stats: also return the per-patch channel sums
-    [2][tiles][cout] of the output for ``bn_stats_tiles``."""
+    [2][tiles][cout] of the output for ``bn_stats_tiles``; stat_bn=(aux, mean, invstd): the second per-patch sum
+    becomes sum(y * xhat(aux)) (the output is a gradient, aux the BatchNorm input) for ``bn_bwd(..., tile_stats=)``."""
     _chk(x, wpk, bias, addend, addend_mask)
     n, h, w, cin = x.shape
     y = _new(x, n, h, w, cout)
@@ -68,8 +70,9 @@ def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, 
         tiles = _lib.load().adyolo_conv3x3_tiles(n, h, w)
         stats = _new(x, 2, tiles, cout)
     sc, sh = in_affine if in_affine is not None else (None, None)
+    sa, sm, si = stat_bn if stat_bn is not None else (None, None, None)
     _c("adyolo_conv3x3_fwd", _p(x), _p(wpk), _p(bias), _p(addend), _p(addend_mask), _p(sc), _p(sh), _p(y), _p(stats),
-       n, h, w, cin, cout, int(relu), _stream())
+       _p(sa), _p(sm), _p(si), n, h, w, cin, cout, int(relu), _stream())
     return (y, stats) if want_stats else y
 
 
@@ -205,14 +208,19 @@ def affine(x, scale, shift):
     return y
 
 
-def bn_bwd(dy, x, gamma, mean, invstd, relu_mask=False):
-    """-> dx, dgamma, dbeta.  relu_mask: additionally multiply dx by (x > 0) (x is a ReLU output)."""
+def bn_bwd(dy, x, gamma, mean, invstd, relu_mask=False, tile_stats=None):
+    """-> dx, dgamma, dbeta.  relu_mask: additionally multiply dx by (x > 0) (x is a ReLU output).
+    tile_stats: per-patch (sum dy, sum dy*xhat) written by the convolution that produced dy (skips the reduce pass)."""
     _chk(dy, x, gamma, mean, invstd)
     c = x.shape[-1]
     rows = x.numel() // c
     sdy, sdyx = _new(x, c), _new(x, c)
-    partial = _new(x, 2 * 1024 * c)
-    _c("adyolo_bn_bwd_reduce", _p(dy), _p(x), _p(mean), _p(invstd), _p(sdy), _p(sdyx), _p(partial), rows, c, _stream())
+    if tile_stats is not None:
+        _c("adyolo_bn_bwd_tiles", _p(tile_stats), _p(sdy), _p(sdyx), tile_stats.shape[1], c, _stream())
+    else:
+        partial = _new(x, 2 * 1024 * c)
+        _c("adyolo_bn_bwd_reduce", _p(dy), _p(x), _p(mean), _p(invstd), _p(sdy), _p(sdyx), _p(partial), rows, c,
+           _stream())
     dx = torch.empty_like(x)
     _c("adyolo_bn_bwd_apply", _p(dy), _p(x), _p(gamma), _p(mean), _p(invstd), _p(sdy), _p(sdyx), _p(dx), NULL, NULL,
        rows, c, int(relu_mask), _stream())

@@ -66,8 +66,10 @@ int adyolo_nchw_to_nhwc8(const float *x, float *y, int B, int C, int H, int W, v
  *   y = relu?( conv(x', w) + bias + addend' )   with the optional fusions
  *     x' = x*in_scale[c] + in_shift[c] on in-image pixels (BatchNorm affine of the producer; zero padding stays 0)
  *     addend' = addend * (addend_mask > 0)  (residual gradient  de * (e > 0)  formed on the fly)
- *     stats [2][tiles][Cout]: per 256-pixel patch, per channel sum and sum of squares of y -- the BatchNorm
- *       statistics / SE squeeze of the consumer without a separate read pass (adyolo_bn_stats_tiles finishes).
+ *     stats [2][tiles][Cout]: per 256-pixel patch, per channel sum of y and either sum of y^2 (stat_aux == NULL: the
+ *       BatchNorm statistics / SE squeeze of the consumer, finished by adyolo_bn_stats_tiles) or sum of
+ *       y * (stat_aux - stat_mean[c]) * stat_invstd[c] (y is a gradient, stat_aux the BatchNorm input at the same
+ *       positions: the two sums of BatchNorm's backward, finished by adyolo_bn_bwd_tiles) -- no separate read pass.
  * data-gradient = the same call with the dgrad packing (wpk_dgrad, Cin<->Cout swapped).
  * weight-gradient: adyolo_conv3x3_wgrad accumulates into `slabs` ([n_slabs][Cout][9][CinP] float32,
  * n_slabs = adyolo_conv3x3_wgrad_slabs(...)) then reduces them into dw in the reference layout
@@ -79,7 +81,8 @@ int adyolo_pack_w3x3(const float *w /*[Cout][Cin_real][3][3]*/, float *wpk_fwd /
 int adyolo_conv3x3_tiles(int N, int H, int W);   /* number of 256-pixel patches = rows of `stats` */
 int adyolo_conv3x3_fwd(const float *x, const float *wpk, const float *bias, const float *addend,
                        const float *addend_mask, const float *in_scale, const float *in_shift, float *y,
-                       float *stats, int N, int H, int W, int Cin, int Cout, int relu, void *stream);
+                       float *stats, const float *stat_aux, const float *stat_mean, const float *stat_invstd,
+                       int N, int H, int W, int Cin, int Cout, int relu, void *stream);
 int adyolo_conv3x3_wgrad_slabs(int N, int H, int W, int Cin, int Cout);
 int adyolo_conv3x3_wgrad(const float *x, const float *dy, const float *in_scale, const float *in_shift,
                          float *slabs, float *dw, int N, int H, int W, int Cin, int Cin_real, int Cout,
@@ -137,6 +140,8 @@ int adyolo_affine_nhwc(const float *x, const float *scale, const float *shift, f
                        int C, void *stream);
 int adyolo_bn_bwd_reduce(const float *dy, const float *x, const float *mean, const float *invstd,
                          float *sdy, float *sdyx, float *partial, long rows, int C, void *stream);
+/* sdy / sdyx from the per-patch sums a data-gradient convolution wrote (stat_aux mode) */
+int adyolo_bn_bwd_tiles(const float *tile_stats, float *sdy, float *sdyx, int tiles, int C, void *stream);
 int adyolo_bn_bwd_apply(const float *dy, const float *x, const float *gamma, const float *mean,
                         const float *invstd, const float *sdy, const float *sdyx, float *dx,
                         float *dgamma, float *dbeta, long rows, int C, int relu_mask, void *stream);
