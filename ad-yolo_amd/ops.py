@@ -5,6 +5,7 @@ in ``dist.py``, torch.distributed/RCCL.  Every function launches hand-written gf
 ``libadyolo_hip.so``; nothing in this module computes with ATen ops.
 """
 import ctypes
+import os
 
 import torch
 
@@ -44,10 +45,29 @@ def _zeros(like, *shape):
 
 
 # ---------------------------------------------------------------------------------------------- conv
-def pack_w3x3(w, cin_pad, want_dgrad=True):
-    """w [Cout][Cin][3][3] -> (wpk_fwd [Cout][9][cin_pad], wpk_dgrad [cin_pad][9][Cout] or None)."""
+def conv_algo():
+    """'winograd' (default: F(2x2,3x3) on the fp32 MFMA, 2.25x fewer matrix FLOPs) or 'direct' (implicit GEMM);
+    chosen per call of ``pack_w3x3`` from ADYOLO_CONV_ALGO."""
+    a = os.environ.get("ADYOLO_CONV_ALGO", "winograd").lower()
+    if a not in ("winograd", "direct"):
+        raise _lib.AdyoloHipError("ADYOLO_CONV_ALGO must be 'winograd' or 'direct' (got %r)" % a)
+    return a
+
+
+def pack_w3x3(w, cin_pad, want_dgrad=True, algo=None):
+    """w [Cout][Cin][3][3] -> (fwd pack, dgrad pack or None).
+
+    direct:   wpk_fwd [Cout][9][cin_pad], wpk_dgrad [cin_pad][9][Cout]
+    winograd: u_fwd [16][Cout/32][cin_pad/8][256], u_dgrad [16][cin_pad/32][Cout/8][256]  (needs both channel
+              counts to be multiples of 32; the 8-channel stem stays direct).  ``conv3x3`` tells them apart by rank."""
     _chk(w)
     cout, cin = w.shape[0], w.shape[1]
+    algo = algo or conv_algo()
+    if algo == "winograd" and cin_pad % 32 == 0 and cout % 32 == 0:
+        uf = _new(w, 16, cout // 32, cin_pad // 8, 256)
+        ud = _new(w, 16, cin_pad // 32, cout // 8, 256) if want_dgrad else None
+        _c("adyolo_wino_pack_w", _p(w), _p(uf), _p(ud), cout, cin, cin_pad, _stream())
+        return uf, ud
     wf = _new(w, cout, 9, cin_pad)
     wd = _new(w, cin_pad, 9, cout) if want_dgrad else None
     _c("adyolo_pack_w3x3", _p(w), _p(wf), _p(wd), cout, cin, cin_pad, _stream())
@@ -56,7 +76,7 @@ def pack_w3x3(w, cin_pad, want_dgrad=True):
 
 def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, in_affine=None, want_stats=False,
             stat_bn=None):
-    """x [N][H][W][Cin] -> [N][H][W][cout];  wpk [cout][9][Cin].
+    """x [N][H][W][Cin] -> [N][H][W][cout];  wpk from ``pack_w3x3`` (direct [cout][9][Cin] or Winograd, rank 4).
 
     in_affine=(scale, shift): the producer's BatchNorm affine is applied while staging x (padding stays 0);
     addend_mask: addend is multiplied by (mask > 0); want_stats: also return the per-patch channel sums
@@ -64,15 +84,16 @@ def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, 
     becomes sum(y * xhat(aux)) (the output is a gradient, aux the BatchNorm input) for ``bn_bwd(..., tile_stats=)``."""
     _chk(x, wpk, bias, addend, addend_mask)
     n, h, w, cin = x.shape
+    wino = wpk.dim() == 4
     y = _new(x, n, h, w, cout)
     stats = None
     if want_stats:
-        tiles = _lib.load().adyolo_conv3x3_tiles(n, h, w)
+        tiles = (_lib.load().adyolo_wino_tiles if wino else _lib.load().adyolo_conv3x3_tiles)(n, h, w)
         stats = _new(x, 2, tiles, cout)
     sc, sh = in_affine if in_affine is not None else (None, None)
     sa, sm, si = stat_bn if stat_bn is not None else (None, None, None)
-    _c("adyolo_conv3x3_fwd", _p(x), _p(wpk), _p(bias), _p(addend), _p(addend_mask), _p(sc), _p(sh), _p(y), _p(stats),
-       _p(sa), _p(sm), _p(si), n, h, w, cin, cout, int(relu), _stream())
+    _c("adyolo_wino_fwd" if wino else "adyolo_conv3x3_fwd", _p(x), _p(wpk), _p(bias), _p(addend), _p(addend_mask),
+       _p(sc), _p(sh), _p(y), _p(stats), _p(sa), _p(sm), _p(si), n, h, w, cin, cout, int(relu), _stream())
     return (y, stats) if want_stats else y
 
 

@@ -83,6 +83,18 @@ int adyolo_conv3x3_fwd(const float *x, const float *wpk, const float *bias, cons
                        const float *addend_mask, const float *in_scale, const float *in_shift, float *y,
                        float *stats, const float *stat_aux, const float *stat_mean, const float *stat_invstd,
                        int N, int H, int W, int Cin, int Cout, int relu, void *stream);
+/* K2w  the same operator as Winograd F(2x2,3x3) (2.25x fewer matrix FLOPs; fp32 throughout, results agree with the
+ *      direct form to ~1e-6 relative).  u_fwd / u_dgrad: the transformed filters G g G^T in MFMA-fragment order
+ *      [16][Cout/32][Cin/8][64][4] (forward) / [16][Cin/32][Cout/8][64][4] (data-gradient, taps flipped, channels
+ *      transposed); Cin and Cout multiples of 32.  adyolo_wino_fwd takes the arguments of adyolo_conv3x3_fwd with
+ *      `u` in place of `wpk`; its `stats` rows are 8x16-pixel patches: adyolo_wino_tiles(N,H,W) of them. */
+int adyolo_wino_pack_w(const float *w /*[Cout][Cin_real][3][3]*/, float *u_fwd /*or NULL*/, float *u_dgrad /*or NULL*/,
+                       int Cout, int Cin_real, int Cin, void *stream);
+int adyolo_wino_tiles(int N, int H, int W);
+int adyolo_wino_fwd(const float *x, const float *u, const float *bias, const float *addend,
+                    const float *addend_mask, const float *in_scale, const float *in_shift, float *y, float *stats,
+                    const float *stat_aux, const float *stat_mean, const float *stat_invstd, int N, int H, int W,
+                    int Cin, int Cout, int relu, void *stream);
 int adyolo_conv3x3_wgrad_slabs(int N, int H, int W, int Cin, int Cout);
 int adyolo_conv3x3_wgrad(const float *x, const float *dy, const float *in_scale, const float *in_shift,
                          float *slabs, float *dw, int N, int H, int W, int Cin, int Cin_real, int Cout,

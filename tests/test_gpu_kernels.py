@@ -57,7 +57,8 @@ def assert_close(got, ref, tol, what):
     (1, 5, 5, 32, 32, False, False, False),      # tile much larger than the image
     (1, 33, 40, 32, 64, True, False, False),     # ragged both ways, TW=32
 ])
-def test_conv3x3_forward(ops, n, h, w, cin, cout, relu, bias, addend):
+@pytest.mark.parametrize("algo", ["direct", "winograd"])
+def test_conv3x3_forward(ops, n, h, w, cin, cout, relu, bias, addend, algo):
     g = torch.Generator().manual_seed(n * 1000 + h * 10 + cin)
     x = torch.randn(n, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
@@ -72,17 +73,19 @@ def test_conv3x3_forward(ops, n, h, w, cin, cout, relu, bias, addend):
     xg = dev(nhwc(x))
     if cin_p != cin:
         xg = dev(F.pad(nhwc(x), (0, cin_p - cin)))
-    wpk, _ = ops.pack_w3x3(dev(wt), cin_p, want_dgrad=False)
+    wpk, _ = ops.pack_w3x3(dev(wt), cin_p, want_dgrad=False, algo=algo)
+    assert (wpk.dim() == 4) == (algo == "winograd" and cin != 7)
     y = ops.conv3x3(xg, wpk, cout, bias=dev(b) if bias else None, addend=dev(nhwc(add)) if addend else None, relu=relu)
     torch.cuda.synchronize()
-    assert_close(nchw(y), ref, 2e-5, "conv3x3 fwd")
+    assert_close(nchw(y), ref, 2e-5, "conv3x3 fwd (%s)" % algo)
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout", [
     (2, 16, 64, 32, 32), (2, 13, 32, 32, 64), (1, 18, 16, 64, 128), (1, 9, 16, 256, 256), (2, 20, 64, 7, 32),
     (3, 40, 64, 32, 32),
 ])
-def test_conv3x3_dgrad_wgrad(ops, n, h, w, cin, cout):
+@pytest.mark.parametrize("algo", ["direct", "winograd"])
+def test_conv3x3_dgrad_wgrad(ops, n, h, w, cin, cout, algo):
     g = torch.Generator().manual_seed(7 + cin + cout)
     x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
     wt = (torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)).requires_grad_(True)
@@ -95,14 +98,15 @@ def test_conv3x3_dgrad_wgrad(ops, n, h, w, cin, cout):
     torch.cuda.synchronize()
     assert_close(dw, wt.grad, 2e-5, "conv3x3 wgrad")
     if cin != 7:
-        _, wpk_d = ops.pack_w3x3(dev(wt.detach()), cin_p, want_dgrad=True)
+        _, wpk_d = ops.pack_w3x3(dev(wt.detach()), cin_p, want_dgrad=True, algo=algo)
         dx = ops.conv3x3(dyg, wpk_d, cin)
         torch.cuda.synchronize()
-        assert_close(nchw(dx), x.grad, 2e-5, "conv3x3 dgrad")
+        assert_close(nchw(dx), x.grad, 2e-5, "conv3x3 dgrad (%s)" % algo)
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout", [(2, 20, 64, 32, 32), (3, 17, 16, 64, 128), (2, 9, 32, 32, 64)])
-def test_conv3x3_fused_affine_mask_stats(ops, n, h, w, cin, cout):
+@pytest.mark.parametrize("algo", ["direct", "winograd"])
+def test_conv3x3_fused_affine_mask_stats(ops, n, h, w, cin, cout, algo):
     """in_affine (producer BN affine applied while staging; padding stays zero), masked addend, epilogue statistics."""
     g = torch.Generator().manual_seed(h * 7 + cin)
     x = torch.randn(n, cin, h, w, generator=g)
@@ -111,7 +115,7 @@ def test_conv3x3_fused_affine_mask_stats(ops, n, h, w, cin, cout):
     add, mask = torch.randn(n, cout, h, w, generator=g), torch.randn(n, cout, h, w, generator=g)
     xa = x * scale[None, :, None, None] + shift[None, :, None, None]
     ref = F.relu(F.conv2d(xa, wt, None, padding=1) + add * (mask > 0))
-    wpk, _ = ops.pack_w3x3(dev(wt), cin, want_dgrad=False)
+    wpk, _ = ops.pack_w3x3(dev(wt), cin, want_dgrad=False, algo=algo)
     y, st = ops.conv3x3(dev(nhwc(x)), wpk, cout, addend=dev(nhwc(add)), addend_mask=dev(nhwc(mask)), relu=True,
                         in_affine=(dev(scale), dev(shift)), want_stats=True)
     ssum, mean, invstd = ops.bn_stats_tiles(st, n, h * w)
@@ -460,7 +464,12 @@ def _params(nb_classes=12):
                              "optim": "Adam", "lr": 1e-3, "weight_decay": 0.0}}
 
 
-def test_wrapper_model_matches_reference_golden(ops):
+@pytest.mark.parametrize("algo,noise_factor", [("direct", 2.0), ("winograd", 4.0)])
+def test_wrapper_model_matches_reference_golden(ops, monkeypatch, algo, noise_factor):
+    """Forward outputs (eval and train mode) hold the 1e-3 bar with either convolution algorithm.  Winograd F(2x2,3x3)
+    carries ~3x the rounding noise of the direct form (its output transform cancels larger intermediates), which shows
+    in the ill-conditioned whole-model gradients: bounded at 4x (direct: 2x) the reference's own fp32 noise."""
+    monkeypatch.setenv("ADYOLO_CONV_ALGO", algo)
     from oracle.filler import fill_module_
     from adyolo_amd.wrapper import WrapperModel
     g = np.load(os.path.join(G, "encoder.npz"))
@@ -490,7 +499,7 @@ def test_wrapper_model_matches_reference_golden(ops):
     # Gradients of the early layers are ill-conditioned in fp32 (34 normalised layers on a 2 x 64 x 64 input): the
     # reference's OWN fp32 gradients deviate from an fp64 evaluation of the same graph by up to 2.6e-3 of their
     # absmax.  So: (a) vs the reference golden at 1e-2, and (b) vs an fp64 evaluation of the oracle at
-    # max(1e-3, 2 x the reference's own fp32 deviation from fp64).
+    # max(1e-3, noise_factor x the reference's own fp32 deviation from fp64).
     from oracle import seresnet as onet
     from oracle.filler import fill_state_dict
     enc64, _ = onet.split_state_dict(fill_state_dict(onet.state_dict_spec()))
@@ -512,12 +521,12 @@ def test_wrapper_model_matches_reference_golden(ops):
             ref_noise = float((ref.double() - t64).abs().max()) / am
             mine = float((got.double() - t64).abs().max()) / am
             worst = max(worst, mine)
-            assert mine <= max(1e-3, 2.0 * ref_noise), "%s: %.2e of absmax vs fp64 (reference fp32: %.2e)" % (key, mine, ref_noise)
+            assert mine <= max(1e-3, noise_factor * ref_noise), "%s: %.2e of absmax vs fp64 (reference fp32: %.2e)" % (key, mine, ref_noise)
             assert_close(got, ref, 1e-2, key + " vs reference golden")
         if key.startswith("stat_") and not key.endswith("num_batches_tracked"):
             assert_close(sd[key[5:]], torch.from_numpy(g[key]), 1e-4, key)
     assert int(sd["bn1.num_batches_tracked"]) == int(g["stat_bn1.num_batches_tracked"])
-    print("worst gradient deviation from fp64: %.2e of absmax" % worst)
+    print("[%s] worst gradient deviation from fp64: %.2e of absmax" % (algo, worst))
 
 
 def test_conformer_pieces_match_torch(ops):

@@ -20,13 +20,14 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--which", default="fwd,wgrad")
     ap.add_argument("--stages", default="1,2,3,4")
+    ap.add_argument("--algo", default=None, help="direct | winograd (default: ADYOLO_CONV_ALGO)")
     ap.add_argument("--fused", action="store_true", help="fwd: in_affine + epilogue stats + masked addend; wgrad: in_affine")
     a = ap.parse_args()
     for st in [int(s) for s in a.stages.split(",")]:
         h, w, cin, cout = SHAPES[st]
         x = torch.randn(a.batch, h, w, cin, device="cuda:0")
         wt = torch.randn(cout, max(cin, 1) if cin != 8 else 7, 3, 3, device="cuda:0") * 0.05
-        wpk, _ = ops.pack_w3x3(wt, cin, want_dgrad=False)
+        wpk, _ = ops.pack_w3x3(wt, cin, want_dgrad=False, algo=a.algo)
         dy = torch.randn(a.batch, h, w, cout, device="cuda:0")
         flops = 2.0 * a.batch * h * w * cout * 9 * cin
         aff = (torch.rand(cin, device="cuda:0") + 0.5, torch.randn(cin, device="cuda:0")) if (a.fused and cin != 8) else None
