@@ -28,6 +28,8 @@ SIGNATURES = {
     "adyolo_wino_pack_w": (I, [P, P, P, I, I, I, P]),
     "adyolo_wino_tiles": (I, [I] * 3),
     "adyolo_wino_fwd": (I, [P] * 12 + [I] * 6 + [P]),
+    "adyolo_wino_wgrad_slabs": (I, [I] * 5),
+    "adyolo_wino_wgrad": (I, [P] * 7 + [I] * 6 + [P]),
     "adyolo_conv3x3_wgrad_slabs": (I, [I] * 5),
     "adyolo_conv3x3_wgrad": (I, [P] * 6 + [I] * 6 + [P]),
     "adyolo_gemm": (I, [P] * 5 + [I] * 10 + [P]),

@@ -31,6 +31,7 @@ struct WinoCfg {
     static constexpr int PBUF = 8 * 32 * CBP;                // [wave][b][tile][CBP]
     static constexpr int LDS_FLOATS = (2 * WPATCH > PBUF) ? 2 * WPATCH : PBUF;
 };
+constexpr int WMAXC = 512;                 // largest Cin of the Winograd forward kernel (affine table in LDS)
 
 __device__ __forceinline__ float4 f4_fma(float4 a, float s, float4 b) {      // b + s * a
     return make_float4(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z), fmaf(s, a.w, b.w));
@@ -48,9 +49,15 @@ __global__ __launch_bounds__(256, 2) void wino_fwd_kernel(
     using Cfg = WinoCfg<NT>;
     constexpr int CB = Cfg::CB, CBP = Cfg::CBP;
     __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float aff[2 * WMAXC];      // producer BatchNorm scale | shift (1 | 0 if none)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform: keeps xi-dependent values in SGPRs
     const int li = lane & 31, lh = lane >> 5;
+    for (int c = tid; c < Cin; c += 256) {
+        aff[c] = in_scale ? in_scale[c] : 1.f;
+        aff[WMAXC + c] = in_scale ? in_shift[c] : 0.f;
+    }
     // block -> (spatial patch, channel block): blocks are dealt round-robin to the 8 XCDs; with xcd_div = 8/ncb
     // an XCD always works on channel block (xcd % ncb), so its L2 keeps one slice of U
     int sp, cb;
@@ -86,73 +93,78 @@ __global__ __launch_bounds__(256, 2) void wino_fwd_kernel(
     const int tr = li >> 3, tc = li & 7;
     const int offa = (((2 * tr + ia) * 2) * WHALF + tc) * WAS + lh * 4;
     const int offb = (((2 * tr + ib) * 2) * WHALF + tc) * WAS + lh * 4;
-    constexpr int J1 = WHALF * WAS, J2 = WAS, J3 = WHALF * WAS + WAS;       // column j of the 4x4 tile
+    constexpr int J1 = WHALF * WAS, J2 = WAS;                                // column j of the 4x4 tile: (j & 1) J1 + (j >> 1) J2
 
     // staging: thread owns 16-byte piece q of pixels spix0 + 32 i
     const int sq = tid & 7, spix0 = tid >> 3;
     constexpr int APT = 6;                                                    // 180 pixels / 32 per pass
     const int nchunks = Cin / WKC, nkg = Cin / 8;
     const size_t ustride_pos = (size_t)(Cout / 32) * nkg * 256;               // floats per transform position
-    const float *ubase = u + ((size_t)(wave * 4) * (Cout / 32) + (size_t)cb * NT) * nkg * 256 + lane * 4;
+    // uniform base + 32-bit lane offset: global_load with an SGPR base, no 64-bit address arithmetic per load
+    const char *ubase = reinterpret_cast<const char *>(u + ((size_t)(wave * 4) * (Cout / 32) + (size_t)cb * NT) * nkg * 256);
+    const unsigned ulane = lane * 16u;
 
-    // staging registers: raw pixels of the next chunk (clamped, unconditional loads so that they are issued back to
-    // back), the affine and the zero padding are applied when they are written to LDS
-    float4 pv[APT];
-    unsigned psrc[APT];                                   // in 16-byte units from x
-    unsigned okmask = 0;
-#pragma unroll
-    for (int i = 0; i < APT; ++i) {
-        const int pix = spix0 + i * 32;
-        const int hy = pix / 18, hx = pix - hy * 18;
-        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-        const bool ok = pix < 180 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        okmask |= (ok ? 1u : 0u) << i;
-        const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-        psrc[i] = (unsigned)(((((size_t)n * H + cy) * W + cx) * Cin) >> 2) + sq;
-    }
-    auto load_patch = [&](int c0) {
-#pragma unroll
-        for (int i = 0; i < APT; ++i) pv[i] = reinterpret_cast<const float4 *>(x + c0)[psrc[i]];
+    // staging registers: raw pixels of half of the next chunk's patch (clamped, unconditional loads so that they are
+    // issued back to back); the affine and the zero padding are applied when they are written to LDS.  Source
+    // offsets, LDS offsets and the in-image flags are RECOMPUTED per call from an opaque zero: hoisted out of the loop
+    // they would cost 13 long-lived registers, which this kernel (256 VGPRs at 2 workgroups per CU) would spill, and a
+    // scratch reload drains the B-operand prefetches (scratch and global loads share vmcnt).
+    float4 pv[APT / 2];
+    const char *xsamp = reinterpret_cast<const char *>(x + (size_t)n * H * W * Cin);
+    auto opaque_zero = [&]() {
+        int z;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+        return z;
     };
-    auto store_patch = [&](float *buf, int c0) {
-        float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in_scale) {
-            isc = *reinterpret_cast<const float4 *>(in_scale + c0 + sq * 4);
-            ish = *reinterpret_cast<const float4 *>(in_shift + c0 + sq * 4);
-        }
+    auto load_patch = [&](int half, int c0) {
+        const int z = opaque_zero();
 #pragma unroll
-        for (int i = 0; i < APT; ++i) {
-            const int pix = spix0 + i * 32;
-            if (pix < 180) {
-                const int hy = pix / 18, hx = pix - hy * 18;
-                const bool ok = (okmask >> i) & 1u;
-                const float4 v = pv[i];
-                const float4 o = ok ? make_float4(fmaf(v.x, isc.x, ish.x), fmaf(v.y, isc.y, ish.y), fmaf(v.z, isc.z, ish.z),
-                                                  fmaf(v.w, isc.w, ish.w))
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4 *>(&buf[((hy * 2 + (hx & 1)) * WHALF + (hx >> 1)) * WAS + sq * 4]) = o;
-            }
+        for (int ii = 0; ii < APT / 2; ++ii) {
+            const int pix = spix0 + (half * (APT / 2) + ii) * 32 + z;
+            const int hy = (pix * 3641) >> 16, hx = pix - hy * 18;            // pix / 18 for pix < 2^12
+            const int cy = min(max(ty0 + hy - 1, 0), H - 1), cx = min(max(tx0 + hx - 1, 0), W - 1);
+            const unsigned off = (unsigned)((cy * W + cx) * Cin + sq * 4 + c0) * 4u;
+            pv[ii] = *reinterpret_cast<const float4 *>(xsamp + off);
+        }
+    };
+    // Branch-free on purpose: a wait for pv[i] inside a divergent branch leaves the load "possibly outstanding" on the
+    // other path, and the compiler then drains the B-operand prefetches at the top of every chunk to protect pv's
+    // registers.  Out-of-image pixels are zeroed with a bit mask; threads without a 6th pixel write into the 16-byte
+    // pad of their first pixel.
+    auto store_patch = [&](int half, float *buf, int c0) {
+        const float4 isc = *reinterpret_cast<const float4 *>(&aff[c0 + sq * 4]);
+        const float4 ish = *reinterpret_cast<const float4 *>(&aff[WMAXC + c0 + sq * 4]);
+        const int z = opaque_zero();
+#pragma unroll
+        for (int ii = 0; ii < APT / 2; ++ii) {
+            const int pix = spix0 + (half * (APT / 2) + ii) * 32 + z;
+            const bool real = pix < 180;
+            const int hy0 = (pix * 3641) >> 16, hx0 = pix - hy0 * 18;
+            const int gy = ty0 + hy0 - 1, gx = tx0 + hx0 - 1;
+            const unsigned m = (real && gy >= 0 && gy < H && gx >= 0 && gx < W) ? 0xffffffffu : 0u;
+            const int pw = real ? pix : spix0;
+            const int hy = (pw * 3641) >> 16, hx = pw - hy * 18;
+            const float4 v = pv[ii];
+            float4 o;
+            o.x = __uint_as_float(__float_as_uint(fmaf(v.x, isc.x, ish.x)) & m);
+            o.y = __uint_as_float(__float_as_uint(fmaf(v.y, isc.y, ish.y)) & m);
+            o.z = __uint_as_float(__float_as_uint(fmaf(v.z, isc.z, ish.z)) & m);
+            o.w = __uint_as_float(__float_as_uint(fmaf(v.w, isc.w, ish.w)) & m);
+            *reinterpret_cast<float4 *>(&buf[((hy * 2 + (hx & 1)) * WHALF + (hx >> 1)) * WAS + (real ? sq * 4 : 32)]) = o;
         }
     };
     float4 r0, r1, r2, r3;
-    float4 da0, da1, da2, da3, db0, db1, db2, db3;      // raw patch pixels of the next 8-channel group
-    auto issue_rows = [&](const float *As, int g) {
-        const float *pa = As + offa + g * 8, *pb = As + offb + g * 8;
+    float4 da0, da1, db0, db1;                          // raw patch pixels in flight (two columns of the 4x4 tile at a time)
+    auto issue_cols = [&](const float *As, int g, int half) {     // columns 2 half, 2 half + 1 of rows ia, ib
+        const float *pa = As + offa + g * 8 + half * J2, *pb = As + offb + g * 8 + half * J2;
         da0 = *reinterpret_cast<const float4 *>(pa);
         da1 = *reinterpret_cast<const float4 *>(pa + J1);
-        da2 = *reinterpret_cast<const float4 *>(pa + J2);
-        da3 = *reinterpret_cast<const float4 *>(pa + J3);
         db0 = *reinterpret_cast<const float4 *>(pb);
         db1 = *reinterpret_cast<const float4 *>(pb + J1);
-        db2 = *reinterpret_cast<const float4 *>(pb + J2);
-        db3 = *reinterpret_cast<const float4 *>(pb + J3);
     };
-    auto combine_rows = [&]() {                         // r[j] = d[ia][j] + sg d[ib][j]
-        r0 = f4_fma(db0, sg, da0);
-        r1 = f4_fma(db1, sg, da1);
-        r2 = f4_fma(db2, sg, da2);
-        r3 = f4_fma(db3, sg, da3);
-    };
+    // r[j] = d[ia][j] + sg d[ib][j]
+    auto combine_lo = [&]() { r0 = f4_fma(db0, sg, da0); r1 = f4_fma(db1, sg, da1); };
+    auto combine_hi = [&]() { r2 = f4_fma(db0, sg, da0); r3 = f4_fma(db1, sg, da1); };
 
     // B fragments of the first 8-channel group
     float4 bq[4][NT];
@@ -160,10 +172,13 @@ __global__ __launch_bounds__(256, 2) void wino_fwd_kernel(
     for (int v = 0; v < 4; ++v)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-            bq[v][nt] = *reinterpret_cast<const float4 *>(ubase + v * ustride_pos + (size_t)nt * nkg * 256);
+            bq[v][nt] = *reinterpret_cast<const float4 *>(ubase + ((unsigned)((v * ustride_pos + (size_t)nt * nkg * 256) * 4) + ulane));
 
-    load_patch(0);
-    store_patch(lds, 0);
+    __syncthreads();                                      // affine table visible
+    load_patch(0, 0);
+    store_patch(0, lds, 0);
+    load_patch(1, 0);
+    store_patch(1, lds, 0);
     __syncthreads();
 
     // The main loop is a hand-placed software pipeline; __builtin_amdgcn_sched_barrier(0) pins it (left alone, the
@@ -173,39 +188,64 @@ __global__ __launch_bounds__(256, 2) void wino_fwd_kernel(
     //   other LDS buffer at its end; the LDS reads of group g+1 are issued under the MFMAs of step (g, 3).
     for (int ch = 0; ch < nchunks; ++ch) {
         const float *As = lds + (ch & 1) * WPATCH;
-        if (ch + 1 < nchunks) load_patch((ch + 1) * WKC);
-        issue_rows(As, 0);
-        combine_rows();
+        const bool more = ch + 1 < nchunks;
+        float *An = lds + ((ch + 1) & 1) * WPATCH;
+        if (more) load_patch(0, (ch + 1) * WKC);
+        issue_cols(As, 0, 0);
+        combine_lo();
+        issue_cols(As, 0, 1);
+        combine_hi();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < WKC / 8; ++g) {
             const int kg = ch * (WKC / 8) + g;
             const int kgn = kg + 1 < nkg ? kg + 1 : kg;
+            const bool nextg = g + 1 < WKC / 8;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const float4 a = v == 0 ? f4_sub(r0, r2) : (v == 1 ? f4_add(r1, r2) : (v == 2 ? f4_sub(r2, r1) : f4_sub(r1, r3)));
-                if (v == 3 && g + 1 < WKC / 8) {        // LDS reads of the next group go out ahead of this step's MFMAs
-                    issue_rows(As, g + 1);
+                // the LDS reads of the next group ride under this group's last step: columns 0,1 ahead of its first
+                // MFMAs, columns 2,3 in the middle (r0..r3 are dead once `a` of step 3 exists)
+                if (v == 3 && nextg) {
+                    issue_cols(As, g + 1, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     acc[v][nt] = mfma32(a.x, bq[v][nt].x, acc[v][nt]);
                     acc[v][nt] = mfma32(a.y, bq[v][nt].y, acc[v][nt]);
+                    if (NT == 1 && v == 3 && nextg) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        combine_lo();
+                        issue_cols(As, g + 1, 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     acc[v][nt] = mfma32(a.z, bq[v][nt].z, acc[v][nt]);
                     acc[v][nt] = mfma32(a.w, bq[v][nt].w, acc[v][nt]);
+                    if (NT == 2 && nt == 0 && v == 3 && nextg) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        combine_lo();
+                        issue_cols(As, g + 1, 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    bq[v][nt] = *reinterpret_cast<const float4 *>(ubase + v * ustride_pos + ((size_t)nt * nkg + kgn) * 256);
-                if (v == 3 && g + 1 < WKC / 8) {
+                    bq[v][nt] = *reinterpret_cast<const float4 *>(
+                        ubase + ((unsigned)((v * ustride_pos + ((size_t)nt * nkg + kgn) * 256) * 4) + ulane));
+                if (v == 3 && nextg) {
                     __builtin_amdgcn_sched_barrier(0);
-                    combine_rows();
+                    combine_hi();
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (g == 1 && more) {                       // mid-chunk: first half lands in the other buffer, second half requested
+                store_patch(0, An, (ch + 1) * WKC);
+                load_patch(1, (ch + 1) * WKC);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (ch + 1 < nchunks) store_patch(lds + ((ch + 1) & 1) * WPATCH, (ch + 1) * WKC);
+        if (more) store_patch(1, An, (ch + 1) * WKC);
         __syncthreads();
     }
 
@@ -378,8 +418,9 @@ extern "C" int adyolo_wino_fwd(const float *x, const float *u, const float *bias
                                float *stats, const float *stat_aux, const float *stat_mean, const float *stat_invstd,
                                int N, int H, int W, int Cin, int Cout, int relu, void *stream) {
     ADYOLO_REQUIRE(x && u && y && N > 0 && H > 0 && W > 0, ADYOLO_EINVAL, "wino_fwd: bad arguments");
-    ADYOLO_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0 && Cin > 0 && Cout > 0, ADYOLO_ENOSUP,
-                   "wino_fwd: Cin=%d and Cout=%d must be multiples of 32", Cin, Cout);
+    ADYOLO_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0 && Cin > 0 && Cout > 0 && Cin <= WMAXC, ADYOLO_ENOSUP,
+                   "wino_fwd: Cin=%d (<= 512) and Cout=%d must be multiples of 32", Cin, Cout);
+    ADYOLO_REQUIRE((size_t)H * W * Cin * 4 < ((size_t)1 << 31), ADYOLO_ENOSUP, "wino_fwd: one sample must stay below 2 GiB");
     ADYOLO_REQUIRE((in_scale == nullptr) == (in_shift == nullptr) && (!addend_mask || addend), ADYOLO_EINVAL,
                    "wino_fwd: in_scale/in_shift come together; addend_mask needs addend");
     ADYOLO_REQUIRE(!stat_aux || (stats && stat_mean && stat_invstd), ADYOLO_EINVAL,
@@ -403,4 +444,303 @@ extern "C" int adyolo_wino_fwd(const float *x, const float *u, const float *bias
                            addend_mask, in_scale, in_shift, y, stats, stat_aux, stat_mean, stat_invstd, H, W, Cin, Cout,
                            tilesW, tilesH, nsp, ncb, xcd_div, relu);
     return check_launch("wino_fwd");
+}
+
+namespace adyolo {
+
+// ================================================================================================
+// K2w weight-gradient, Winograd form (replaces the backward-weights half of nn.Conv2d, resnet.py:16,18):
+//     dw = G^T [ sum over 2x2 output tiles of (B^T d B) (.) (A e A^T) ] G         d: 4x4 input tile, e: 2x2 tile of dy
+// i.e. 16 GEMMs  dU[pos][ci][co] = sum_tiles V[pos][tile][ci] E[pos][tile][co]  with the contraction over tiles --
+// 16 instead of 36 multiplies per tile, channel pair.  One workgroup owns a (32 ci x 32*NT co) block of all 16
+// positions (wave w: transform row xi = w) and walks 16-pixel-wide column strips of the images top to bottom, one
+// tile row (8 tiles = one MFMA k-group) per step.  Both operands need the TILE index along a lane's registers, so the
+// two new x rows and dy rows of a step are fetched with channel-contiguous dword loads (128-byte rows per pixel) and
+// written to LDS transposed, [row][column phase j][channel][8 tiles (+4 pad)]: a ds_read_b128 then yields 4 tiles
+// of one channel, and the 48-byte channel stride keeps every 16-lane group on 16 distinct slots.  x rows live in a
+// 6-slot ring (4 read + 2 being written), dy rows in a 4-slot ring; one barrier per step.  Each workgroup writes one
+// slab of dU; slabs are summed in a fixed order and G^T . G is applied by two small kernels (deterministic).
+constexpr int WG_SEG = 32;                 // tile rows per work item
+constexpr int WG_TS = 12;                  // floats per (row, j, channel): 8 tiles + pad
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
+    const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ in_scale,
+    const float *__restrict__ in_shift, float *__restrict__ slabs, int H, int W, int Cin, int Cout, int tilesW,
+    int tilesH, int nseg, int nitems, int nsplit, int ciBlocks) {
+    constexpr int CB = 32 * NT;
+    constexpr int XROW = 4 * 32 * WG_TS;          // floats per x row slot
+    constexpr int DROW = 2 * CB * WG_TS;          // floats per dy row slot
+    __shared__ __attribute__((aligned(16))) float Xs[6 * XROW];
+    __shared__ __attribute__((aligned(16))) float Dsh[4 * DROW];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int split = blockIdx.x;
+    const int cbk = blockIdx.y / ciBlocks, ibk = blockIdx.y - cbk * ciBlocks;
+    const int co0 = cbk * CB, c0 = ibk * 32;
+
+    f32x16 acc[4][NT];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[v][nt][r] = 0.f;
+
+    // transform row xi = wave.  x side (B^T): r[j] = d[ia][j] + sg d[ib][j];  dy side (A): s[j] = ca e[0][j] + cb e[1][j]
+    const int ia = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int ib = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sg = wave == 1 ? 1.f : -1.f;
+    const float ca = wave == 3 ? 0.f : 1.f;
+    const float cb = wave == 0 ? 0.f : (wave == 1 ? 1.f : -1.f);
+    const int aoff = li * WG_TS + lh * 4;
+
+    // staging roles: x side -- channel xci, row xr (of 2), column phase xj, both tile quads;  dy side -- channel dco,
+    // row dr, column phase dj, DQ tile quads starting at dq0
+    const int xci = tid & 31, xg = tid >> 5, xr = xg >> 2, xj = xg & 3;
+    float xsc = 1.f, xsh = 0.f;
+    if (in_scale) {
+        xsc = in_scale[c0 + xci];
+        xsh = in_shift[c0 + xci];
+    }
+    constexpr int DQ = NT == 2 ? 2 : 1;
+    const int dco = NT == 2 ? (tid & 63) : (tid & 31);
+    const int dg = NT == 2 ? (tid >> 6) : (tid >> 5);
+    const int dr = NT == 2 ? (dg >> 1) : (dg >> 2);
+    const int dj = NT == 2 ? (dg & 1) : ((dg >> 1) & 1);
+    const int dq0 = NT == 2 ? 0 : (dg & 1);
+    const int xmaxoff = ((H * W - 1) * Cin + xci) * 4, dmaxoff = ((H * W - 1) * Cout + dco) * 4;   // own channel of the last pixel, bytes
+    float *xdst = Xs + (xj * 32 + xci) * WG_TS;
+    float *ddst = Dsh + (dj * CB + dco) * WG_TS + dq0 * 4;
+
+    for (int item = split; item < nitems; item += nsplit) {
+        const int seg = item % nseg;
+        const int rest = item / nseg;
+        const int tw = rest % tilesW, n = rest / tilesW;
+        const int tr0 = seg * WG_SEG;
+        const int nsteps = min(WG_SEG, tilesH - tr0);
+        const int tx0 = tw * 16;
+        // uniform sample base + 32-bit byte offsets (clamped into the sample: out-of-image pixels are masked to zero
+        // when they are written to LDS, the loads themselves stay unconditional so that all 16 go out back to back)
+        const char *xn = reinterpret_cast<const char *>(x + (size_t)n * H * W * Cin + c0);
+        const char *dn = reinterpret_cast<const char *>(dy + (size_t)n * H * W * Cout + co0);
+        const int xgx0 = tx0 - 1 + xj, dgx0 = tx0 + dj + 8 * dq0;     // column of tile 0 of quad 0
+        const int xcol = (xgx0 * Cin + xci) * 4, dcol = (dgx0 * Cout + dco) * 4;
+
+        float xraw[8], draw[4 * DQ];
+        auto load_x = [&](int rr0) {              // rows rr0, rr0+1 (relative to image row 2 tr0 - 1)
+            const int gy = 2 * tr0 - 1 + rr0 + xr;
+            const int row = min(max(gy, 0), H - 1) * W * Cin * 4 + xcol;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {         // tile k of the strip: column xgx0 + 2k
+                const int off = min(max(row + k * 2 * Cin * 4, 0), xmaxoff);
+                xraw[k] = *reinterpret_cast<const float *>(xn + (unsigned)off);
+            }
+        };
+        auto store_x = [&](int rr0) {
+            const int gy = 2 * tr0 - 1 + rr0 + xr;
+            const bool rowok = gy >= 0 && gy < H;
+            float t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int gx = xgx0 + 2 * k;
+                t[k] = (rowok && gx >= 0 && gx < W) ? fmaf(xraw[k], xsc, xsh) : 0.f;
+            }
+            float *p = xdst + ((rr0 + xr) % 6) * XROW;
+            *reinterpret_cast<float4 *>(p) = make_float4(t[0], t[1], t[2], t[3]);
+            *reinterpret_cast<float4 *>(p + 4) = make_float4(t[4], t[5], t[6], t[7]);
+        };
+        auto load_d = [&](int rd0) {              // dy rows rd0, rd0+1 (relative to image row 2 tr0)
+            const int gy = 2 * tr0 + rd0 + dr;
+            const int row = min(gy, H - 1) * W * Cout * 4 + dcol;
+#pragma unroll
+            for (int k = 0; k < 4 * DQ; ++k) {
+                const int off = min(row + k * 2 * Cout * 4, dmaxoff);
+                draw[k] = *reinterpret_cast<const float *>(dn + (unsigned)off);
+            }
+        };
+        auto store_d = [&](int rd0) {
+            const int gy = 2 * tr0 + rd0 + dr;
+            const bool rowok = gy < H;
+            float *p = ddst + ((rd0 + dr) & 3) * DROW;
+#pragma unroll
+            for (int q = 0; q < DQ; ++q) {
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = (rowok && dgx0 + 2 * (4 * q + e) < W) ? draw[4 * q + e] : 0.f;
+                *reinterpret_cast<float4 *>(p + q * 4) = make_float4(t[0], t[1], t[2], t[3]);
+            }
+        };
+
+        load_x(0);
+        load_d(0);
+        store_x(0);
+        store_d(0);
+        load_x(2);
+        store_x(2);
+        __syncthreads();
+
+#pragma unroll 1
+        for (int t = 0; t < nsteps; ++t) {
+            const bool more = t + 1 < nsteps;
+            if (more) {
+                load_x(2 * t + 4);
+                load_d(2 * t + 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float *xa = Xs + ((2 * t + ia) % 6) * XROW + aoff;
+            const float *xb = Xs + ((2 * t + ib) % 6) * XROW + aoff;
+            const float *e0 = Dsh + ((2 * t) & 3) * DROW + aoff;
+            const float *e1 = Dsh + ((2 * t + 1) & 3) * DROW + aoff;
+            float4 r0, r1, r2, r3;
+            {
+                const float4 a0 = *reinterpret_cast<const float4 *>(xa);
+                const float4 a1 = *reinterpret_cast<const float4 *>(xa + 32 * WG_TS);
+                const float4 a2 = *reinterpret_cast<const float4 *>(xa + 64 * WG_TS);
+                const float4 a3 = *reinterpret_cast<const float4 *>(xa + 96 * WG_TS);
+                const float4 b0 = *reinterpret_cast<const float4 *>(xb);
+                const float4 b1 = *reinterpret_cast<const float4 *>(xb + 32 * WG_TS);
+                const float4 b2 = *reinterpret_cast<const float4 *>(xb + 64 * WG_TS);
+                const float4 b3 = *reinterpret_cast<const float4 *>(xb + 96 * WG_TS);
+                r0 = f4_fma(b0, sg, a0);
+                r1 = f4_fma(b1, sg, a1);
+                r2 = f4_fma(b2, sg, a2);
+                r3 = f4_fma(b3, sg, a3);
+            }
+            float4 s0[NT], s1[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 p0 = *reinterpret_cast<const float4 *>(e0 + nt * 32 * WG_TS);
+                const float4 p1 = *reinterpret_cast<const float4 *>(e0 + (CB + nt * 32) * WG_TS);
+                const float4 q0 = *reinterpret_cast<const float4 *>(e1 + nt * 32 * WG_TS);
+                const float4 q1 = *reinterpret_cast<const float4 *>(e1 + (CB + nt * 32) * WG_TS);
+                s0[nt] = make_float4(ca * p0.x + cb * q0.x, ca * p0.y + cb * q0.y, ca * p0.z + cb * q0.z, ca * p0.w + cb * q0.w);
+                s1[nt] = make_float4(ca * p1.x + cb * q1.x, ca * p1.y + cb * q1.y, ca * p1.z + cb * q1.z, ca * p1.w + cb * q1.w);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float4 a = v == 0 ? f4_sub(r0, r2) : (v == 1 ? f4_add(r1, r2) : (v == 2 ? f4_sub(r2, r1) : f4_sub(r1, r3)));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float4 b = v == 0 ? s0[nt]
+                                            : (v == 1 ? f4_add(s0[nt], s1[nt])
+                                                      : (v == 2 ? f4_sub(s0[nt], s1[nt])
+                                                                : make_float4(-s1[nt].x, -s1[nt].y, -s1[nt].z, -s1[nt].w)));
+                    acc[v][nt] = mfma32(a.x, b.x, acc[v][nt]);
+                    acc[v][nt] = mfma32(a.y, b.y, acc[v][nt]);
+                    acc[v][nt] = mfma32(a.z, b.z, acc[v][nt]);
+                    acc[v][nt] = mfma32(a.w, b.w, acc[v][nt]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                store_x(2 * t + 4);
+                store_d(2 * t + 2);
+            }
+            __syncthreads();
+        }
+    }
+
+    // one slab per workgroup: [split][pos][Cin][Cout]
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int pos = wave * 4 + v;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mfma_row(r, lane);
+                slabs[(((size_t)split * 16 + pos) * Cin + c0 + m) * Cout + co0 + nt * 32 + li] = acc[v][nt][r];
+            }
+    }
+}
+
+// slabs [nslab][total] -> du [total] (fixed order, partial sums in double)
+__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ du,
+                                                                int nslab, int total) {
+    __shared__ double red[256];
+    const double sum = block_colsum32(slabs, nslab, (size_t)total, blockIdx.x * 32, total, red);
+    const int idx = blockIdx.x * 32 + (threadIdx.x & 31);
+    if ((threadIdx.x >> 5) == 0 && idx < total) du[idx] = (float)sum;
+}
+
+// dw[co][ci][3][3] = G^T dU[.][ci][co] G
+__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float *__restrict__ du, float *__restrict__ dw,
+                                                                int Cin, int Cin_real, int Cout) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // over [Cin][Cout], co fastest
+    if (idx >= Cin * Cout) return;
+    const int co = idx % Cout, ci = idx / Cout;
+    if (ci >= Cin_real) return;
+    float d[4][4];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) d[p >> 2][p & 3] = du[(size_t)p * Cin * Cout + idx];
+    float t[3][4];                                // t = G^T d
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        t[0][v] = d[0][v] + 0.5f * (d[1][v] + d[2][v]);
+        t[1][v] = 0.5f * (d[1][v] - d[2][v]);
+        t[2][v] = 0.5f * (d[1][v] + d[2][v]) + d[3][v];
+    }
+    float *o = dw + ((size_t)co * Cin_real + ci) * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        o[a * 3 + 0] = t[a][0] + 0.5f * (t[a][1] + t[a][2]);
+        o[a * 3 + 1] = 0.5f * (t[a][1] - t[a][2]);
+        o[a * 3 + 2] = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
+    }
+}
+
+static int wino_wgrad_geometry(int N, int H, int W, int Cin, int Cout, int *nt_o, int *nseg_o, int *nitems_o) {
+    const int nt = Cout % 64 == 0 ? 2 : 1;
+    const int tilesH = cdiv(H, 2), tilesW = cdiv(W, 16);
+    const int nseg = cdiv(tilesH, WG_SEG);
+    const int nitems = N * tilesW * nseg;
+    const int pairs = (Cout / (32 * nt)) * (Cin / 32);
+    int nsplit = 512 / pairs;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > nitems) nsplit = nitems;
+    if (nt_o) *nt_o = nt;
+    if (nseg_o) *nseg_o = nseg;
+    if (nitems_o) *nitems_o = nitems;
+    return nsplit;
+}
+
+}  // namespace adyolo
+
+extern "C" int adyolo_wino_wgrad_slabs(int N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 32) return ADYOLO_EINVAL;
+    return adyolo::wino_wgrad_geometry(N, H, W, Cin, Cout, nullptr, nullptr, nullptr);
+}
+
+extern "C" int adyolo_wino_wgrad(const float *x, const float *dy, const float *in_scale, const float *in_shift,
+                                 float *slabs, float *du, float *dw, int N, int H, int W, int Cin, int Cin_real,
+                                 int Cout, void *stream) {
+    ADYOLO_REQUIRE(x && dy && slabs && du && dw && N > 0 && H > 0 && W > 0, ADYOLO_EINVAL, "wino_wgrad: bad arguments");
+    ADYOLO_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0 && Cin > 0 && Cout > 0 && Cin_real <= Cin && Cin_real > 0, ADYOLO_ENOSUP,
+                   "wino_wgrad: unsupported channels Cin=%d Cout=%d", Cin, Cout);
+    ADYOLO_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), ADYOLO_EINVAL, "wino_wgrad: in_scale/in_shift come together");
+    ADYOLO_REQUIRE((size_t)H * W * (Cin > Cout ? Cin : Cout) * 4 < ((size_t)1 << 31), ADYOLO_ENOSUP,
+                   "wino_wgrad: one sample must stay below 2 GiB");
+    hipStream_t st = as_stream(stream);
+    int nt, nseg, nitems;
+    const int nsplit = wino_wgrad_geometry(N, H, W, Cin, Cout, &nt, &nseg, &nitems);
+    const int tilesH = cdiv(H, 2), tilesW = cdiv(W, 16), ciBlocks = Cin / 32;
+    dim3 grid((unsigned)nsplit, (unsigned)((Cout / (32 * nt)) * ciBlocks));
+    if (nt == 2)
+        hipLaunchKernelGGL((wino_wgrad_kernel<2>), grid, dim3(256), 0, st, x, dy, in_scale, in_shift, slabs, H, W, Cin,
+                           Cout, tilesW, tilesH, nseg, nitems, nsplit, ciBlocks);
+    else
+        hipLaunchKernelGGL((wino_wgrad_kernel<1>), grid, dim3(256), 0, st, x, dy, in_scale, in_shift, slabs, H, W, Cin,
+                           Cout, tilesW, tilesH, nseg, nitems, nsplit, ciBlocks);
+    int rc = check_launch("wino_wgrad");
+    if (rc) return rc;
+    const int total = 16 * Cin * Cout;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, slabs, du, nsplit, total);
+    rc = check_launch("wino_wgrad_reduce");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(cdiv(Cin * Cout, 256)), dim3(256), 0, st, du, dw, Cin, Cin_real, Cout);
+    return check_launch("wino_wgrad_finish");
 }

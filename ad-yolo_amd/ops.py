@@ -97,18 +97,30 @@ def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, 
     return (y, stats) if want_stats else y
 
 
-def conv3x3_wgrad(x, dy, cin_real, in_affine=None):
-    """x [N][H][W][Cin], dy [N][H][W][Cout] -> dw [Cout][cin_real][3][3] (x optionally seen through an affine)."""
+def conv3x3_wgrad(x, dy, cin_real, in_affine=None, algo=None):
+    """x [N][H][W][Cin], dy [N][H][W][Cout] -> dw [Cout][cin_real][3][3] (x optionally seen through an affine).
+
+    Winograd form (default) when both channel counts are multiples of 32, else the direct implicit GEMM."""
     _chk(x, dy)
     n, h, w, cin = x.shape
     cout = dy.shape[3]
+    sc, sh = in_affine if in_affine is not None else (None, None)
+    dw = _new(x, cout, cin_real, 3, 3)
+    algo = algo or os.environ.get("ADYOLO_WGRAD_ALGO") or conv_algo()
+    if algo == "winograd" and cin % 32 == 0 and cout % 32 == 0:
+        nslab = _lib.load().adyolo_wino_wgrad_slabs(n, h, w, cin, cout)
+        if nslab <= 0:
+            raise _lib.AdyoloHipError("wino_wgrad_slabs rejected the shape")
+        slabs = _new(x, nslab, 16, cin, cout)
+        du = _new(x, 16, cin, cout)
+        _c("adyolo_wino_wgrad", _p(x), _p(dy), _p(sc), _p(sh), _p(slabs), _p(du), _p(dw), n, h, w, cin, cin_real, cout,
+           _stream())
+        return dw
     nslab = _lib.load().adyolo_conv3x3_wgrad_slabs(n, h, w, cin, cout)
     if nslab <= 0:
         raise _lib.AdyoloHipError("conv3x3_wgrad_slabs rejected the shape")
     cinp = ((cin + 31) // 32) * 32
     slabs = _new(x, nslab, cout, 9, cinp)
-    dw = _new(x, cout, cin_real, 3, 3)
-    sc, sh = in_affine if in_affine is not None else (None, None)
     _c("adyolo_conv3x3_wgrad", _p(x), _p(dy), _p(sc), _p(sh), _p(slabs), _p(dw), n, h, w, cin, cin_real, cout, _stream())
     return dw
 

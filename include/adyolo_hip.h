@@ -95,6 +95,11 @@ int adyolo_wino_fwd(const float *x, const float *u, const float *bias, const flo
                     const float *addend_mask, const float *in_scale, const float *in_shift, float *y, float *stats,
                     const float *stat_aux, const float *stat_mean, const float *stat_invstd, int N, int H, int W,
                     int Cin, int Cout, int relu, void *stream);
+/* Winograd weight-gradient: dw = G^T [ sum_tiles (B^T d B)(.)(A e A^T) ] G.  slabs: [n_slabs][16][Cin][Cout] float32 with
+ * n_slabs = adyolo_wino_wgrad_slabs(...); du: [16][Cin][Cout] scratch; dw: reference layout [Cout][Cin_real][3][3]. */
+int adyolo_wino_wgrad_slabs(int N, int H, int W, int Cin, int Cout);
+int adyolo_wino_wgrad(const float *x, const float *dy, const float *in_scale, const float *in_shift, float *slabs,
+                      float *du, float *dw, int N, int H, int W, int Cin, int Cin_real, int Cout, void *stream);
 int adyolo_conv3x3_wgrad_slabs(int N, int H, int W, int Cin, int Cout);
 int adyolo_conv3x3_wgrad(const float *x, const float *dy, const float *in_scale, const float *in_shift,
                          float *slabs, float *dw, int N, int H, int W, int Cin, int Cin_real, int Cout,

@@ -38,7 +38,7 @@ def main():
                 else:
                     fn = lambda: ops.conv3x3(x, wpk, cout)  # noqa: E731
             else:
-                fn = lambda: ops.conv3x3_wgrad(x, dy, wt.shape[1], in_affine=aff)  # noqa: E731
+                fn = lambda: ops.conv3x3_wgrad(x, dy, wt.shape[1], in_affine=aff, algo=a.algo)  # noqa: E731
             fn()
             torch.cuda.synchronize()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
