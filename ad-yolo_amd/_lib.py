@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libadyolo_hip.so")
+LIB_PATH = os.environ.get("ADYOLO_LIB") or os.path.join(_HERE, "libadyolo_hip.so")   # ADYOLO_LIB: an alternative build (A/B runs)
 
 P = ctypes.c_void_p
 I = ctypes.c_int

@@ -65,9 +65,22 @@ class KernelTimer:
     def summary(self, family):
         recs = self.records.get(family, [])
         if not recs:
-            return 0, 0.0, 0.0
+            return 0, 0.0, 0.0, 0.0
         ms = sum(s.elapsed_time(e) for s, e, _ in recs)
-        return len(recs), ms, float(sum(w for _, _, w in recs))
+        return len(recs), ms, float(sum(w[0] for _, _, w in recs)), float(sum(w[1] for _, _, w in recs))
+
+
+def load_traffic(wino):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic.json: rocprofv3
+    --pmc FETCH_SIZE and --pmc WRITE_SIZE over this same command, corrected as MI355X_MICROARCH.md prescribes);
+    counters cannot be collected inside the timed run, so this is null when no PMC summary matches the algorithm."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return t.get("winograd" if wino else "direct", {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_baseline(seconds_budget=12.0, clip_seconds=20, batch=2):
@@ -148,10 +161,18 @@ def main():
     target = synthetic_targets(B, T // 4, 12, seed=1234 + rank).to(device)
 
     timer = KernelTimer()
-    timer.wrap(ops, "conv3x3", "conv3x3_fwd_dgrad",
-               lambda x, wpk, cout, **kw: 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * cout * 9 * x.shape[3])
-    timer.wrap(ops, "conv3x3_wgrad", "conv3x3_wgrad",
-               lambda x, dy, cin_real, **kw: 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * dy.shape[3] * 9 * x.shape[3])
+    # work = (algorithmic FLOPs of the 3x3 convolution, matrix FLOPs actually issued: 16/36 of that in Winograd form)
+    wino = ops.conv_algo() == "winograd"
+
+    def conv_work(x, wpk, cout, **kw):
+        alg = 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * cout * 9 * x.shape[3]
+        return alg, alg * (16.0 / 36.0 if wpk.dim() == 4 else 1.0)
+
+    def wgrad_work(x, dy, cin_real, **kw):
+        alg = 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * dy.shape[3] * 9 * x.shape[3]
+        return alg, alg * (16.0 / 36.0 if (wino and x.shape[3] % 32 == 0 and dy.shape[3] % 32 == 0) else 1.0)
+    timer.wrap(ops, "conv3x3", "conv3x3_fwd_dgrad", conv_work)
+    timer.wrap(ops, "conv3x3_wgrad", "conv3x3_wgrad", wgrad_work)
     feat_call = trainer.features.__call__
     k1_rec = []
 
@@ -188,8 +209,9 @@ def main():
     loss_val = float(loss)
 
     if rank == 0:
-        n_f, ms_f, fl_f = timer.summary("conv3x3_fwd_dgrad")
-        n_w, ms_w, fl_w = timer.summary("conv3x3_wgrad")
+        n_f, ms_f, fl_f, ex_f = timer.summary("conv3x3_fwd_dgrad")
+        n_w, ms_w, fl_w, ex_w = timer.summary("conv3x3_wgrad")
+        executed = ex_f / (ms_f * 1e-3) / 1e12 if ms_f > 0 else 0.0
         k1_ms = sum(s.elapsed_time(e) for s, e in k1_rec) / max(1, len(k1_rec))
         k1_bytes = FeatureExtractor.algorithmic_bytes(B, n_samples)
         achieved = fl_f / (ms_f * 1e-3) / 1e12 if ms_f > 0 else 0.0
@@ -202,14 +224,20 @@ def main():
             "config": {"workload": args.encoder + " + adyolo loss, synthetic 4ch 24kHz %ds clips, bs=%d per GPU, "
                                    "12 classes, features+fwd+loss+bwd+allreduce+Adam" % (args.seconds, B),
                        "global_batch": world * B, "clip_seconds": args.seconds, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_fwd_kernel (forward + data-gradient launches)",
+            # achieved = ALGORITHMIC 3x3-convolution FLOPs / time; the Winograd kernels issue 16/36 of
+            # them, so frac can exceed 1 -- `mfma_issued` / `mfma_util` is the matrix-pipe utilisation proper
+            "roofline": {"bound": "mfma",
+                         "kernel": ("wino_fwd_kernel (Winograd F(2x2,3x3)" if wino else "conv3x3_fwd_kernel (direct") +
+                                   "; forward + data-gradient launches)",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": load_traffic(wino),
+                         "mfma_issued": round(executed, 2), "mfma_util": round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
                          "launches": n_f, "avg_launch_ms": round(ms_f / max(1, n_f), 4),
                          "share_of_step": round(ms_f / (dt * 1e3), 4)},
             "stages": {
                 "conv3x3_wgrad": {"launches": n_w, "avg_launch_ms": round(ms_w / max(1, n_w), 4),
                                   "achieved_tflops": round(fl_w / (ms_w * 1e-3) / 1e12, 2) if ms_w > 0 else 0.0,
+                                  "mfma_issued_tflops": round(ex_w / (ms_w * 1e-3) / 1e12, 2) if ms_w > 0 else 0.0,
                                   "share_of_step": round(ms_w / (dt * 1e3), 4)},
                 "k1_features": {"ms": round(k1_ms, 4), "algorithmic_GB": round(k1_bytes / 1e9, 4),
                                 "achieved_GBps": round(k1_bytes / (k1_ms * 1e-3) / 1e9, 1) if k1_ms > 0 else 0.0,
