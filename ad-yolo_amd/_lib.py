@@ -41,7 +41,7 @@ SIGNATURES = {
     "adyolo_bn_scale_shift": (I, [P] * 6 + [I, P]),
     "adyolo_affine_nhwc": (I, [P] * 4 + [L, I, P]),
     "adyolo_bn_bwd_reduce": (I, [P] * 7 + [L, I, P]),
-    "adyolo_bn_bwd_tiles": (I, [P, P, P, I, I, P]),
+    "adyolo_bn_bwd_tiles": (I, [P, P, P, P, I, I, P]),
     "adyolo_bn_bwd_apply": (I, [P] * 10 + [L, I, I, P]),
     "adyolo_se_fc_fwd": (I, [P] * 10 + [I, I, I, I, P]),
     "adyolo_se_tail_fwd": (I, [P] * 6 + [I, I, I, P]),

@@ -468,10 +468,27 @@ extern "C" int adyolo_bn_bwd_reduce(const float *dy, const float *x, const float
     return check_launch("bn_bwd_reduce_final");
 }
 
-extern "C" int adyolo_bn_bwd_tiles(const float *tile_stats, float *sdy, float *sdyx, int tiles, int C, void *stream) {
-    ADYOLO_REQUIRE(tile_stats && sdy && sdyx && tiles > 0 && C > 0, ADYOLO_EINVAL, "bn_bwd_tiles: bad arguments");
-    hipLaunchKernelGGL(persample_reduce_kernel, dim3(cdiv(C, 32), 1), dim3(256), 0, as_stream(stream), tile_stats, sdy,
-                       sdyx, 1, tiles, C);
+extern "C" int adyolo_bn_bwd_tiles(const float *tile_stats, float *sdy, float *sdyx, float *partial, int tiles, int C,
+                                   void *stream) {
+    ADYOLO_REQUIRE(tile_stats && sdy && sdyx && partial && tiles > 0 && C > 0, ADYOLO_EINVAL, "bn_bwd_tiles: bad arguments");
+    // two stages (a single stage would leave C/32 workgroups summing tens of thousands of patches each):
+    // groups = the largest divisor of `tiles` <= 256;  partial = [2][256][C] floats
+    int groups = 1;
+    for (int g = 256; g > 1; --g)
+        if (tiles % g == 0) {
+            groups = g;
+            break;
+        }
+    hipStream_t st = as_stream(stream);
+    if (groups == 1) {
+        hipLaunchKernelGGL(persample_reduce_kernel, dim3(cdiv(C, 32), 1), dim3(256), 0, st, tile_stats, sdy, sdyx, 1, tiles, C);
+        return check_launch("bn_bwd_tiles");
+    }
+    hipLaunchKernelGGL(persample_reduce_kernel, dim3(cdiv(C, 32), groups), dim3(256), 0, st, tile_stats, partial,
+                       partial + (size_t)groups * C, groups, tiles / groups, C);
+    int rc = check_launch("bn_bwd_tiles_groups");
+    if (rc) return rc;
+    hipLaunchKernelGGL(persample_reduce_kernel, dim3(cdiv(C, 32), 1), dim3(256), 0, st, partial, sdy, sdyx, 1, groups, C);
     return check_launch("bn_bwd_tiles");
 }
 

@@ -24,12 +24,16 @@ constexpr int WAS = 36;                    // floats per staged pixel (144 B)
 constexpr int WHALF = 10;                  // slots per (row, parity) half row (9 used)
 constexpr int WPATCH = 10 * 2 * WHALF * WAS;   // floats per staged patch (28.8 KB)
 
-template <int NT>
+// ONE = the whole Cin fits one chunk (Cin == 32: stage 1): a single patch buffer, 44 KB of LDS and <= 168 VGPRs, so THREE
+// workgroups per CU cover each other's prologue / epilogue (one 32-channel chunk is only 16 steps of matrix work)
+template <int NT, bool ONE>
 struct WinoCfg {
     static constexpr int CB = 32 * NT;
     static constexpr int CBP = CB + 8;                       // epilogue exchange row (conflict-free b32 writes)
     static constexpr int PBUF = 8 * 32 * CBP;                // [wave][b][tile][CBP]
-    static constexpr int LDS_FLOATS = (2 * WPATCH > PBUF) ? 2 * WPATCH : PBUF;
+    static constexpr int NBUF = ONE ? 1 : 2;
+    static constexpr int LDS_FLOATS = (NBUF * WPATCH > PBUF) ? NBUF * WPATCH : PBUF;
+    static constexpr int WG_PER_CU = (ONE && NT == 1) ? 3 : 2;
 };
 constexpr int WMAXC = 512;                 // largest Cin of the Winograd forward kernel (affine table in LDS)
 
@@ -39,24 +43,25 @@ __device__ __forceinline__ float4 f4_fma(float4 a, float s, float4 b) {      // 
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
-template <int NT>
-__global__ __launch_bounds__(256, 2) void wino_fwd_kernel(
+template <int NT, bool ONE>
+__global__ __launch_bounds__(256, (WinoCfg<NT, ONE>::WG_PER_CU)) void wino_fwd_kernel(
     const float *__restrict__ x, const float *__restrict__ u, const float *__restrict__ bias,
     const float *__restrict__ addend, const float *__restrict__ addend_mask, const float *__restrict__ in_scale,
     const float *__restrict__ in_shift, float *__restrict__ y, float *__restrict__ stats,
     const float *__restrict__ stat_aux, const float *__restrict__ stat_mean, const float *__restrict__ stat_invstd,
     int H, int W, int Cin, int Cout, int tilesW, int tilesH, int nsp, int ncb, int xcd_div, int relu) {
-    using Cfg = WinoCfg<NT>;
+    using Cfg = WinoCfg<NT, ONE>;
     constexpr int CB = Cfg::CB, CBP = Cfg::CBP;
+    constexpr int AFFC = ONE ? WKC : WMAXC;               // channels in the affine table
     __shared__ __attribute__((aligned(16))) float lds[Cfg::LDS_FLOATS];
-    __shared__ __attribute__((aligned(16))) float aff[2 * WMAXC];      // producer BatchNorm scale | shift (1 | 0 if none)
+    __shared__ __attribute__((aligned(16))) float aff[2 * AFFC];      // producer BatchNorm scale | shift (1 | 0 if none)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform: keeps xi-dependent values in SGPRs
     const int li = lane & 31, lh = lane >> 5;
     for (int c = tid; c < Cin; c += 256) {
         aff[c] = in_scale ? in_scale[c] : 1.f;
-        aff[WMAXC + c] = in_scale ? in_shift[c] : 0.f;
+        aff[AFFC + c] = in_scale ? in_shift[c] : 0.f;
     }
     // block -> (spatial patch, channel block): blocks are dealt round-robin to the 8 XCDs; with xcd_div = 8/ncb
     // an XCD always works on channel block (xcd % ncb), so its L2 keeps one slice of U
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void wino_fwd_kernel(
         asm volatile("v_mov_b32 %0, 0" : "=v"(z));
         return z;
     };
-    auto load_patch = [&](int half, int c0) {
+    auto load_patch_into = [&](float4 (&dst)[APT / 2], int half, int c0) {
         const int z = opaque_zero();
 #pragma unroll
         for (int ii = 0; ii < APT / 2; ++ii) {
@@ -124,16 +129,17 @@ __global__ __launch_bounds__(256, 2) void wino_fwd_kernel(
             const int hy = (pix * 3641) >> 16, hx = pix - hy * 18;            // pix / 18 for pix < 2^12
             const int cy = min(max(ty0 + hy - 1, 0), H - 1), cx = min(max(tx0 + hx - 1, 0), W - 1);
             const unsigned off = (unsigned)((cy * W + cx) * Cin + sq * 4 + c0) * 4u;
-            pv[ii] = *reinterpret_cast<const float4 *>(xsamp + off);
+            dst[ii] = *reinterpret_cast<const float4 *>(xsamp + off);
         }
     };
+    auto load_patch = [&](int half, int c0) { load_patch_into(pv, half, c0); };
     // Branch-free on purpose: a wait for pv[i] inside a divergent branch leaves the load "possibly outstanding" on the
     // other path, and the compiler then drains the B-operand prefetches at the top of every chunk to protect pv's
     // registers.  Out-of-image pixels are zeroed with a bit mask; threads without a 6th pixel write into the 16-byte
     // pad of their first pixel.
-    auto store_patch = [&](int half, float *buf, int c0) {
+    auto store_patch_from = [&](const float4 (&src)[APT / 2], int half, float *buf, int c0) {
         const float4 isc = *reinterpret_cast<const float4 *>(&aff[c0 + sq * 4]);
-        const float4 ish = *reinterpret_cast<const float4 *>(&aff[WMAXC + c0 + sq * 4]);
+        const float4 ish = *reinterpret_cast<const float4 *>(&aff[AFFC + c0 + sq * 4]);
         const int z = opaque_zero();
 #pragma unroll
         for (int ii = 0; ii < APT / 2; ++ii) {
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void wino_fwd_kernel(
             const unsigned m = (real && gy >= 0 && gy < H && gx >= 0 && gx < W) ? 0xffffffffu : 0u;
             const int pw = real ? pix : spix0;
             const int hy = (pw * 3641) >> 16, hx = pw - hy * 18;
-            const float4 v = pv[ii];
+            const float4 v = src[ii];
             float4 o;
             o.x = __uint_as_float(__float_as_uint(fmaf(v.x, isc.x, ish.x)) & m);
             o.y = __uint_as_float(__float_as_uint(fmaf(v.y, isc.y, ish.y)) & m);
@@ -153,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void wino_fwd_kernel(
             *reinterpret_cast<float4 *>(&buf[((hy * 2 + (hx & 1)) * WHALF + (hx >> 1)) * WAS + (real ? sq * 4 : 32)]) = o;
         }
     };
+    auto store_patch = [&](int half, float *buf, int c0) { store_patch_from(pv, half, buf, c0); };
     float4 r0, r1, r2, r3;
     float4 da0, da1, db0, db1;                          // raw patch pixels in flight (two columns of the 4x4 tile at a time)
     auto issue_cols = [&](const float *As, int g, int half) {     // columns 2 half, 2 half + 1 of rows ia, ib
@@ -167,18 +174,29 @@ __global__ __launch_bounds__(256, 2) void wino_fwd_kernel(
     auto combine_hi = [&]() { r2 = f4_fma(db0, sg, da0); r3 = f4_fma(db1, sg, da1); };
 
     // B fragments of the first 8-channel group
-    float4 bq[4][NT];
+    // B fragments: PF 8-channel groups in flight.  NT = 2: one group = 4 steps = 2048 matrix cycles ahead (register-bound);
+    // NT = 1: a step is only 4 MFMAs, so two groups keep the same 2048 cycles of cover (one group exposes the L2 latency)
+    constexpr int PF = NT == 1 ? 2 : 1;
+    float4 bq[PF][4][NT];
 #pragma unroll
-    for (int v = 0; v < 4; ++v)
+    for (int p = 0; p < PF; ++p)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            bq[v][nt] = *reinterpret_cast<const float4 *>(ubase + ((unsigned)((v * ustride_pos + (size_t)nt * nkg * 256) * 4) + ulane));
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int kg0 = p < nkg ? p : nkg - 1;
+                bq[p][v][nt] = *reinterpret_cast<const float4 *>(
+                    ubase + ((unsigned)((v * ustride_pos + ((size_t)nt * nkg + kg0) * 256) * 4) + ulane));
+            }
 
     __syncthreads();                                      // affine table visible
-    load_patch(0, 0);
-    store_patch(0, lds, 0);
-    load_patch(1, 0);
-    store_patch(1, lds, 0);
+    {                                                     // first patch: both halves in flight together
+        float4 pw[APT / 2];
+        load_patch_into(pv, 0, 0);
+        load_patch_into(pw, 1, 0);
+        store_patch_from(pv, 0, lds, 0);
+        store_patch_from(pw, 1, lds, 0);
+    }
     __syncthreads();
 
     // The main loop is a hand-placed software pipeline; __builtin_amdgcn_sched_barrier(0) pins it (left alone, the
@@ -187,9 +205,9 @@ __global__ __launch_bounds__(256, 2) void wino_fwd_kernel(
     //   cycles ahead of their use); the next chunk's pixels are requested at the top of the chunk and written to the
     //   other LDS buffer at its end; the LDS reads of group g+1 are issued under the MFMAs of step (g, 3).
     for (int ch = 0; ch < nchunks; ++ch) {
-        const float *As = lds + (ch & 1) * WPATCH;
-        const bool more = ch + 1 < nchunks;
-        float *An = lds + ((ch + 1) & 1) * WPATCH;
+        const float *As = lds + (ONE ? 0 : (ch & 1) * WPATCH);
+        const bool more = !ONE && ch + 1 < nchunks;
+        float *An = lds + (ONE ? 0 : ((ch + 1) & 1) * WPATCH);
         if (more) load_patch(0, (ch + 1) * WKC);
         issue_cols(As, 0, 0);
         combine_lo();
@@ -199,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void wino_fwd_kernel(
 #pragma unroll
         for (int g = 0; g < WKC / 8; ++g) {
             const int kg = ch * (WKC / 8) + g;
-            const int kgn = kg + 1 < nkg ? kg + 1 : kg;
+            const int kgn = kg + PF < nkg ? kg + PF : nkg - 1;
             const bool nextg = g + 1 < WKC / 8;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
@@ -212,16 +230,16 @@ __global__ __launch_bounds__(256, 2) void wino_fwd_kernel(
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    acc[v][nt] = mfma32(a.x, bq[v][nt].x, acc[v][nt]);
-                    acc[v][nt] = mfma32(a.y, bq[v][nt].y, acc[v][nt]);
+                    acc[v][nt] = mfma32(a.x, bq[g % PF][v][nt].x, acc[v][nt]);
+                    acc[v][nt] = mfma32(a.y, bq[g % PF][v][nt].y, acc[v][nt]);
                     if (NT == 1 && v == 3 && nextg) {
                         __builtin_amdgcn_sched_barrier(0);
                         combine_lo();
                         issue_cols(As, g + 1, 1);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    acc[v][nt] = mfma32(a.z, bq[v][nt].z, acc[v][nt]);
-                    acc[v][nt] = mfma32(a.w, bq[v][nt].w, acc[v][nt]);
+                    acc[v][nt] = mfma32(a.z, bq[g % PF][v][nt].z, acc[v][nt]);
+                    acc[v][nt] = mfma32(a.w, bq[g % PF][v][nt].w, acc[v][nt]);
                     if (NT == 2 && nt == 0 && v == 3 && nextg) {
                         __builtin_amdgcn_sched_barrier(0);
                         combine_lo();
@@ -231,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void wino_fwd_kernel(
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    bq[v][nt] = *reinterpret_cast<const float4 *>(
+                    bq[g % PF][v][nt] = *reinterpret_cast<const float4 *>(
                         ubase + ((unsigned)((v * ustride_pos + ((size_t)nt * nkg + kgn) * 256) * 4) + ulane));
                 if (v == 3 && nextg) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -435,14 +453,16 @@ extern "C" int adyolo_wino_fwd(const float *x, const float *u, const float *bias
         blocks = cdiv(nsp, xcd_div) * 8;
     }
     hipStream_t st = as_stream(stream);
-    if (nt == 2)
-        hipLaunchKernelGGL((wino_fwd_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, x, u, bias, addend,
-                           addend_mask, in_scale, in_shift, y, stats, stat_aux, stat_mean, stat_invstd, H, W, Cin, Cout,
-                           tilesW, tilesH, nsp, ncb, xcd_div, relu);
-    else
-        hipLaunchKernelGGL((wino_fwd_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, x, u, bias, addend,
-                           addend_mask, in_scale, in_shift, y, stats, stat_aux, stat_mean, stat_invstd, H, W, Cin, Cout,
-                           tilesW, tilesH, nsp, ncb, xcd_div, relu);
+#define ADYOLO_WINO_FWD(NT_, ONE_)                                                                                  \
+    hipLaunchKernelGGL((wino_fwd_kernel<NT_, ONE_>), dim3((unsigned)blocks), dim3(256), 0, st, x, u, bias, addend,       \
+                       addend_mask, in_scale, in_shift, y, stats, stat_aux, stat_mean, stat_invstd, H, W, Cin, Cout,    \
+                       tilesW, tilesH, nsp, ncb, xcd_div, relu)
+    if (Cin == WKC) {
+        if (nt == 2) ADYOLO_WINO_FWD(2, true); else ADYOLO_WINO_FWD(1, true);
+    } else {
+        if (nt == 2) ADYOLO_WINO_FWD(2, false); else ADYOLO_WINO_FWD(1, false);
+    }
+#undef ADYOLO_WINO_FWD
     return check_launch("wino_fwd");
 }
 

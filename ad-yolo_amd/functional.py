@@ -15,9 +15,10 @@ from . import ops
 FUSE_AFFINE = os.environ.get("ADYOLO_FUSE_AFFINE", "1") != "0"   # BN1 affine applied while conv2 stages its input
 FUSE_STATS = os.environ.get("ADYOLO_FUSE_STATS", "1") != "0"     # BN statistics from the conv epilogue
 FUSE_DR = os.environ.get("ADYOLO_FUSE_DR", "1") != "0"           # identity-shortcut gradient formed in the dgrad epilogue
-# BN1 backward sums from the dgrad(conv2) epilogue: measured 7 % SLOWER per step (the epilogue's extra strided reads of
-# the BatchNorm input are not hidden), so it is off by default and kept only as an A/B switch
-FUSE_BNBWD = os.environ.get("ADYOLO_FUSE_BNBWD", "0") != "0"
+# BN1 backward sums from the dgrad(conv2) epilogue (no separate read pass over dy and the BatchNorm input).  With the direct
+# kernel's scalar epilogue and a one-stage tile reduction this was 7 % slower; with the Winograd kernel's float4 epilogue and
+# the two-stage adyolo_bn_bwd_tiles it measures 173.5 -> 171.0 ms per step, so it is on (ADYOLO_FUSE_BNBWD=0 switches it off)
+FUSE_BNBWD = os.environ.get("ADYOLO_FUSE_BNBWD", "1") != "0"
 
 
 def _c(t):

@@ -249,7 +249,8 @@ def bn_bwd(dy, x, gamma, mean, invstd, relu_mask=False, tile_stats=None):
     rows = x.numel() // c
     sdy, sdyx = _new(x, c), _new(x, c)
     if tile_stats is not None:
-        _c("adyolo_bn_bwd_tiles", _p(tile_stats), _p(sdy), _p(sdyx), tile_stats.shape[1], c, _stream())
+        _c("adyolo_bn_bwd_tiles", _p(tile_stats), _p(sdy), _p(sdyx), _p(_new(tile_stats, 2, 256, c)), tile_stats.shape[1], c,
+           _stream())
     else:
         partial = _new(x, 2 * 1024 * c)
         _c("adyolo_bn_bwd_reduce", _p(dy), _p(x), _p(mean), _p(invstd), _p(sdy), _p(sdyx), _p(partial), rows, c,

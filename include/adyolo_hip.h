@@ -158,7 +158,8 @@ int adyolo_affine_nhwc(const float *x, const float *scale, const float *shift, f
 int adyolo_bn_bwd_reduce(const float *dy, const float *x, const float *mean, const float *invstd,
                          float *sdy, float *sdyx, float *partial, long rows, int C, void *stream);
 /* sdy / sdyx from the per-patch sums a data-gradient convolution wrote (stat_aux mode) */
-int adyolo_bn_bwd_tiles(const float *tile_stats, float *sdy, float *sdyx, int tiles, int C, void *stream);
+int adyolo_bn_bwd_tiles(const float *tile_stats, float *sdy, float *sdyx, float *partial /*[2][256][C]*/, int tiles, int C,
+                        void *stream);
 int adyolo_bn_bwd_apply(const float *dy, const float *x, const float *gamma, const float *mean,
                         const float *invstd, const float *sdy, const float *sdyx, float *dx,
                         float *dgamma, float *dbeta, long rows, int C, int relu_mask, void *stream);
