@@ -473,26 +473,29 @@ namespace adyolo {
 //     dw = G^T [ sum over 2x2 output tiles of (B^T d B) (.) (A e A^T) ] G         d: 4x4 input tile, e: 2x2 tile of dy
 // i.e. 16 GEMMs  dU[pos][ci][co] = sum_tiles V[pos][tile][ci] E[pos][tile][co]  with the contraction over tiles --
 // 16 instead of 36 multiplies per tile, channel pair.  One workgroup owns a (32 ci x 32*NT co) block of all 16
-// positions (wave w: transform row xi = w) and walks 16-pixel-wide column strips of the images top to bottom, one
-// tile row (8 tiles = one MFMA k-group) per step.  Both operands need the TILE index along a lane's registers, so the
-// two new x rows and dy rows of a step are fetched with channel-contiguous dword loads (128-byte rows per pixel) and
-// written to LDS transposed, [row][column phase j][channel][8 tiles (+4 pad)]: a ds_read_b128 then yields 4 tiles
-// of one channel, and the 48-byte channel stride keeps every 16-lane group on 16 distinct slots.  x rows live in a
-// 6-slot ring (4 read + 2 being written), dy rows in a 4-slot ring; one barrier per step.  Each workgroup writes one
-// slab of dU; slabs are summed in a fixed order and G^T . G is applied by two small kernels (deterministic).
-constexpr int WG_SEG = 32;                 // tile rows per work item
-constexpr int WG_TS = 12;                  // floats per (row, j, channel): 8 tiles + pad
+// positions (wave w: transform row xi = w) and walks 16-pixel-wide column strips of the images top to bottom, TWO
+// tile rows (2 x 8 tiles = two MFMA k-groups, 32*NT MFMAs per wave) per step and barrier.  Both operands need the TILE
+// index along a lane's registers, so the four new x rows and dy rows of a step are fetched with channel-contiguous
+// dword loads (SGPR base + 32-bit offsets, all issued before the step's MFMAs, one whole step = 4096 matrix cycles
+// ahead of their use) and written to LDS transposed, [row][column phase j][channel][8 tiles]: a ds_read_b128 then
+// yields 4 tiles of one channel.  The two tile quads of a channel are swapped when (channel >> 3) is odd, which puts
+// every 16-lane ds_read_b128 group on 16 distinct 16-byte slots without padding.  x rows live in a 10-slot ring
+// (6 read + 4 being written), dy rows in an 8-slot ring: 72 KB, two workgroups per CU.  Signs of the dy transform
+// (A = [[1,0],[1,1],[1,-1],[0,-1]]) that are plain negations are folded into one sign flip of the accumulators at the
+// end; waves 0 and 3 read one dy row instead of two.  Each workgroup writes one slab of dU; slabs are summed in a
+// fixed order and G^T . G is applied by two small kernels (deterministic).
 
 template <int NT>
 __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
     const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ in_scale,
     const float *__restrict__ in_shift, float *__restrict__ slabs, int H, int W, int Cin, int Cout, int tilesW,
-    int tilesH, int nseg, int nitems, int nsplit, int ciBlocks) {
+    int tilesH, int nseg, int seg_rows, int nitems, int nsplit, int ciBlocks) {
     constexpr int CB = 32 * NT;
-    constexpr int XROW = 4 * 32 * WG_TS;          // floats per x row slot
-    constexpr int DROW = 2 * CB * WG_TS;          // floats per dy row slot
-    __shared__ __attribute__((aligned(16))) float Xs[6 * XROW];
-    __shared__ __attribute__((aligned(16))) float Dsh[4 * DROW];
+    constexpr int XROW = 4 * 32 * 8;              // floats per x row slot
+    constexpr int DROW = 2 * CB * 8;              // floats per dy row slot
+    constexpr int XSLOTS = 10, DSLOTS = 8;
+    __shared__ __attribute__((aligned(16))) float Xs[XSLOTS * XROW];
+    __shared__ __attribute__((aligned(16))) float Dsh[DSLOTS * DROW];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -509,135 +512,179 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[v][nt][r] = 0.f;
 
-    // transform row xi = wave.  x side (B^T): r[j] = d[ia][j] + sg d[ib][j];  dy side (A): s[j] = ca e[0][j] + cb e[1][j]
+    // transform row xi = wave.  x side (B^T): r[j] = d[ia][j] + sg d[ib][j]
     const int ia = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
     const int ib = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float sg = wave == 1 ? 1.f : -1.f;
-    const float ca = wave == 3 ? 0.f : 1.f;
-    const float cb = wave == 0 ? 0.f : (wave == 1 ? 1.f : -1.f);
-    const int aoff = li * WG_TS + lh * 4;
+    const int aoff = li * 8 + ((lh ^ ((li >> 3) & 1)) << 2);        // channel li, tile quad lh (swizzled)
 
-    // staging roles: x side -- channel xci, row xr (of 2), column phase xj, both tile quads;  dy side -- channel dco,
-    // row dr, column phase dj, DQ tile quads starting at dq0
+    // staging roles.  x: channel xci, column phase xj, rows xr and xr + 2 of the step's four, all 8 tiles.
+    // dy: channel dco, column phase dj, rows dr and dr + 2, DK tiles starting at tile dk0
     const int xci = tid & 31, xg = tid >> 5, xr = xg >> 2, xj = xg & 3;
     float xsc = 1.f, xsh = 0.f;
     if (in_scale) {
         xsc = in_scale[c0 + xci];
         xsh = in_shift[c0 + xci];
     }
-    constexpr int DQ = NT == 2 ? 2 : 1;
+    constexpr int DK = NT == 2 ? 8 : 4;
     const int dco = NT == 2 ? (tid & 63) : (tid & 31);
     const int dg = NT == 2 ? (tid >> 6) : (tid >> 5);
     const int dr = NT == 2 ? (dg >> 1) : (dg >> 2);
     const int dj = NT == 2 ? (dg & 1) : ((dg >> 1) & 1);
-    const int dq0 = NT == 2 ? 0 : (dg & 1);
-    const int xmaxoff = ((H * W - 1) * Cin + xci) * 4, dmaxoff = ((H * W - 1) * Cout + dco) * 4;   // own channel of the last pixel, bytes
-    float *xdst = Xs + (xj * 32 + xci) * WG_TS;
-    float *ddst = Dsh + (dj * CB + dco) * WG_TS + dq0 * 4;
+    const int dk0 = NT == 2 ? 0 : 4 * (dg & 1);
+    const int xsw = (xci >> 3) & 1, dsw = (dco >> 3) & 1;
+    float *xdst = Xs + (xj * 32 + xci) * 8;
+    float *ddst = Dsh + (dj * CB + dco) * 8;
+    const bool ragged = (W & 15) != 0 || (H & 1) != 0;              // uniform: the general masking path
+    const int xrowb = W * Cin * 4, drowb = W * Cout * 4, xpixb = Cin * 4, dpixb = Cout * 4;
 
     for (int item = split; item < nitems; item += nsplit) {
         const int seg = item % nseg;
         const int rest = item / nseg;
         const int tw = rest % tilesW, n = rest / tilesW;
-        const int tr0 = seg * WG_SEG;
-        const int nsteps = min(WG_SEG, tilesH - tr0);
+        const int tr0 = seg * seg_rows;
+        const int nrows = min(seg_rows, tilesH - tr0);
+        const int nbig = (nrows + 1) >> 1;
         const int tx0 = tw * 16;
-        // uniform sample base + 32-bit byte offsets (clamped into the sample: out-of-image pixels are masked to zero
-        // when they are written to LDS, the loads themselves stay unconditional so that all 16 go out back to back)
-        const char *xn = reinterpret_cast<const char *>(x + (size_t)n * H * W * Cin + c0);
+        const char *xn = reinterpret_cast<const char *>(x + (size_t)n * H * W * Cin + c0);        // uniform bases
         const char *dn = reinterpret_cast<const char *>(dy + (size_t)n * H * W * Cout + co0);
-        const int xgx0 = tx0 - 1 + xj, dgx0 = tx0 + dj + 8 * dq0;     // column of tile 0 of quad 0
-        const int xcol = (xgx0 * Cin + xci) * 4, dcol = (dgx0 * Cout + dco) * 4;
+        const int xgx0 = tx0 - 1 + xj, dgx0 = tx0 + dj + 2 * dk0;     // image column of tile 0 of this thread's run
 
-        float xraw[8], draw[4 * DQ];
-        auto load_x = [&](int rr0) {              // rows rr0, rr0+1 (relative to image row 2 tr0 - 1)
-            const int gy = 2 * tr0 - 1 + rr0 + xr;
-            const int row = min(max(gy, 0), H - 1) * W * Cin * 4 + xcol;
+        float xraw[2][8], draw[2][DK];            // (never live together: see the step loop)
+        // (column offsets are recomputed per call from an opaque zero: hoisted out of the step loop they would hold
+        //  16 more registers and this kernel would spill)
+        auto opaque_zero = [&]() {
+            int z;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+            return z;
+        };
+        // rows rr0 + xr and rr0 + xr + 2 (relative to image row 2 tr0 - 1); offsets clamped into the sample, the
+        // loads are unconditional
+        auto load_x_into = [&](float (&xr_)[2][8], int rr0) {
+            const int gxz = xgx0 + opaque_zero();
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {         // tile k of the strip: column xgx0 + 2k
-                const int off = min(max(row + k * 2 * Cin * 4, 0), xmaxoff);
-                xraw[k] = *reinterpret_cast<const float *>(xn + (unsigned)off);
+            for (int p = 0; p < 2; ++p) {
+                const int gy = 2 * tr0 - 1 + rr0 + xr + 2 * p;
+                const int row = min(max(gy, 0), H - 1) * xrowb;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int gx = min(max(gxz + 2 * k, 0), W - 1);
+                    xr_[p][k] = *reinterpret_cast<const float *>(xn + (unsigned)(row + gx * xpixb + xci * 4));
+                }
             }
         };
-        auto store_x = [&](int rr0) {
-            const int gy = 2 * tr0 - 1 + rr0 + xr;
-            const bool rowok = gy >= 0 && gy < H;
-            float t[8];
+        auto store_x_from = [&](const float (&xr_)[2][8], int rr0) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int gx = xgx0 + 2 * k;
-                t[k] = (rowok && gx >= 0 && gx < W) ? fmaf(xraw[k], xsc, xsh) : 0.f;
+            for (int p = 0; p < 2; ++p) {
+                const int rr = rr0 + xr + 2 * p;
+                const int gy = 2 * tr0 - 1 + rr;
+                const bool rowok = gy >= 0 && gy < H;
+                float t[8];
+                if (!ragged) {          // only the two outer tiles of a strip can leave the image
+                    const float sc = rowok ? xsc : 0.f, sh = rowok ? xsh : 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t[k] = fmaf(xr_[p][k], sc, sh);
+                    t[0] = xgx0 >= 0 ? t[0] : 0.f;
+                    t[7] = xgx0 + 14 < W ? t[7] : 0.f;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int gx = xgx0 + 2 * k;
+                        t[k] = (rowok && gx >= 0 && gx < W) ? fmaf(xr_[p][k], xsc, xsh) : 0.f;
+                    }
+                }
+                float *q = xdst + (rr % XSLOTS) * XROW;
+                *reinterpret_cast<float4 *>(q + (xsw << 2)) = make_float4(t[0], t[1], t[2], t[3]);
+                *reinterpret_cast<float4 *>(q + ((xsw ^ 1) << 2)) = make_float4(t[4], t[5], t[6], t[7]);
             }
-            float *p = xdst + ((rr0 + xr) % 6) * XROW;
-            *reinterpret_cast<float4 *>(p) = make_float4(t[0], t[1], t[2], t[3]);
-            *reinterpret_cast<float4 *>(p + 4) = make_float4(t[4], t[5], t[6], t[7]);
         };
-        auto load_d = [&](int rd0) {              // dy rows rd0, rd0+1 (relative to image row 2 tr0)
-            const int gy = 2 * tr0 + rd0 + dr;
-            const int row = min(gy, H - 1) * W * Cout * 4 + dcol;
+        auto load_d = [&](int rd0) {              // dy rows rd0 + dr, rd0 + dr + 2 (relative to image row 2 tr0)
+            const int gxz = dgx0 + opaque_zero();
 #pragma unroll
-            for (int k = 0; k < 4 * DQ; ++k) {
-                const int off = min(row + k * 2 * Cout * 4, dmaxoff);
-                draw[k] = *reinterpret_cast<const float *>(dn + (unsigned)off);
+            for (int p = 0; p < 2; ++p) {
+                const int gy = 2 * tr0 + rd0 + dr + 2 * p;
+                const int row = min(gy, H - 1) * drowb;
+#pragma unroll
+                for (int k = 0; k < DK; ++k) {
+                    const int gx = min(gxz + 2 * k, W - 1);
+                    draw[p][k] = *reinterpret_cast<const float *>(dn + (unsigned)(row + gx * dpixb + dco * 4));
+                }
             }
         };
         auto store_d = [&](int rd0) {
-            const int gy = 2 * tr0 + rd0 + dr;
-            const bool rowok = gy < H;
-            float *p = ddst + ((rd0 + dr) & 3) * DROW;
 #pragma unroll
-            for (int q = 0; q < DQ; ++q) {
-                float t[4];
+            for (int p = 0; p < 2; ++p) {
+                const int rd = rd0 + dr + 2 * p;
+                float t[DK];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) t[e] = (rowok && dgx0 + 2 * (4 * q + e) < W) ? draw[4 * q + e] : 0.f;
-                *reinterpret_cast<float4 *>(p + q * 4) = make_float4(t[0], t[1], t[2], t[3]);
+                for (int k = 0; k < DK; ++k) t[k] = draw[p][k];
+                if (ragged) {
+                    const bool rowok = 2 * tr0 + rd < H;
+#pragma unroll
+                    for (int k = 0; k < DK; ++k) t[k] = (rowok && dgx0 + 2 * k < W) ? t[k] : 0.f;
+                }
+                float *q = ddst + (rd & (DSLOTS - 1)) * DROW;
+                if (NT == 2) {
+                    *reinterpret_cast<float4 *>(q + (dsw << 2)) = make_float4(t[0], t[1], t[2], t[3]);
+                    *reinterpret_cast<float4 *>(q + ((dsw ^ 1) << 2)) = make_float4(t[DK - 4], t[DK - 3], t[DK - 2], t[DK - 1]);
+                } else {
+                    *reinterpret_cast<float4 *>(q + ((((dk0 >> 2) ^ dsw) & 1) << 2)) = make_float4(t[0], t[1], t[2], t[3]);
+                }
             }
         };
 
-        load_x(0);
-        load_d(0);
-        store_x(0);
-        store_d(0);
-        load_x(2);
-        store_x(2);
+        auto load_x = [&](int rr0) { load_x_into(xraw, rr0); };
+        auto store_x = [&](int rr0) { store_x_from(xraw, rr0); };
+        {                                           // prologue: x rows 0..7 and dy rows 0..3, one exposed latency
+            float xraw2[2][8];
+            load_x_into(xraw, 0);
+            load_d(0);
+            load_x_into(xraw2, 4);
+            store_x_from(xraw, 0);
+            store_d(0);
+            store_x_from(xraw2, 4);
+        }
         __syncthreads();
 
-#pragma unroll 1
-        for (int t = 0; t < nsteps; ++t) {
-            const bool more = t + 1 < nsteps;
-            if (more) {
-                load_x(2 * t + 4);
-                load_d(2 * t + 2);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const float *xa = Xs + ((2 * t + ia) % 6) * XROW + aoff;
-            const float *xb = Xs + ((2 * t + ib) % 6) * XROW + aoff;
-            const float *e0 = Dsh + ((2 * t) & 3) * DROW + aoff;
-            const float *e1 = Dsh + ((2 * t + 1) & 3) * DROW + aoff;
+        auto substep = [&](int rb) {                  // one tile row: x rows rb .. rb + 3, dy rows rb, rb + 1 of the rings
+            const float *xa = Xs + ((rb + ia) % XSLOTS) * XROW + aoff;
+            const float *xb = Xs + ((rb + ib) % XSLOTS) * XROW + aoff;
+            const float *e0 = Dsh + (rb & (DSLOTS - 1)) * DROW + aoff;
+            const float *e1 = Dsh + ((rb + 1) & (DSLOTS - 1)) * DROW + aoff;
             float4 r0, r1, r2, r3;
             {
                 const float4 a0 = *reinterpret_cast<const float4 *>(xa);
-                const float4 a1 = *reinterpret_cast<const float4 *>(xa + 32 * WG_TS);
-                const float4 a2 = *reinterpret_cast<const float4 *>(xa + 64 * WG_TS);
-                const float4 a3 = *reinterpret_cast<const float4 *>(xa + 96 * WG_TS);
+                const float4 a1 = *reinterpret_cast<const float4 *>(xa + 32 * 8);
+                const float4 a2 = *reinterpret_cast<const float4 *>(xa + 64 * 8);
+                const float4 a3 = *reinterpret_cast<const float4 *>(xa + 96 * 8);
                 const float4 b0 = *reinterpret_cast<const float4 *>(xb);
-                const float4 b1 = *reinterpret_cast<const float4 *>(xb + 32 * WG_TS);
-                const float4 b2 = *reinterpret_cast<const float4 *>(xb + 64 * WG_TS);
-                const float4 b3 = *reinterpret_cast<const float4 *>(xb + 96 * WG_TS);
+                const float4 b1 = *reinterpret_cast<const float4 *>(xb + 32 * 8);
+                const float4 b2 = *reinterpret_cast<const float4 *>(xb + 64 * 8);
+                const float4 b3 = *reinterpret_cast<const float4 *>(xb + 96 * 8);
                 r0 = f4_fma(b0, sg, a0);
                 r1 = f4_fma(b1, sg, a1);
                 r2 = f4_fma(b2, sg, a2);
                 r3 = f4_fma(b3, sg, a3);
             }
+            // dy side, row xi of A e A^T up to sign: wave 0: e0, wave 1: e0 + e1, wave 2: e0 - e1, wave 3: e1 (negated
+            // at the end); columns: nu 0: s0, 1: s0 + s1, 2: s0 - s1, 3: s1 (negated at the end)
             float4 s0[NT], s1[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const float4 p0 = *reinterpret_cast<const float4 *>(e0 + nt * 32 * WG_TS);
-                const float4 p1 = *reinterpret_cast<const float4 *>(e0 + (CB + nt * 32) * WG_TS);
-                const float4 q0 = *reinterpret_cast<const float4 *>(e1 + nt * 32 * WG_TS);
-                const float4 q1 = *reinterpret_cast<const float4 *>(e1 + (CB + nt * 32) * WG_TS);
-                s0[nt] = make_float4(ca * p0.x + cb * q0.x, ca * p0.y + cb * q0.y, ca * p0.z + cb * q0.z, ca * p0.w + cb * q0.w);
-                s1[nt] = make_float4(ca * p1.x + cb * q1.x, ca * p1.y + cb * q1.y, ca * p1.z + cb * q1.z, ca * p1.w + cb * q1.w);
+                if (wave == 0) {
+                    s0[nt] = *reinterpret_cast<const float4 *>(e0 + nt * 32 * 8);
+                    s1[nt] = *reinterpret_cast<const float4 *>(e0 + (CB + nt * 32) * 8);
+                } else if (wave == 3) {
+                    s0[nt] = *reinterpret_cast<const float4 *>(e1 + nt * 32 * 8);
+                    s1[nt] = *reinterpret_cast<const float4 *>(e1 + (CB + nt * 32) * 8);
+                } else {
+                    const float4 p0 = *reinterpret_cast<const float4 *>(e0 + nt * 32 * 8);
+                    const float4 p1 = *reinterpret_cast<const float4 *>(e0 + (CB + nt * 32) * 8);
+                    const float4 q0 = *reinterpret_cast<const float4 *>(e1 + nt * 32 * 8);
+                    const float4 q1 = *reinterpret_cast<const float4 *>(e1 + (CB + nt * 32) * 8);
+                    s0[nt] = f4_fma(q0, sg, p0);          // sg = +1 for wave 1, -1 for wave 2
+                    s1[nt] = f4_fma(q1, sg, p1);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -645,10 +692,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
                 const float4 a = v == 0 ? f4_sub(r0, r2) : (v == 1 ? f4_add(r1, r2) : (v == 2 ? f4_sub(r2, r1) : f4_sub(r1, r3)));
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const float4 b = v == 0 ? s0[nt]
-                                            : (v == 1 ? f4_add(s0[nt], s1[nt])
-                                                      : (v == 2 ? f4_sub(s0[nt], s1[nt])
-                                                                : make_float4(-s1[nt].x, -s1[nt].y, -s1[nt].z, -s1[nt].w)));
+                    const float4 b = v == 0 ? s0[nt] : (v == 1 ? f4_add(s0[nt], s1[nt]) : (v == 2 ? f4_sub(s0[nt], s1[nt]) : s1[nt]));
                     acc[v][nt] = mfma32(a.x, b.x, acc[v][nt]);
                     acc[v][nt] = mfma32(a.y, b.y, acc[v][nt]);
                     acc[v][nt] = mfma32(a.z, b.z, acc[v][nt]);
@@ -656,24 +700,38 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (more) {
-                store_x(2 * t + 4);
-                store_d(2 * t + 2);
-            }
+        };
+
+        // step T: dy rows of step T+1 are requested at the top and land in LDS after the first tile row; the x rows of
+        // step T+1 are requested then and land after the second (16 prefetch registers at a time instead of 32)
+        // (the prefetch is unconditional -- on the last step it fetches clamped rows nobody reads: a load/store pair
+        //  under `if (more)` leaves the loads "possibly outstanding" in the compiler's vmcnt scoreboard at the loop
+        //  header, and it then drains every prefetch right after issuing it)
+#pragma unroll 1
+        for (int T = 0; T < nbig; ++T) {
+            load_d(4 * T + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            substep(4 * T);
+            store_d(4 * T + 4);
+            load_x(4 * T + 6);
+            __builtin_amdgcn_sched_barrier(0);
+            if (2 * T + 1 < nrows) substep(4 * T + 2);
+            store_x(4 * T + 6);
             __syncthreads();
         }
     }
 
-    // one slab per workgroup: [split][pos][Cin][Cout]
+    // one slab per workgroup: [split][pos][Cin][Cout];  folded signs: wave 3 and nu = 3 each negate
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int pos = wave * 4 + v;
+        const float sgn = ((wave == 3) != (v == 3)) ? -1.f : 1.f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mfma_row(r, lane);
-                slabs[(((size_t)split * 16 + pos) * Cin + c0 + m) * Cout + co0 + nt * 32 + li] = acc[v][nt][r];
+                slabs[(((size_t)split * 16 + pos) * Cin + c0 + m) * Cout + co0 + nt * 32 + li] = sgn * acc[v][nt][r];
             }
     }
 }
@@ -713,17 +771,28 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float *__r
     }
 }
 
-static int wino_wgrad_geometry(int N, int H, int W, int Cin, int Cout, int *nt_o, int *nseg_o, int *nitems_o) {
+// Work items = (sample, 16-pixel column strip, segment of seg_rows tile rows).  Every item pays one exposed prologue
+// (8 x rows + 4 dy rows), so segments are as long as they can be while each of the ~512 resident workgroups still
+// gets about four items (measured: 32-row segments 3.53 ms, 64-row 3.31 ms at stage 4).
+static int wino_wgrad_geometry(int N, int H, int W, int Cin, int Cout, int *nt_o, int *nseg_o, int *seg_rows_o,
+                               int *nitems_o) {
     const int nt = Cout % 64 == 0 ? 2 : 1;
     const int tilesH = cdiv(H, 2), tilesW = cdiv(W, 16);
-    const int nseg = cdiv(tilesH, WG_SEG);
-    const int nitems = N * tilesW * nseg;
     const int pairs = (Cout / (32 * nt)) * (Cin / 32);
     int nsplit = 512 / pairs;
     if (nsplit < 1) nsplit = 1;
+    const int strips = N * tilesW;
+    int nseg = cdiv(4 * nsplit, strips);                  // segments per strip for ~4 items per workgroup
+    if (nseg < 1) nseg = 1;
+    int seg_rows = cdiv(tilesH, nseg);
+    seg_rows += seg_rows & 1;                             // even: a step is two tile rows
+    if (seg_rows < 16) seg_rows = 16;
+    nseg = cdiv(tilesH, seg_rows);
+    const int nitems = strips * nseg;
     if (nsplit > nitems) nsplit = nitems;
     if (nt_o) *nt_o = nt;
     if (nseg_o) *nseg_o = nseg;
+    if (seg_rows_o) *seg_rows_o = seg_rows;
     if (nitems_o) *nitems_o = nitems;
     return nsplit;
 }
@@ -732,7 +801,7 @@ static int wino_wgrad_geometry(int N, int H, int W, int Cin, int Cout, int *nt_o
 
 extern "C" int adyolo_wino_wgrad_slabs(int N, int H, int W, int Cin, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 32) return ADYOLO_EINVAL;
-    return adyolo::wino_wgrad_geometry(N, H, W, Cin, Cout, nullptr, nullptr, nullptr);
+    return adyolo::wino_wgrad_geometry(N, H, W, Cin, Cout, nullptr, nullptr, nullptr, nullptr);
 }
 
 extern "C" int adyolo_wino_wgrad(const float *x, const float *dy, const float *in_scale, const float *in_shift,
@@ -745,16 +814,16 @@ extern "C" int adyolo_wino_wgrad(const float *x, const float *dy, const float *i
     ADYOLO_REQUIRE((size_t)H * W * (Cin > Cout ? Cin : Cout) * 4 < ((size_t)1 << 31), ADYOLO_ENOSUP,
                    "wino_wgrad: one sample must stay below 2 GiB");
     hipStream_t st = as_stream(stream);
-    int nt, nseg, nitems;
-    const int nsplit = wino_wgrad_geometry(N, H, W, Cin, Cout, &nt, &nseg, &nitems);
+    int nt, nseg, seg_rows, nitems;
+    const int nsplit = wino_wgrad_geometry(N, H, W, Cin, Cout, &nt, &nseg, &seg_rows, &nitems);
     const int tilesH = cdiv(H, 2), tilesW = cdiv(W, 16), ciBlocks = Cin / 32;
     dim3 grid((unsigned)nsplit, (unsigned)((Cout / (32 * nt)) * ciBlocks));
     if (nt == 2)
         hipLaunchKernelGGL((wino_wgrad_kernel<2>), grid, dim3(256), 0, st, x, dy, in_scale, in_shift, slabs, H, W, Cin,
-                           Cout, tilesW, tilesH, nseg, nitems, nsplit, ciBlocks);
+                           Cout, tilesW, tilesH, nseg, seg_rows, nitems, nsplit, ciBlocks);
     else
         hipLaunchKernelGGL((wino_wgrad_kernel<1>), grid, dim3(256), 0, st, x, dy, in_scale, in_shift, slabs, H, W, Cin,
-                           Cout, tilesW, tilesH, nseg, nitems, nsplit, ciBlocks);
+                           Cout, tilesW, tilesH, nseg, seg_rows, nitems, nsplit, ciBlocks);
     int rc = check_launch("wino_wgrad");
     if (rc) return rc;
     const int total = 16 * Cin * Cout;
