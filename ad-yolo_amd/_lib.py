@@ -89,6 +89,9 @@ SIGNATURES = {
     "adyolo_ln_fwd": (I, [P] * 4 + [L, I, F, P]),
     "adyolo_ln_bwd": (I, [P] * 7 + [L, I, F, P]),
     "adyolo_foa_rotate": (I, [P, P, P, I, L, P]),
+    "adyolo_pcm16_to_f32": (I, [P, P, L, P]),
+    "adyolo_mask_ranges": (I, [P, P, I, I, I, I, P]),
+    "adyolo_colstats": (I, [P, P, P, L, I, P]),
     "adyolo_adam_step": (I, [P] * 4 + [L, F, F, F, F, F, I, F, P]),
 }
 

@@ -64,3 +64,48 @@ class RotationAug:
         if comb_no is None:
             comb_no = int(random.uniform(0, 16))
         return rotate_audio(audio.view(1, -1, 4), [comb_no]).view_as(audio), rotate_labels(label, comb_no)
+
+
+class SpecAug:
+    """Feature-wise spec-augmentation (reference src/utils/augmentations.py:6-33) on the GPU feature tensor.
+
+    The reference applies torchaudio 0.10's ``TimeMasking`` / ``FrequencyMasking`` to a (C, T, F) tensor, i.e. (quirk)
+    its "time" mask (axis 2) zeroes MEL BINS and its "frequency" mask (axis 1) zeroes FRAMES; both with probability
+    ``spec_augment_thresh`` per sample, identity when ``spec_augment`` is false (the default) or on validation data.
+    ``mask_along_axis``: value = U(0,1) * mask_param, start = U(0,1) * (size - value), mask [int(start), int(start+value)).
+    torchaudio is not installed in this image, so the draw order is restated from its published 0.10 source (parity of the
+    random stream unpinned); the masking itself is exact and tested against NumPy slicing.
+    ``augment(feat)``: feat (B, T, 64, 8) float32 channels-last on the GPU, masked in place per sample.
+    """
+
+    def __init__(self, params: dict, is_valid: bool):
+        a = params.get("aug_config", {})
+        self.apply_augment = bool(a.get("spec_augment", False)) and not is_valid
+        self.thresh = a.get("spec_augment_thresh", 0.5)
+        self.time_mask_param = a.get("spec_augment_time_mask_param", 0)
+        self.freq_mask_param = a.get("spec_augment_freq_mask_param", 0)
+
+    @staticmethod
+    def _range(mask_param, size):
+        value = random.random() * mask_param
+        start = random.random() * (size - value)
+        return int(start), int(start + value)
+
+    def draw(self, batch, t, f):
+        """-> int32 (batch, 4) host tensor {t0, t1, f0, f1}; empty ranges where a mask is not applied."""
+        rng = torch.zeros((batch, 4), dtype=torch.int32)
+        for b in range(batch):
+            if random.random() <= self.thresh:                       # reference "time_masking": last axis = mel bins
+                rng[b, 2], rng[b, 3] = self._range(self.time_mask_param, f)
+            if random.random() <= self.thresh:                       # reference "frequency_masking": axis 1 = frames
+                rng[b, 0], rng[b, 1] = self._range(self.freq_mask_param, t)
+        return rng
+
+    def augment(self, feat, ranges=None):
+        if not self.apply_augment:
+            return feat
+        from . import ops
+        b, t, f, _ = feat.shape
+        if ranges is None:
+            ranges = self.draw(b, t, f)
+        return ops.mask_ranges_(feat, ranges.to(feat.device, non_blocking=True).contiguous())

@@ -120,3 +120,42 @@ def load_scaler_npz(path):
     """Scaler statistics stored as .npz (mel_mean/mel_std (1,64,4), iv_mean/iv_std (1,64,3))."""
     z = np.load(path)
     return {"MEL": {"mean": z["mel_mean"], "std": z["mel_std"]}, "IV": {"mean": z["iv_mean"], "std": z["iv_std"]}}
+
+
+class ScalerFitter:
+    """Train-set feature statistics on the GPU (reference src/preprocess.py:86-130: mean / std / max / min over all frames,
+    per mel bin and channel, population std).  ``partial_fit(audio)`` runs K1 WITHOUT a scaler on a batch of raw audio
+    and accumulates per-column sums in float64; ``finalize()`` returns the reference's ``scaler_wts.pkl`` dictionary
+    ({'MEL'|'IV': {'mean','std','max','min'}} with shapes (1, 64, 4) / (1, 64, 3))."""
+
+    def __init__(self, device="cuda:0"):
+        self.fx = FeatureExtractor(None, device)
+        self.n = 0
+        self.acc = None
+
+    def partial_fit(self, audio):
+        from . import ops
+        feat = self.fx(audio, channels_last8=True)                  # (B, T, 64, 8)
+        b, t, f, c = feat.shape
+        st = ops.colstats(feat.view(b * t, f * c))                  # float64 [4][512]
+        if self.acc is None:
+            self.acc = st.clone()
+        else:
+            self.acc[0] += st[0]
+            self.acc[1] += st[1]
+            self.acc[2] = torch.maximum(self.acc[2], st[2])
+            self.acc[3] = torch.minimum(self.acc[3], st[3])
+        self.n += b * t
+        return self
+
+    def finalize(self):
+        a = self.acc.cpu().numpy().reshape(4, N_MELS, 8)
+        mean = a[0] / self.n
+        var = np.maximum(a[1] / self.n - mean * mean, 0.0)
+        out = {"MEL": {}, "IV": {}}
+        for key, sl in (("MEL", slice(0, 4)), ("IV", slice(4, 7))):
+            out[key]["mean"] = mean[None, :, sl].copy()
+            out[key]["std"] = np.sqrt(var)[None, :, sl].copy()
+            out[key]["max"] = a[2][None, :, sl].copy()
+            out[key]["min"] = a[3][None, :, sl].copy()
+        return out

@@ -651,3 +651,34 @@ def gemm_batched(a, b, c, m, n, k, lda, ldb, ldc, trans_a, trans_b, outer, inner
     _c("adyolo_gemm_batched", _p(a), _p(b), _p(c), m, n, k, lda, ldb, ldc, int(trans_a), int(trans_b), outer, inner,
        oa, ia, ob, ib, oc, ic, float(alpha), int(accumulate), _stream())
     return c
+
+
+# ---------------------------------------------------------------------------------------------- input pipeline (8f rows 2-3)
+def pcm16_to_f32(pcm, out=None):
+    """int16 samples (any shape, contiguous, on the GPU) -> float32 ``x / 32768 + 1e-8`` (datasets.py:105)."""
+    if not pcm.is_cuda or pcm.dtype != torch.int16 or not pcm.is_contiguous():
+        raise _lib.AdyoloHipError("pcm16_to_f32 needs a contiguous int16 tensor on a HIP device")
+    if out is None:
+        out = torch.empty(pcm.shape, dtype=torch.float32, device=pcm.device)
+    _c("adyolo_pcm16_to_f32", _p(pcm), _p(out), pcm.numel(), _stream())
+    return out
+
+
+def mask_ranges_(feat, ranges):
+    """In-place SpecAug masking of feat [B][T][F][C]: ranges int32 [B][4] = {t0, t1, f0, f1} per sample."""
+    _chk(feat)
+    if ranges.dtype != torch.int32 or not ranges.is_cuda or not ranges.is_contiguous():
+        raise _lib.AdyoloHipError("mask_ranges_ needs contiguous int32 ranges on the device")
+    b, t, f, c = feat.shape
+    _c("adyolo_mask_ranges", _p(feat), _p(ranges), b, t, f, c, _stream())
+    return feat
+
+
+def colstats(a2d):
+    """[rows][cols] fp32 -> float64 [4][cols]: column sum, sum of squares, max, min."""
+    _chk(a2d)
+    rows, cols = a2d.shape
+    out = torch.empty((4, cols), dtype=torch.float64, device=a2d.device)
+    partial = _new(a2d, 4, 1024, cols)
+    _c("adyolo_colstats", _p(a2d), _p(partial), _p(out), rows, cols, _stream())
+    return out

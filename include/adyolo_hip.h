@@ -278,6 +278,18 @@ int adyolo_adpit_loss(const float *out, const float *tgt, float *loss, float *do
                       int C, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Input pipeline around K1.
+ *   adyolo_pcm16_to_f32: staged WAV samples int16 -> float, x / 32768 + 1e-8 (src/datasets.py:105, src/preprocess.py:104)
+ *   adyolo_mask_ranges:  SpecAug (src/utils/augmentations.py:6-33) on feat [B][T][F][C]: per sample zero frames [t0,t1) and
+ *                        mel bins [f0,f1); ranges [B][4] int32 = {t0, t1, f0, f1}, an empty range masks nothing
+ *   adyolo_colstats:     per-column sum, sum of squares, max, min of a [rows][cols] fp32 matrix -> out [4][cols] float64
+ *                        (train-set scaler statistics, src/preprocess.py:86-130); partial = [4][1024][cols] fp32 scratch
+ * ---------------------------------------------------------------------------------------------- */
+int adyolo_pcm16_to_f32(const int16_t *pcm, float *out, long n, void *stream);
+int adyolo_mask_ranges(float *feat, const int32_t *ranges, int B, int T, int F, int C, void *stream);
+int adyolo_colstats(const float *a, float *partial, double *out, long rows, int cols, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K9  ResNet-Conformer encoder pieces (src/models/backbones/resnet_conformer.py), channels-last fp32
  *   im2col / col2im / pack_wk : general strided convolution = im2col + adyolo_gemm; rows of `col` / `wk` are
  *       (kh, kw, c)-ordered and padded to a multiple of 4 floats (Kp).  Used for the 7x7 s(1,2) stem (:347) and the

@@ -753,3 +753,116 @@ def test_train_step_runs_and_learns(ops):
     losses = [float(step.step(audio, target)) for _ in range(8)]
     assert all(np.isfinite(losses)), losses
     assert losses[-1] < losses[0], losses
+
+
+# ------------------------------------------------------------------------------------------------ input pipeline (8f rows 2-4)
+@pytest.mark.parametrize("n", [8 * 1000, 8 * 1000 + 5, 3])
+def test_pcm16_to_f32_matches_numpy(ops, n):
+    rs = np.random.RandomState(n)
+    pcm = rs.randint(-32768, 32768, size=n).astype(np.int16)
+    got = ops.pcm16_to_f32(torch.from_numpy(pcm).to("cuda:0"))
+    torch.cuda.synchronize()
+    ref = (pcm.astype(np.float64) / 32768.0 + 1e-8).astype(np.float32)       # datasets.py:105, cast like torch.Tensor(...)
+    assert np.array_equal(got.cpu().numpy(), ref)
+
+
+def test_audio_stager_double_buffers(ops):
+    from adyolo_amd.datasets import AudioStager
+    rs = np.random.RandomState(0)
+    st = AudioStager(3, 2400, "cuda:0")
+    batches = [rs.randint(-32768, 32768, size=(3, 2400, 4)).astype(np.int16) for _ in range(3)]
+    for pcm in batches:
+        st.stage(list(pcm))
+        a = st.get()
+        torch.cuda.synchronize()
+        assert a.shape == (3, 2400, 4) and a.dtype == torch.float32
+        assert np.array_equal(a.cpu().numpy(), (pcm.astype(np.float64) / 32768.0 + 1e-8).astype(np.float32))
+
+
+def test_specaug_masking_matches_numpy(ops):
+    from adyolo_amd.augmentations import SpecAug
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(5, 40, 64, 8, generator=g)
+    rng = torch.tensor([[3, 11, 0, 0], [0, 0, 60, 64], [0, 40, 5, 6], [0, 0, 0, 0], [39, 40, 0, 64]], dtype=torch.int32)
+    ref = x.clone()
+    for b, (t0, t1, f0, f1) in enumerate(rng.tolist()):
+        ref[b, t0:t1] = 0.0
+        ref[b, :, f0:f1] = 0.0
+    sa = SpecAug({"aug_config": {"spec_augment": True, "spec_augment_thresh": 1.0, "spec_augment_time_mask_param": 8,
+                                 "spec_augment_freq_mask_param": 8}}, is_valid=False)
+    got = sa.augment(dev(x), ranges=rng)
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu(), ref)
+    again = sa.augment(dev(x))                  # drawn ranges: only zeros are introduced
+    torch.cuda.synchronize()
+    a = again.cpu()
+    assert bool(((a == x) | (a == 0)).all())
+
+
+def test_scaler_fitter_matches_numpy_and_oracle(ops):
+    """mean / std / max / min of the unscaled features over all frames (preprocess.py:117-126, population std)."""
+    from adyolo_amd.datasets import synthetic_audio
+    from adyolo_amd.features import FeatureExtractor, ScalerFitter
+    from oracle import features as ofeat
+    audio = synthetic_audio(3, 24000, seed=77)
+    fit = ScalerFitter("cuda:0")
+    fit.partial_fit(dev(audio[:2].contiguous()))
+    fit.partial_fit(dev(audio[2:].contiguous()))
+    sc = fit.finalize()
+    torch.cuda.synchronize()
+    feat = FeatureExtractor(None, "cuda:0")(dev(audio), channels_last8=True).cpu().double().numpy()    # (3, 40, 64, 8)
+    flat = feat.reshape(-1, 64, 8)
+    for key, sl in (("MEL", slice(0, 4)), ("IV", slice(4, 7))):
+        assert sc[key]["mean"].shape == (1, 64, sl.stop - sl.start)
+        np.testing.assert_allclose(sc[key]["mean"][0], flat[:, :, sl].mean(0), rtol=0, atol=2e-6 * np.abs(flat).max())
+        np.testing.assert_allclose(sc[key]["std"][0], flat[:, :, sl].std(0), rtol=1e-5, atol=1e-6)
+        # (K1 accumulates mel bins with LDS float atomics: two runs of it may differ in the last ulp)
+        np.testing.assert_allclose(sc[key]["max"][0], flat[:, :, sl].max(0), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(sc[key]["min"][0], flat[:, :, sl].min(0), rtol=0, atol=1e-5)
+    # against the float64 CPU oracle of the reference feature code (features differ at the fp32 FFT level)
+    mel = ofeat.mel_filterbank()
+    o = np.stack([ofeat.get_feature(audio[b].double().numpy(), None, mel)[0] for b in range(3)])        # (3, 7, 40, 64)
+    om = o.transpose(0, 2, 3, 1).reshape(-1, 64, 7)
+    np.testing.assert_allclose(sc["MEL"]["mean"][0], om[:, :, :4].mean(0), atol=2e-3)
+    np.testing.assert_allclose(sc["MEL"]["std"][0], om[:, :, :4].std(0), atol=2e-3)
+    np.testing.assert_allclose(sc["IV"]["mean"][0], om[:, :, 4:].mean(0), atol=2e-4)
+    np.testing.assert_allclose(sc["IV"]["std"][0], om[:, :, 4:].std(0), atol=2e-4)
+
+
+def test_resume_from_a_torch_adam_checkpoint_continues_identically(ops, tmp_path):
+    """A reference-side run (torch.optim.Adam on the CPU) checkpointed after 2 steps and resumed on the fused gfx950 Adam
+    takes the same third step (train.py:148-150 resume path)."""
+    from adyolo_amd import checkpoint as ck
+    from adyolo_amd.dist import FlatParameters
+    from adyolo_amd.train import FusedAdam
+    from adyolo_amd.wrapper import WrapperModel
+    torch.manual_seed(11)
+    model = WrapperModel((1, 7, 64, 64), (), _params()).to("cuda:0")
+    twin = [torch.nn.Parameter(p.detach().cpu().clone()) for p in model.parameters()]
+    adam = torch.optim.Adam(twin, lr=1e-3)
+    grads = [[torch.randn_like(p) for p in twin] for _ in range(3)]
+    for s in range(2):
+        for p, g_ in zip(twin, grads[s]):
+            p.grad = g_.clone()
+        adam.step()
+    path = os.path.join(tmp_path, "model_ckpt.h5")
+    sd = dict(zip(model.state_dict().keys(), [None] * 1000))
+    msd = model.state_dict()
+    pnames = [k for k, _ in model.named_parameters()]
+    for k, p in zip(pnames, twin):
+        msd[k] = p.detach().clone()
+    torch.save({"start_epoch_nb": 2, "model_state_dict": {k: v.cpu() for k, v in msd.items()},
+                "optim_state_dict": adam.state_dict(), "confidence_thresh": 0.5, "rng_state": None, "best_log": {},
+                "train_remaining_file": []}, path)
+    flat = FlatParameters(model)
+    opt = FusedAdam(flat)
+    ck.load_checkpoint(path, model, opt, device="cuda:0")
+    for p, g_ in zip(model.parameters(), grads[2]):
+        p.grad.copy_(g_.to("cuda:0"))
+    opt.step()
+    for p, g_ in zip(twin, grads[2]):
+        p.grad = g_.clone()
+    adam.step()
+    torch.cuda.synchronize()
+    for (k, p), q in zip(model.named_parameters(), twin):
+        assert_close(p, q, 1e-6, "parameter %s after the resumed step" % k)

@@ -163,3 +163,81 @@ def test_rotation_labels_match_reference():
         lab = rotate_labels(label, c)
         rows = np.asarray([[fr] + [float(v) for v in ev] for fr, evs in lab.items() for ev in evs])
         np.testing.assert_array_equal(rows, g["label_rot"][c])
+
+
+def _cpu_params():
+    return {"args": {"device": "cpu", "encoder": "se-resnet34", "loss": "adyolo"}, "data_config": {"nb_classes": 12},
+            "train_config": {"grid_size": [45, 45], "nb_anchors": 5, "optim": "Adam", "lr": 1e-3, "weight_decay": 0.0}}
+
+
+def test_checkpoint_files_follow_the_reference_format(tmp_path):
+    """optim_state_dict is torch.optim.Adam's layout in model.parameters() order (what the reference's
+    optimizer.state_dict() writes, train.py:239-247), whatever the flat buffer's internal order; model_ckpt.h5 round-trips
+    model, optimizer moments, step count and all four RNG streams (utility.py:32-50) without touching torch.cuda on CPU."""
+    import random
+    from adyolo_amd import checkpoint as ck
+    from adyolo_amd.dist import FlatParameters
+    from adyolo_amd.train import FusedAdam
+    from adyolo_amd.wrapper import WrapperModel
+    torch.manual_seed(3)
+    model = WrapperModel((1, 7, 64, 64), (), _cpu_params())
+    twin = [torch.nn.Parameter(p.detach().clone()) for p in model.parameters()]
+    adam = torch.optim.Adam(twin, lr=2e-3, betas=(0.8, 0.95), eps=1e-7)
+    for _ in range(2):
+        for p in twin:
+            p.grad = torch.randn_like(p)
+        adam.step()
+    ref = adam.state_dict()
+    flat = FlatParameters(model)                                    # reversed internal order
+    opt = FusedAdam(flat)
+    ck.load_optimizer_state_dict(opt, model, ref)
+    assert (opt.lr, opt.betas, opt.eps, opt.step_count) == (2e-3, (0.8, 0.95), 1e-7, 2)
+    mine = ck.optimizer_state_dict(opt, model)
+    assert mine["param_groups"][0]["params"] == ref["param_groups"][0]["params"]
+    for i, st in ref["state"].items():
+        assert int(mine["state"][i]["step"]) == int(st["step"])
+        assert torch.equal(mine["state"][i]["exp_avg"], st["exp_avg"])
+        assert torch.equal(mine["state"][i]["exp_avg_sq"], st["exp_avg_sq"])
+    # file round trip incl. RNG
+    path = os.path.join(tmp_path, "model_ckpt.h5")
+    os.environ["PYTHONHASHSEED"] = "100"
+    ck.save_checkpoint(path, model, opt, 7, 0.4, {"best_epoch": 3, "best_conf_thresh": 0.4}, ["a.wav", "b.wav"], "cpu")
+    expect = (random.random(), float(np.random.rand()), float(torch.rand(1)))
+    saved = torch.load(path, map_location="cpu", weights_only=False)
+    assert sorted(saved) == sorted(["start_epoch_nb", "model_state_dict", "optim_state_dict", "confidence_thresh",
+                                    "rng_state", "best_log", "train_remaining_file"])
+    assert list(saved["model_state_dict"]) == list(model.state_dict())
+    model2 = WrapperModel((1, 7, 64, 64), (), _cpu_params())
+    opt2 = FusedAdam(FlatParameters(model2))
+    got = ck.load_checkpoint(path, model2, opt2, device="cpu")
+    assert got["start_epoch_nb"] == 7 and got["train_remaining_file"] == ["a.wav", "b.wav"]
+    assert (random.random(), float(np.random.rand()), float(torch.rand(1))) == expect
+    for (k, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert opt2.step_count == 2 and torch.equal(opt2.exp_avg.sort().values, opt.exp_avg.sort().values)
+    # torch.optim.Adam itself accepts the written optimizer state (a reference-side resume)
+    adam2 = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in model.parameters()])
+    adam2.load_state_dict(saved["optim_state_dict"])
+    assert adam2.state_dict()["state"][0]["exp_avg"].shape == ref["state"][0]["exp_avg"].shape
+
+
+def test_specaug_policy():
+    """identity by default and on validation data; drawn ranges follow torchaudio 0.10's mask_along_axis bounds; the
+    reference's (C, T, F) call makes its "time" mask act on mel bins and its "frequency" mask on frames."""
+    import random
+    from adyolo_amd.augmentations import SpecAug
+    off = SpecAug({"aug_config": {"spec_augment": False}}, is_valid=False)
+    val = SpecAug({"aug_config": {"spec_augment": True, "spec_augment_thresh": 1.0}}, is_valid=True)
+    x = torch.zeros(1)
+    assert off.augment(x) is x and val.augment(x) is x
+    sa = SpecAug({"aug_config": {"spec_augment": True, "spec_augment_thresh": 1.0, "spec_augment_time_mask_param": 10,
+                                 "spec_augment_freq_mask_param": 30}}, is_valid=False)
+    random.seed(5)
+    r = sa.draw(64, 800, 64).numpy()
+    assert r.shape == (64, 4) and (r[:, 0] >= 0).all() and (r[:, 1] <= 800).all() and (r[:, 3] <= 64).all()
+    assert (r[:, 1] - r[:, 0]).max() <= 30 and (r[:, 3] - r[:, 2]).max() <= 10        # frames <- freq param, bins <- time param
+    assert (r[:, 1] - r[:, 0]).max() > 10                                            # really the 30-wide one
+    random.seed(5)
+    never = SpecAug({"aug_config": {"spec_augment": True, "spec_augment_thresh": -1.0, "spec_augment_time_mask_param": 10,
+                                    "spec_augment_freq_mask_param": 30}}, is_valid=False).draw(8, 800, 64)
+    assert int(never.abs().sum()) == 0
