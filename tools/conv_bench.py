@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--which", default="fwd,wgrad")
     ap.add_argument("--stages", default="1,2,3,4")
     ap.add_argument("--algo", default=None, help="direct | winograd (default: ADYOLO_CONV_ALGO)")
+    ap.add_argument("--zeros", action="store_true", help="all-zero operands (DVFS check: same cycles, less power)")
     ap.add_argument("--fused", action="store_true", help="fwd: in_affine + epilogue stats + masked addend; wgrad: in_affine")
     a = ap.parse_args()
     for st in [int(s) for s in a.stages.split(",")]:
@@ -29,6 +30,8 @@ def main():
         wt = torch.randn(cout, max(cin, 1) if cin != 8 else 7, 3, 3, device="cuda:0") * 0.05
         wpk, _ = ops.pack_w3x3(wt, cin, want_dgrad=False, algo=a.algo)
         dy = torch.randn(a.batch, h, w, cout, device="cuda:0")
+        if a.zeros:
+            x.zero_(); wt.zero_(); dy.zero_(); wpk.zero_()
         flops = 2.0 * a.batch * h * w * cout * 9 * cin
         aff = (torch.rand(cin, device="cuda:0") + 0.5, torch.randn(cin, device="cuda:0")) if (a.fused and cin != 8) else None
         for which in a.which.split(","):
