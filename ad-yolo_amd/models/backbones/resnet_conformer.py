@@ -39,6 +39,19 @@ def _dropout(x, p, training, rng):
     return Fn.DropoutFn.apply(x, rng.mask(x, p))
 
 
+def _conv3x3_s1(x, w):
+    """Stride-1 3x3 convolution.  Winograd kernels on wide maps; the deep stages of this ResNet have strided the
+    frequency axis down to 2 and 1 bins, where an 8 x 16-pixel Winograd patch would be 87-94 % padding, so those run as
+    im2col + GEMM.  For W == 1 only the centre kernel column ever meets data (the other two see zero padding), so the
+    convolution IS the 3 x 1 one on w[:, :, :, 1:2]; the outer taps get exactly zero gradient, as in the reference."""
+    wd = x.shape[2]
+    if wd == 1:
+        return Fn.ConvFn.apply(x, w[:, :, :, 1:2].contiguous(), (1, 1), (1, 0))
+    if wd == 2:
+        return Fn.ConvFn.apply(x, w, (1, 1), (1, 1))
+    return Fn.Conv3x3S1Fn.apply(x, w)
+
+
 class BasicBlock(nn.Module):
     def __init__(self, inplanes, planes, stride=(1, 1), downsample=None):
         super().__init__()
@@ -51,11 +64,11 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         if self.stride == (1, 1):
-            out = Fn.Conv3x3S1Fn.apply(x, self.conv1.weight)
+            out = _conv3x3_s1(x, self.conv1.weight)
         else:
             out = Fn.ConvFn.apply(x, self.conv1.weight, self.stride, (1, 1))
         out = Fn.BatchNormFn.apply(out, self.bn1.weight, self.bn1.bias, self.bn1, self.training, True, None)
-        out = Fn.Conv3x3S1Fn.apply(out, self.conv2.weight)
+        out = _conv3x3_s1(out, self.conv2.weight)
         if self.downsample is not None:
             idn = Fn.ConvFn.apply(x, self.downsample["0"].weight, self.stride, (0, 0))
             d = self.downsample["1"]
