@@ -56,6 +56,9 @@ def assert_close(got, ref, tol, what):
     (1, 10, 16, 256, 256, False, False, True),
     (1, 5, 5, 32, 32, False, False, False),      # tile much larger than the image
     (1, 33, 40, 32, 64, True, False, False),     # ragged both ways, TW=32
+    (3, 7, 50, 64, 96, False, True, True),       # 3 channel blocks (no XCD mapping), odd sizes, 3 x 4 x 1 patches
+    (5, 8, 16, 512, 64, True, False, False),     # deepest reduction the Winograd affine table allows (Cin = 512)
+    (7, 24, 16, 32, 128, False, False, False),   # one-chunk variant, 21 patches on 4 channel blocks (ragged block deal)
 ])
 @pytest.mark.parametrize("algo", ["direct", "winograd"])
 def test_conv3x3_forward(ops, n, h, w, cin, cout, relu, bias, addend, algo):
@@ -84,6 +87,7 @@ def test_conv3x3_forward(ops, n, h, w, cin, cout, relu, bias, addend, algo):
     (2, 16, 64, 32, 32), (2, 13, 32, 32, 64), (1, 18, 16, 64, 128), (1, 9, 16, 256, 256), (2, 20, 64, 7, 32),
     (3, 40, 64, 32, 32), (2, 150, 24, 32, 64), (1, 67, 37, 64, 32),
     (6, 132, 16, 256, 256),      # Winograd wgrad: 18 work items on 16 slabs -> several items per workgroup, ragged segment
+    (2, 21, 19, 96, 32),         # odd H and W (general masking path), 3 input-channel blocks
 ])
 @pytest.mark.parametrize("algo", ["direct", "winograd"])
 def test_conv3x3_dgrad_wgrad(ops, n, h, w, cin, cout, algo):
