@@ -549,6 +549,15 @@ extern "C" int adyolo_se_tail_bwd_reduce(const float *de, const float *e, const 
     return check_launch("se_tail_bwd_reduce_final");
 }
 
+// the same two per-sample sums from the per-patch sums a convolution epilogue already produced (stat_mask = e,
+// stat_aux = c): tile_stats [2][N*G][C] -> sg, sgx [N][C]
+extern "C" int adyolo_se_tail_bwd_tiles(const float *tile_stats, float *sg, float *sgx, int N, int G, int C, void *stream) {
+    ADYOLO_REQUIRE(tile_stats && sg && sgx && N > 0 && G > 0 && C > 0, ADYOLO_EINVAL, "se_tail_bwd_tiles: bad arguments");
+    hipLaunchKernelGGL(persample_reduce_kernel, dim3(cdiv(C, 32), N), dim3(256), 0, as_stream(stream), tile_stats, sg, sgx,
+                       N, G, C);
+    return check_launch("se_tail_bwd_tiles");
+}
+
 extern "C" long adyolo_se_fc_bwd_words(int C, int Cr) { return 2L * C * Cr + Cr + 3L * C; }
 
 extern "C" int adyolo_se_fc_bwd(const float *sg, const float *sgx, const float *ssum, const float *gamma,

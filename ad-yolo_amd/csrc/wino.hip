@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256, (WinoCfg<NT, ONE>::WG_PER_CU)) void wino_fwd_k
     const float *__restrict__ addend, const float *__restrict__ addend_mask, const float *__restrict__ in_scale,
     const float *__restrict__ in_shift, float *__restrict__ y, float *__restrict__ stats,
     const float *__restrict__ stat_aux, const float *__restrict__ stat_mean, const float *__restrict__ stat_invstd,
-    int H, int W, int Cin, int Cout, int tilesW, int tilesH, int nsp, int ncb, int xcd_div, int relu) {
+    const float *__restrict__ stat_mask, int H, int W, int Cin, int Cout, int tilesW, int tilesH, int nsp, int ncb,
+    int xcd_div, int relu) {
     using Cfg = WinoCfg<NT, ONE>;
     constexpr int CB = Cfg::CB, CBP = Cfg::CBP;
     constexpr int AFFC = ONE ? WKC : WMAXC;               // channels in the affine table
@@ -323,6 +324,11 @@ __global__ __launch_bounds__(256, (WinoCfg<NT, ONE>::WG_PER_CU)) void wino_fwd_k
                     if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
                     *reinterpret_cast<float4 *>(y + o) = v;      // (non-temporal loads/stores here: measured 1 % slower)
                     if (stats) {
+                        if (stat_mask) {        // statistics of v * (mask > 0): the SE / BN2 backward sums of the block below
+                            const float4 mk = *reinterpret_cast<const float4 *>(stat_mask + o);
+                            v = make_float4(mk.x > 0.f ? v.x : 0.f, mk.y > 0.f ? v.y : 0.f, mk.z > 0.f ? v.z : 0.f,
+                                            mk.w > 0.f ? v.w : 0.f);
+                        }
                         ssum = f4_add(ssum, v);
                         if (stat_aux) {
                             const float4 ax = *reinterpret_cast<const float4 *>(stat_aux + o);
@@ -434,7 +440,7 @@ extern "C" int adyolo_wino_pack_w(const float *w, float *u_fwd, float *u_dgrad, 
 extern "C" int adyolo_wino_fwd(const float *x, const float *u, const float *bias, const float *addend,
                                const float *addend_mask, const float *in_scale, const float *in_shift, float *y,
                                float *stats, const float *stat_aux, const float *stat_mean, const float *stat_invstd,
-                               int N, int H, int W, int Cin, int Cout, int relu, void *stream) {
+                               const float *stat_mask, int N, int H, int W, int Cin, int Cout, int relu, void *stream) {
     ADYOLO_REQUIRE(x && u && y && N > 0 && H > 0 && W > 0, ADYOLO_EINVAL, "wino_fwd: bad arguments");
     ADYOLO_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0 && Cin > 0 && Cout > 0 && Cin <= WMAXC, ADYOLO_ENOSUP,
                    "wino_fwd: Cin=%d (<= 512) and Cout=%d must be multiples of 32", Cin, Cout);
@@ -443,6 +449,7 @@ extern "C" int adyolo_wino_fwd(const float *x, const float *u, const float *bias
                    "wino_fwd: in_scale/in_shift come together; addend_mask needs addend");
     ADYOLO_REQUIRE(!stat_aux || (stats && stat_mean && stat_invstd), ADYOLO_EINVAL,
                    "wino_fwd: stat_aux needs stats, stat_mean and stat_invstd");
+    ADYOLO_REQUIRE(!stat_mask || stats, ADYOLO_EINVAL, "wino_fwd: stat_mask needs stats");
     const int tilesW = cdiv(W, 16), tilesH = cdiv(H, 8);
     const int nsp = N * tilesH * tilesW;
     const int nt = Cout % 64 == 0 ? 2 : 1;
@@ -455,8 +462,8 @@ extern "C" int adyolo_wino_fwd(const float *x, const float *u, const float *bias
     hipStream_t st = as_stream(stream);
 #define ADYOLO_WINO_FWD(NT_, ONE_)                                                                                  \
     hipLaunchKernelGGL((wino_fwd_kernel<NT_, ONE_>), dim3((unsigned)blocks), dim3(256), 0, st, x, u, bias, addend,       \
-                       addend_mask, in_scale, in_shift, y, stats, stat_aux, stat_mean, stat_invstd, H, W, Cin, Cout,    \
-                       tilesW, tilesH, nsp, ncb, xcd_div, relu)
+                       addend_mask, in_scale, in_shift, y, stats, stat_aux, stat_mean, stat_invstd, stat_mask, H, W,   \
+                       Cin, Cout, tilesW, tilesH, nsp, ncb, xcd_div, relu)
     if (Cin == WKC) {
         if (nt == 2) ADYOLO_WINO_FWD(2, true); else ADYOLO_WINO_FWD(1, true);
     } else {

@@ -19,6 +19,20 @@ FUSE_DR = os.environ.get("ADYOLO_FUSE_DR", "1") != "0"           # identity-shor
 # kernel's scalar epilogue and a one-stage tile reduction this was 7 % slower; with the Winograd kernel's float4 epilogue and
 # the two-stage adyolo_bn_bwd_tiles it measures 173.5 -> 171.0 ms per step, so it is on (ADYOLO_FUSE_BNBWD=0 switches it off)
 FUSE_BNBWD = os.environ.get("ADYOLO_FUSE_BNBWD", "1") != "0"
+# SE / BN2 backward sums of block A from the dgrad(conv1) epilogue of the identity-shortcut block B that follows it: the
+# launch that produces dA = conv1_dgrad(da_B) + de_B * (e_B > 0) also sums dA * (e_A > 0) and dA * (e_A > 0) * xhat(c_A) per
+# patch (stat_mask = e_A = B's input, stat_aux = c_A), so A's backward skips its three-tensor reduction pass.  Active for 12
+# of the 16 blocks, bit-compatible with the unfused path in the golden tests, but the two extra tensors the epilogue
+# reads cost what the removed pass saved (168.5 vs 168.3 ms per step): off by default, kept as an A/B switch.
+FUSE_SEBWD = os.environ.get("ADYOLO_FUSE_SEBWD", "0") != "0"
+
+
+class BlockLink:
+    """Side channel between two consecutive SE blocks (A feeds only B, B has an identity shortcut and no pooling):
+    A.forward publishes (c_A, mean2_A, invstd2_A); B.backward leaves the per-patch sums for A.backward."""
+
+    def __init__(self):
+        self.cc = self.mean2 = self.invstd2 = self.tiles = None
 
 
 def _c(t):
@@ -94,7 +108,7 @@ class SEBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, training, pool, bns, w1, g1, b1, w2, g2, b2, fw1, fb1, fw2, fb2, wd=None, gd=None, bd=None):
-        bn1, bn2, bnd = bns
+        bn1, bn2, bnd, link_in, link_out = bns
         p = ops.avgpool2(x) if pool else x
         n, h, w_, cin = p.shape
         c = w1.shape[0]
@@ -138,6 +152,11 @@ class SEBlockFn(torch.autograd.Function):
         else:
             r = p
         e = ops.se_tail_fwd(cc, r, scale2, shift2, s)
+        ctx.link_in = link_in if (FUSE_SEBWD and FUSE_DR and training and link_in is not None and not pool
+                                  and wd is None and link_in.cc is not None) else None
+        ctx.link_out = link_out if (FUSE_SEBWD and training) else None
+        if ctx.link_out is not None:
+            link_out.cc, link_out.mean2, link_out.invstd2, link_out.tiles = cc, mean2, invstd2, None
         ctx.training, ctx.pool, ctx.has_down = training, pool, wd is not None
         ctx.in_hw = (x.shape[1], x.shape[2])
         ctx.fused_affine = aff is not None
@@ -159,9 +178,12 @@ class SEBlockFn(torch.autograd.Function):
         n, h, w_, cin = p.shape
         c = cc.shape[-1]
         de = _c(de)
+        tiles = None
+        if ctx.link_out is not None and ctx.link_out.tiles is not None:
+            tiles, ctx.link_out.tiles = ctx.link_out.tiles, None      # left by the block above (its dgrad produced `de`)
         dc, dr, dg2, db2, dfw1, dfb1, dfw2, dfb2 = ops.se_tail_bwd(de, e, cc, g2, b2, mean2, invstd2, ssum2, pooled,
                                                                    hid, s, fw1, fw2,
-                                                                   want_dr=ctx.has_down or not FUSE_DR)
+                                                                   want_dr=ctx.has_down or not FUSE_DR, tile_stats=tiles)
         if ctx.fused_affine:
             a = src
             dw2 = ops.conv3x3_wgrad(a, dc, c, in_affine=(scale1, shift1))
@@ -186,7 +208,11 @@ class SEBlockFn(torch.autograd.Function):
             dp = ops.conv3x3(da, wpk1d, cin, addend=dp_res)
         else:
             # identity shortcut: its gradient de * (e > 0) is formed inside the dgrad epilogue
-            if FUSE_DR:
+            if ctx.link_in is not None:
+                lk = ctx.link_in
+                dp, lk.tiles = ops.conv3x3(da, wpk1d, cin, addend=de, addend_mask=e, want_stats=True,
+                                           stat_bn=(lk.cc, lk.mean2, lk.invstd2), stat_mask=p)
+            elif FUSE_DR:
                 dp = ops.conv3x3(da, wpk1d, cin, addend=de, addend_mask=e)
             else:
                 dp = ops.conv3x3(da, wpk1d, cin, addend=dr)

@@ -81,10 +81,11 @@ class SEBasicBlock(nn.Module):
         else:
             self.downsample = None
 
-    def forward(self, x):
+    def forward(self, x, link_in=None, link_out=None):
+        """link_in / link_out: ``functional.BlockLink`` shared with the block below / above (see FUSE_SEBWD)."""
         fc0, fc2 = self.se.fc["0"], self.se.fc["2"]
         args = [x, self.training, self.pool,
-                (self.bn1, self.bn2, self.downsample["1"] if self.downsample is not None else None),
+                (self.bn1, self.bn2, self.downsample["1"] if self.downsample is not None else None, link_in, link_out),
                 self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight, self.bn2.weight, self.bn2.bias,
                 fc0.weight, fc0.bias, fc2.weight, fc2.bias]
         if self.downsample is not None:
@@ -173,9 +174,12 @@ class SEResnet34(nn.Module):
         x8 = x if channels_last8 else ops.nchw_to_nhwc8(x.contiguous().float())
         y = Fn.StemFn.apply(x8, self.conv1.weight, self.conv1.bias, self.bn1.weight, self.bn1.bias, self.bn1,
                             self.training)
+        link = None                              # BlockLink between consecutive blocks (functional.FUSE_SEBWD)
         for li in range(1, 5):
             for blk in getattr(self, "layer%d" % li):
-                y = blk(y)
+                nxt = Fn.BlockLink()
+                y = blk(y, link_in=link, link_out=nxt)
+                link = nxt
         y = Fn.SAPFn.apply(y, self.attention.W.weight, self.attention.W.bias)
         save = self.training and torch.is_grad_enabled()
         y = Fn.BiGRULayerFn.apply(y, *self.lstm.layer_params(0), save)

@@ -75,14 +75,15 @@ def pack_w3x3(w, cin_pad, want_dgrad=True, algo=None):
 
 
 def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, in_affine=None, want_stats=False,
-            stat_bn=None):
+            stat_bn=None, stat_mask=None):
     """x [N][H][W][Cin] -> [N][H][W][cout];  wpk from ``pack_w3x3`` (direct [cout][9][Cin] or Winograd, rank 4).
 
     in_affine=(scale, shift): the producer's BatchNorm affine is applied while staging x (padding stays 0);
     addend_mask: addend is multiplied by (mask > 0); want_stats: also return the per-patch channel sums
     [2][tiles][cout] of the output for ``bn_stats_tiles``; stat_bn=(aux, mean, invstd): the second per-patch sum
-    becomes sum(y * xhat(aux)) (the output is a gradient, aux the BatchNorm input) for ``bn_bwd(..., tile_stats=)``."""
-    _chk(x, wpk, bias, addend, addend_mask)
+    becomes sum(y * xhat(aux)) (the output is a gradient, aux the BatchNorm input) for ``bn_bwd(..., tile_stats=)``;
+    stat_mask: both sums are taken of y * (stat_mask > 0) (for ``se_tail_bwd(..., tile_stats=)`` of the block below)."""
+    _chk(x, wpk, bias, addend, addend_mask, stat_mask)
     n, h, w, cin = x.shape
     wino = wpk.dim() == 4
     y = _new(x, n, h, w, cout)
@@ -93,7 +94,7 @@ def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, 
     sc, sh = in_affine if in_affine is not None else (None, None)
     sa, sm, si = stat_bn if stat_bn is not None else (None, None, None)
     _c("adyolo_wino_fwd" if wino else "adyolo_conv3x3_fwd", _p(x), _p(wpk), _p(bias), _p(addend), _p(addend_mask),
-       _p(sc), _p(sh), _p(y), _p(stats), _p(sa), _p(sm), _p(si), n, h, w, cin, cout, int(relu), _stream())
+       _p(sc), _p(sh), _p(y), _p(stats), _p(sa), _p(sm), _p(si), _p(stat_mask), n, h, w, cin, cout, int(relu), _stream())
     return (y, stats) if want_stats else y
 
 
@@ -280,17 +281,22 @@ def se_tail_fwd(c_t, r_t, scale, shift, s):
     return e
 
 
-def se_tail_bwd(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1, w2, want_dr=True):
+def se_tail_bwd(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1, w2, want_dr=True, tile_stats=None):
     """Backward of  e = relu(bn2(c) * s + r)  incl. the SE FCs.
-    -> dc, dr, dgamma, dbeta, dw1, db1, dw2, db2"""
+    -> dc, dr, dgamma, dbeta, dw1, db1, dw2, db2
+    tile_stats: per-patch sums [2][tiles][C] of de * (e > 0) and de * (e > 0) * xhat(c) from the convolution epilogue
+    that produced ``de`` (``conv3x3(..., stat_bn=(c, mean, invstd), stat_mask=e)``): the reduction pass is skipped."""
     _chk(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1, w2)
     n, ch = c_t.shape[0], c_t.shape[-1]
     hw = c_t.numel() // (n * ch)
     cr = w1.shape[0]
     sg, sgx = _new(c_t, n, ch), _new(c_t, n, ch)
-    partial = _new(c_t, 2 * 1024 * ch)
-    _c("adyolo_se_tail_bwd_reduce", _p(de), _p(e), _p(c_t), _p(mean), _p(invstd), _p(sg), _p(sgx), _p(partial), n, hw,
-       ch, _stream())
+    if tile_stats is not None:
+        _c("adyolo_se_tail_bwd_tiles", _p(tile_stats), _p(sg), _p(sgx), n, tile_stats.shape[1] // n, ch, _stream())
+    else:
+        partial = _new(c_t, 2 * 1024 * ch)
+        _c("adyolo_se_tail_bwd_reduce", _p(de), _p(e), _p(c_t), _p(mean), _p(invstd), _p(sg), _p(sgx), _p(partial), n, hw,
+           ch, _stream())
     pw = 2 * ch * cr + cr + 3 * ch
     part, packed, cws = _new(c_t, n, pw), _new(c_t, pw), _new(c_t, 1024, pw)
     dpool = _new(c_t, n, ch)

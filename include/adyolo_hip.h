@@ -82,7 +82,10 @@ int adyolo_conv3x3_tiles(int N, int H, int W);   /* number of 256-pixel patches 
 int adyolo_conv3x3_fwd(const float *x, const float *wpk, const float *bias, const float *addend,
                        const float *addend_mask, const float *in_scale, const float *in_shift, float *y,
                        float *stats, const float *stat_aux, const float *stat_mean, const float *stat_invstd,
-                       int N, int H, int W, int Cin, int Cout, int relu, void *stream);
+                       const float *stat_mask, int N, int H, int W, int Cin, int Cout, int relu, void *stream);
+/*   stat_mask (optional, needs stats): the two per-patch sums are taken of y * (stat_mask > 0) instead of y -- with
+ *   stat_aux = c and stat_mask = e of the block BELOW, the data-gradient launch that produces de also produces the
+ *   per-sample sums of the SE / BatchNorm-2 backward (finished by adyolo_se_tail_bwd_tiles), y itself is unaffected. */
 /* K2w  the same operator as Winograd F(2x2,3x3) (2.25x fewer matrix FLOPs; fp32 throughout, results agree with the
  *      direct form to ~1e-6 relative).  u_fwd / u_dgrad: the transformed filters G g G^T in MFMA-fragment order
  *      [16][Cout/32][Cin/8][64][4] (forward) / [16][Cin/32][Cout/8][64][4] (data-gradient, taps flipped, channels
@@ -93,8 +96,8 @@ int adyolo_wino_pack_w(const float *w /*[Cout][Cin_real][3][3]*/, float *u_fwd /
 int adyolo_wino_tiles(int N, int H, int W);
 int adyolo_wino_fwd(const float *x, const float *u, const float *bias, const float *addend,
                     const float *addend_mask, const float *in_scale, const float *in_shift, float *y, float *stats,
-                    const float *stat_aux, const float *stat_mean, const float *stat_invstd, int N, int H, int W,
-                    int Cin, int Cout, int relu, void *stream);
+                    const float *stat_aux, const float *stat_mean, const float *stat_invstd, const float *stat_mask,
+                    int N, int H, int W, int Cin, int Cout, int relu, void *stream);
 /* Winograd weight-gradient: dw = G^T [ sum_tiles (B^T d B)(.)(A e A^T) ] G.  slabs: [n_slabs][16][Cin][Cout] float32 with
  * n_slabs = adyolo_wino_wgrad_slabs(...); du: [16][Cin][Cout] scratch; dw: reference layout [Cout][Cin_real][3][3]. */
 int adyolo_wino_wgrad_slabs(int N, int H, int W, int Cin, int Cout);
@@ -186,6 +189,8 @@ int adyolo_se_tail_fwd(const float *c, const float *r, const float *scale, const
 int adyolo_se_tail_bwd_reduce(const float *de, const float *e, const float *c, const float *mean,
                               const float *invstd, float *sg, float *sgx, float *partial, int N,
                               int HW, int C, void *stream);
+/* sg, sgx from per-patch sums [2][N*G][C] of a convolution epilogue run with stat_mask = e, stat_aux = c */
+int adyolo_se_tail_bwd_tiles(const float *tile_stats, float *sg, float *sgx, int N, int G, int C, void *stream);
 long adyolo_se_fc_bwd_words(int C, int Cr);   /* P = 2*C*Cr + Cr + 3*C */
 int adyolo_se_fc_bwd(const float *sg, const float *sgx, const float *ssum, const float *gamma,
                      const float *beta, const float *mean, const float *invstd, const float *pooled,
