@@ -126,14 +126,21 @@ class LabelPostProcessor:
         self.conf_thresh = thresh
         self.clss_thresh = thresh
 
-    def postprocess(self, output):
+    def decode(self, output):
+        """GPU half of ``postprocess`` (threshold-free): logits (1, T', K) -> decoded predictions as a host array."""
         from . import ops
         if output.shape[0] != 1:
             raise ValueError("postprocess handles one clip at a time (B = 1), like the reference (datasets.py:752-753)")
         dec = ops.yolo_decode(output.contiguous(), self.nb_classes, self.nb_grids, self.nb_anchors, self.grid_size,
                               self.g_overlap)
-        return nms_decoded(dec.cpu().numpy(), self.nb_classes, self.conf_thresh, self.clss_thresh, self.unify_thresh,
-                           self.nms)
+        return dec.cpu().numpy()
+
+    def select(self, decoded):
+        """Host half: confidence / class thresholds + conn-merge NMS on a ``decode`` result."""
+        return nms_decoded(decoded, self.nb_classes, self.conf_thresh, self.clss_thresh, self.unify_thresh, self.nms)
+
+    def postprocess(self, output):
+        return self.select(self.decode(output))
 
 
 def write_seld_output_file(file_pth, output: dict):

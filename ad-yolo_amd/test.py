@@ -29,3 +29,37 @@ def test_epoch(dataloader, filelist, model, criterion, postprocessor, device, ou
             write_seld_output_file(os.path.join(output_pth, filelist[i] + ".csv"), postprocessor.postprocess(output))
             n = i + 1
     return float(total) / max(n, 1) if total is not None else 0.0
+
+
+def sweep_conf_thresh(dataloader, filelist, model, criterion, postprocessor, scorer, device, output_pth,
+                      thresholds=None):
+    """The reference's periodic threshold reset (src/train.py:178-203): try conf_thresh 0.1 .. 0.9, keep the first one
+    with the lowest validation SELD score, leave it set on the post-processor (which rewrites conf AND class threshold,
+    datasets.py:532-534).  The reference re-runs the whole validation epoch for each of the nine thresholds; the network
+    output does not depend on the threshold, so here the model runs ONCE per file and only the host-side selection/NMS,
+    the CSV files and the metrics are redone per threshold -- same files, same scores, a ninth of the forward passes.
+    -> (new_thresh, [[ER, F, LE, LR, SELD] per threshold], mean validation loss)"""
+    import numpy as np
+    if thresholds is None:
+        thresholds = np.arange(0.1, 1.0, 0.1)
+    model.eval()
+    decoded, total, n = [], None, 0
+    with torch.no_grad():
+        for i, (feat, label) in enumerate(dataloader):
+            output = model(feat.to(device).float())
+            loss = criterion(output, label)
+            total = loss.reshape(-1)[:1].clone() if total is None else total + loss.reshape(-1)[:1]
+            decoded.append(postprocessor.decode(output))
+            n = i + 1
+    new_thresh, best, table = postprocessor.get_conf_thresh(), 9999.0, []
+    for th in thresholds:
+        postprocessor.set_conf_thresh(th)
+        delete_and_create_folder(output_pth)
+        for i, dec in enumerate(decoded):
+            write_seld_output_file(os.path.join(output_pth, filelist[i] + ".csv"), postprocessor.select(dec))
+        er, f, le, lr, seld = scorer.get_SELD_Results(output_pth)[:5]
+        table.append([er, f, le, lr, seld])
+        if seld < best:
+            new_thresh, best = th, seld
+    postprocessor.set_conf_thresh(new_thresh)
+    return new_thresh, table, (float(total) / max(n, 1) if total is not None else 0.0)

@@ -241,3 +241,48 @@ def test_specaug_policy():
     never = SpecAug({"aug_config": {"spec_augment": True, "spec_augment_thresh": -1.0, "spec_augment_time_mask_param": 10,
                                     "spec_augment_freq_mask_param": 30}}, is_valid=False).draw(8, 800, 64)
     assert int(never.abs().sum()) == 0
+
+
+def test_threshold_sweep_runs_the_model_once_and_keeps_the_first_minimum(tmp_path):
+    """reference train.py:178-203 semantics (strict '<': the first of equal minima wins; both thresholds are rewritten)
+    with one forward pass per file instead of nine."""
+    from adyolo_amd import test as atest
+
+    class Model(torch.nn.Module):
+        calls = 0
+
+        def forward(self, x):
+            Model.calls += 1
+            return x.sum(dim=(1, 2, 3), keepdim=False).reshape(1, 1, 1)
+
+    class Post:
+        def __init__(self):
+            self.conf_thresh = self.clss_thresh = 0.5
+
+        def get_conf_thresh(self):
+            return self.conf_thresh
+
+        def set_conf_thresh(self, t):
+            self.conf_thresh = self.clss_thresh = t
+
+        def decode(self, output):
+            return float(output)
+
+        def select(self, dec):
+            return {0: [[int(round(self.conf_thresh * 10)), 1.0, 0.0, 0.0]]}
+
+    class Scorer:
+        def get_SELD_Results(self, pth):
+            names = sorted(os.listdir(pth))
+            assert names == ["a.csv", "b.csv"]
+            cls = int(open(os.path.join(pth, names[0])).read().split(",")[1])      # = round(10 * threshold)
+            seld = {3: 0.25, 6: 0.25}.get(cls, 0.5 + 0.01 * cls)                    # two equal minima: 0.3 must win
+            return 0.1, 0.2, 3.0, 0.4, seld, None
+
+    loader = [(torch.ones(1, 7, 4, 64), None), (torch.ones(1, 7, 4, 64) * 2, None)]
+    post = Post()
+    new, table, loss = atest.sweep_conf_thresh(loader, ["a", "b"], Model(), lambda o, l: o.reshape(1), post, Scorer(), "cpu",
+                                               os.path.join(tmp_path, "out"))
+    assert Model.calls == 2 and len(table) == 9
+    assert abs(new - 0.3) < 1e-9 and abs(post.conf_thresh - 0.3) < 1e-9 and abs(post.clss_thresh - 0.3) < 1e-9
+    assert abs(loss - (7 * 4 * 64 * 1.5)) < 1e-3
