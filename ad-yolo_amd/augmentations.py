@@ -1,8 +1,8 @@
 """FOA rotation augmentation.  Mirror of ``RotationAug`` (/root/reference/src/utils/augmentations.py:36-111): 16
 combinations of channel sign flips / X-Y swap with the matching azimuth / elevation remapping of the labels.
 ``rotate_labels`` is the host half (label dict); ``rotate_audio`` applies the channel transform to a whole batch of raw
-audio on the GPU (csrc/optim.hip ``foa_rotate_kernel``).  SpecAug (torchaudio 0.10 masking, augmentations.py:6-33) is
-not built: its arithmetic lives in torchaudio which is absent here (parity unpinned)."""
+audio on the GPU (csrc/optim.hip ``foa_rotate_kernel``).  ``SpecAug`` (augmentations.py:6-33) masks the GPU feature
+tensor (csrc/aug.hip); its random draw restates torchaudio 0.10, which is absent here (parity of the stream unpinned)."""
 import random
 
 import torch

@@ -172,20 +172,138 @@ class AudioStager:
         self.host = [torch.empty(self.shape, dtype=torch.int16).pin_memory() for _ in range(2)]
         self.dev = [torch.empty(self.shape, dtype=torch.int16, device=self.device) for _ in range(2)]
         self.stream = torch.cuda.Stream(device=self.device)
-        self.events = [torch.cuda.Event(), torch.cuda.Event()]
+        self.events = [torch.cuda.Event(), torch.cuda.Event()]        # copy i has landed
+        self.consumed = [None, None]                                  # conversion kernel that read dev[i] (compute stream)
         self.cur = 0
 
     def stage(self, clips):
         i = self.cur ^ 1
         h = self.host[i]
+        if self.consumed[i] is not None:
+            self.events[i].synchronize()          # the previous copy out of this pinned buffer is done
         for b, clip in enumerate(clips):
             h[b].copy_(torch.as_tensor(np.asarray(clip), dtype=torch.int16))
         with torch.cuda.stream(self.stream):
+            if self.consumed[i] is not None:
+                self.stream.wait_event(self.consumed[i])              # dev[i] has been converted by the compute stream
             self.dev[i].copy_(h, non_blocking=True)
             self.events[i].record(self.stream)
         self.cur = i
 
     def get(self):
         from . import ops
-        torch.cuda.current_stream(self.device).wait_event(self.events[self.cur])
-        return ops.pcm16_to_f32(self.dev[self.cur])
+        cs = torch.cuda.current_stream(self.device)
+        cs.wait_event(self.events[self.cur])
+        out = ops.pcm16_to_f32(self.dev[self.cur])
+        ev = torch.cuda.Event()
+        ev.record(cs)
+        self.consumed[self.cur] = ev
+        return out
+
+
+class FoaDataset(torch.utils.data.Dataset):
+    """Raw-audio counterpart of the reference ``Dataset`` (src/datasets.py:21-162): same constructor, directory layout
+    (``foa_dev/dev-train-chunked_<w>s_<s>s``, ``metadata_dev/...``, ``dev-valid`` / ``dev-test``, ``infer_pth``), the
+    same per-epoch file sampling without replacement (``sample_filelist_for_train_iter``, ``get_remaining_file`` /
+    ``init_remaining_file_from_list`` for resume) and the same CSV label reader -- but ``__getitem__`` stops before the
+    arithmetic: it returns ``(pcm int16 (T, 4), comb_no, label_rows)``.  Normalisation, rotation of the audio and the
+    features run on the GPU (``AudioStager`` -> ``rotate_audio`` -> ``FeatureExtractor``); the label half of the rotation
+    and the AD-YOLO label encoding stay here on the host, as in the reference's DataLoader workers."""
+
+    def __init__(self, params: dict, set_type: str, is_valid=False):
+        import copy
+        import os
+        import random
+        self._copy, self._os, self._random = copy, os, random
+        opj = os.path.join
+        self.is_valid, self.is_infer, self.set_type = is_valid, set_type == "infer", set_type
+        self.loss_nm = params["args"]["loss"]
+        dc = params["data_config"]
+        if set_type == "train":
+            sub = "dev-train-chunked_{}s_{}s".format(dc["chunk_window_s"], dc["chunk_stride_s"])
+            self.wav_pth, self.csv_pth = opj(dc["data_pth"], "foa_dev", sub), opj(dc["data_pth"], "metadata_dev", sub)
+            self.total_filelist = [i.replace(".wav", "") for i in os.listdir(self.wav_pth)]
+            self.remaining_file = copy.deepcopy(self.total_filelist)
+            self.nb_samples = params["train_config"]["batch_size"] * params["train_config"]["nb_iters"]
+            self.filelist = []
+            self.sample_filelist_for_train_iter()
+        else:
+            if self.is_infer:
+                self.wav_pth, self.csv_pth = str(params["args"]["infer_pth"]), None
+            else:
+                self.wav_pth = opj(dc["data_pth"], "foa_dev", "dev-{}".format(set_type))
+                self.csv_pth = opj(dc["data_pth"], "metadata_dev", "dev-{}".format(set_type))
+            self.filelist = [i.replace(".wav", "") for i in os.listdir(self.wav_pth)]
+        self.hop_label = int(dc.get("sr", 24000) * dc.get("label_hop_len_s", 0.1))
+        self.rotate = bool(params.get("aug_config", {}).get("rotation_augment", False)) and not is_valid
+        if self.loss_nm != "adyolo":
+            raise NotImplementedError("FoaDataset encodes AD-YOLO labels; use ClasswiseLabelEncoder for %s" % self.loss_nm)
+        self.encoder = YoloLabelEncoder(params)
+
+    def sample_filelist_for_train_iter(self):
+        """datasets.py:67-91, statement for statement (so that a seeded ``random`` draws the same files)."""
+        copy, random = self._copy, self._random
+        self.filelist = []
+        if len(self.remaining_file) >= self.nb_samples:
+            self.filelist = random.sample(self.remaining_file, self.nb_samples)
+            for fnm in self.filelist:
+                self.remaining_file.remove(fnm)
+        elif len(self.remaining_file) <= 0:
+            self.remaining_file = copy.deepcopy(self.total_filelist)
+            self.filelist = random.sample(self.remaining_file, self.nb_samples)
+            for fnm in self.filelist:
+                self.remaining_file.remove(fnm)
+        else:
+            random.shuffle(self.remaining_file)
+            pre_sampled = copy.deepcopy(self.remaining_file)
+            self.remaining_file = copy.deepcopy(self.total_filelist)
+            self.filelist = random.sample(self.remaining_file, self.nb_samples - len(pre_sampled))
+            for fnm in self.filelist:
+                self.remaining_file.remove(fnm)
+            self.filelist.extend(pre_sampled)
+
+    def init_remaining_file_from_list(self, remaining_file: list):
+        self.remaining_file = remaining_file
+
+    def get_remaining_file(self):
+        return self.remaining_file
+
+    def get_filelist(self):
+        return self.filelist
+
+    @staticmethod
+    def load_csv2dict(csv_pth):
+        """datasets.py:103-117: ``frame,class,source,azimuth,elevation`` (or cartesian x,y,z) rows -> {frame: [[...]]}."""
+        label = {}
+        with open(csv_pth, "r") as fid:
+            for line in fid:
+                words = line.strip().split(",")
+                if len(words) < 5:
+                    continue
+                frame_idx = int(words[0])
+                label.setdefault(frame_idx, []).append([int(words[1]), int(words[2])] + [float(w) for w in words[3:6]])
+        return label
+
+    def __len__(self):
+        return len(self.filelist)
+
+    def __getitem__(self, index):
+        from scipy.io import wavfile
+        from .augmentations import rotate_labels
+        name = self.filelist[index]
+        _, pcm = wavfile.read(self._os.path.join(self.wav_pth, name + ".wav"))          # int16 (T, 4)
+        label = {} if self.is_infer else self.load_csv2dict(self._os.path.join(self.csv_pth, name + ".csv"))
+        comb_no = 0
+        if self.rotate:
+            comb_no = int(self._random.uniform(0, 16))                                    # augmentations.py:76
+            label = rotate_labels(label, comb_no)
+        nb_label_frames = pcm.shape[0] // self.hop_label
+        return np.ascontiguousarray(pcm, dtype=np.int16), comb_no, self.encoder.get_yolo_label(label, nb_label_frames)
+
+
+def audio_collate_fn(batch):
+    """list of FoaDataset items -> (pcm int16 (B, T, 4) host tensor, comb_nos list, target (M, 7) float32); the target
+    rows are built exactly like ``collate_fn`` (datasets.py:164-184)."""
+    pcms, combs, labels = zip(*batch)
+    _, target = collate_fn([(np.zeros(1, dtype=np.float32), rows) for rows in labels])
+    return torch.stack([torch.from_numpy(p) for p in pcms], 0), list(combs), target

@@ -108,3 +108,36 @@ def train_one_epoch(params: dict, dataloader, model, optimizer, criterion, devic
         if params.get("args", {}).get("quick_test") and i == 4:
             break
     return float(total) / max(n, 1) if total is not None else 0.0
+
+
+def train_one_epoch_audio(params: dict, dataloader, trainer, stager=None, rotate=True):
+    """The raw-audio epoch: ``dataloader`` yields ``audio_collate_fn`` batches (pcm int16 (B,T,4), comb_nos, target); each is
+    staged to the GPU (int16 over PCIe on a side stream, double-buffered), converted, rotated and handed to
+    ``TrainStep.step`` (features + forward + loss + backward [+ all-reduce] + Adam).  Returns the mean loss with ONE
+    device sync at the end of the epoch (the reference syncs every iteration, train.py:57)."""
+    from .augmentations import rotate_audio
+    from .datasets import AudioStager
+    total, n = None, 0
+    it = iter(dataloader)
+    try:
+        pcm, combs, target = next(it)
+    except StopIteration:
+        return 0.0
+    if stager is None:
+        stager = AudioStager(pcm.shape[0], pcm.shape[1], trainer.flat.flat.device)
+    stager.stage(pcm)
+    while True:
+        audio = stager.get()
+        cur_combs, cur_target = combs, target
+        nxt = next(it, None)
+        if nxt is not None:                       # the next batch crosses PCIe while this step runs
+            pcm, combs, target = nxt
+            stager.stage(pcm)
+        if rotate and any(int(c) != 0 for c in cur_combs):
+            audio = rotate_audio(audio, cur_combs)
+        loss = trainer.step(audio, cur_target)
+        total = loss.detach().reshape(-1)[:1].clone() if total is None else total + loss.detach().reshape(-1)[:1]
+        n += 1
+        if nxt is None or (params.get("args", {}).get("quick_test") and n == 5):
+            break
+    return float(total) / max(n, 1)

@@ -286,3 +286,53 @@ def test_threshold_sweep_runs_the_model_once_and_keeps_the_first_minimum(tmp_pat
     assert Model.calls == 2 and len(table) == 9
     assert abs(new - 0.3) < 1e-9 and abs(post.conf_thresh - 0.3) < 1e-9 and abs(post.clss_thresh - 0.3) < 1e-9
     assert abs(loss - (7 * 4 * 64 * 1.5)) < 1e-3
+
+
+def _write_split(root, sub, names, n_samples, rs):
+    from scipy.io import wavfile
+    wdir, cdir = os.path.join(root, "foa_dev", sub), os.path.join(root, "metadata_dev", sub)
+    os.makedirs(wdir), os.makedirs(cdir)
+    for nm in names:
+        wavfile.write(os.path.join(wdir, nm + ".wav"), 24000, rs.randint(-3000, 3000, size=(n_samples, 4)).astype(np.int16))
+        with open(os.path.join(cdir, nm + ".csv"), "w") as f:
+            for fr in range(0, n_samples // 2400, 3):
+                f.write("%d,%d,0,%d,%d\n" % (fr, fr % 12, (fr * 37) % 360 - 180, (fr * 11) % 160 - 80))
+
+
+def test_raw_audio_dataset_mirrors_the_reference_harness(tmp_path):
+    """FoaDataset: reference directory layout, per-epoch sampling without replacement incl. the three refill branches of
+    datasets.py:67-91, resume hooks, CSV reader, label rotation + AD-YOLO encoding on the host; audio stays int16."""
+    import random
+    from adyolo_amd.augmentations import rotate_labels
+    from adyolo_amd.datasets import FoaDataset, audio_collate_fn
+    rs = np.random.RandomState(0)
+    names = ["clip%02d" % i for i in range(10)]
+    _write_split(str(tmp_path), "dev-train-chunked_1s_1s", names, 24000, rs)
+    _write_split(str(tmp_path), "dev-test", ["t0", "t1"], 48000, rs)
+    params = {"args": {"loss": "adyolo"}, "aug_config": {"rotation_augment": True},
+              "data_config": {"data_pth": str(tmp_path), "chunk_window_s": 1, "chunk_stride_s": 1, "nb_classes": 12},
+              "train_config": {"batch_size": 2, "nb_iters": 2, "grid_size": [45, 45], "g_overlap": 0.5}}
+    random.seed(4)
+    ds = FoaDataset(params, "train")
+    assert len(ds) == 4 and len(ds.get_remaining_file()) == 6 and not set(ds.get_filelist()) & set(ds.get_remaining_file())
+    ds.sample_filelist_for_train_iter()                                  # 6 left -> 4 taken
+    assert len(ds.get_remaining_file()) == 2
+    rest = list(ds.get_remaining_file())
+    ds.sample_filelist_for_train_iter()                                  # 2 left: both kept, 2 drawn from the refilled list
+    assert set(rest) <= set(ds.get_filelist()) and len(ds.get_filelist()) == 4 and len(ds.get_remaining_file()) == 8
+    ds.init_remaining_file_from_list([])
+    ds.sample_filelist_for_train_iter()                                  # empty: refill first
+    assert len(ds.get_remaining_file()) == 6
+    # one item: int16 audio untouched, label rotated with the drawn combination and encoded
+    random.seed(9)
+    pcm, comb, rows = ds[0]
+    random.seed(9)
+    assert comb == int(random.uniform(0, 16)) and pcm.dtype == np.int16 and pcm.shape == (24000, 4)
+    lab = FoaDataset.load_csv2dict(os.path.join(ds.csv_pth, ds.get_filelist()[0] + ".csv"))
+    assert rows == ds.encoder.get_yolo_label(rotate_labels(lab, comb), 10)
+    # evaluation split: no sampling, no rotation; collate builds the (M, 7) target like the reference collate_fn
+    te = FoaDataset(params, "test", is_valid=True)
+    assert sorted(te.get_filelist()) == ["t0", "t1"] and te[0][1] == 0
+    pcm_b, combs, target = audio_collate_fn([te[0], te[1]])
+    assert pcm_b.shape == (2, 48000, 4) and pcm_b.dtype == torch.int16 and combs == [0, 0]
+    assert target.shape[1] == 7 and set(target[:, 0].tolist()) == {0.0, 1.0}
