@@ -63,3 +63,28 @@ def sweep_conf_thresh(dataloader, filelist, model, criterion, postprocessor, sco
             new_thresh, best = th, seld
     postprocessor.set_conf_thresh(new_thresh)
     return new_thresh, table, (float(total) / max(n, 1) if total is not None else 0.0)
+
+
+def test_epoch_audio(dataset, model, features, criterion, postprocessor, device, output_pth):
+    """``test_epoch`` for a raw-audio ``FoaDataset`` split ('valid' / 'test' / 'infer'): one clip at a time like the
+    reference (B = 1, test.py:33-60), int16 audio normalised on the GPU, K1 features, encoder + head, loss, decode + NMS,
+    one CSV per clip named after the file.  Returns the mean loss (0 for 'infer', which has no labels)."""
+    from . import ops
+    from .datasets import audio_collate_fn
+    model.eval()
+    delete_and_create_folder(output_pth)
+    total, n = None, 0
+    names = dataset.get_filelist()
+    with torch.no_grad():
+        for i in range(len(dataset)):
+            pcm, _, rows = dataset[i]
+            t = (pcm.shape[0] // 600) * 600                   # whole hops, like nb_feature_frames in datasets.py:283-286
+            audio = ops.pcm16_to_f32(torch.from_numpy(pcm[:t]).to(device).contiguous()).view(1, t, 4)
+            output = model(features(audio, channels_last8=True), channels_last8=True)
+            if rows:
+                target = audio_collate_fn([(pcm, 0, rows)])[2]
+                loss = criterion(output, target)
+                total = loss.reshape(-1)[:1].clone() if total is None else total + loss.reshape(-1)[:1]
+                n += 1
+            write_seld_output_file(os.path.join(output_pth, names[i] + ".csv"), postprocessor.postprocess(output))
+    return float(total) / max(n, 1) if total is not None else 0.0

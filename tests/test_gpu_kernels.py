@@ -933,3 +933,47 @@ def test_raw_audio_epoch_end_to_end(ops, tmp_path):
         tot_abs += float(d.sum())
         tot_n += d.numel()
     assert tot_abs / tot_n <= 1e-4, "mean parameter difference %.2e" % (tot_abs / tot_n)
+
+
+def test_raw_audio_evaluation_writes_the_same_files_as_the_feature_path(ops, tmp_path):
+    """test_epoch_audio (WAV -> GPU normalise -> K1 -> model -> decode/NMS -> CSV) against test_epoch fed with features
+    computed from host-normalised audio: same loss, same prediction files."""
+    from scipy.io import wavfile
+    from adyolo_amd import test as atest
+    from adyolo_amd.datasets import FoaDataset, audio_collate_fn
+    from adyolo_amd.features import FeatureExtractor
+    from adyolo_amd.postprocess import LabelPostProcessor
+    from adyolo_amd.wrapper import WrapperCriterion, WrapperModel
+    rs = np.random.RandomState(2)
+    wdir, cdir = os.path.join(tmp_path, "foa_dev", "dev-test"), os.path.join(tmp_path, "metadata_dev", "dev-test")
+    os.makedirs(wdir), os.makedirs(cdir)
+    for i in range(2):
+        wavfile.write(os.path.join(wdir, "t%d.wav" % i), 24000, rs.randint(-8000, 8000, size=(48000 + 123 * i, 4)).astype(np.int16))
+        with open(os.path.join(cdir, "t%d.csv" % i), "w") as f:
+            for fr in range(0, 20, 3):
+                f.write("%d,%d,0,%d,%d\n" % (fr, fr % 12, (fr * 53) % 360 - 180, (fr * 9) % 100 - 50))
+    prm = _params()
+    prm["data_config"]["data_pth"] = str(tmp_path)
+    prm["train_config"].update({"conf_thresh": 0.3, "clss_thresh": 0.3, "unify_thresh": 15.0, "nms": "conn-merge"})
+    torch.manual_seed(8)
+    model = WrapperModel((1, 7, 80, 64), (), prm).to("cuda:0")
+    crit, post, fx = WrapperCriterion(prm), LabelPostProcessor(prm), FeatureExtractor(None, "cuda:0")
+    ds = FoaDataset(prm, "test", is_valid=True)
+    out_a, out_b = os.path.join(tmp_path, "out_audio"), os.path.join(tmp_path, "out_feat")
+    loss_a = atest.test_epoch_audio(ds, model, fx, crit, post, "cuda:0", out_a)
+    loader = []
+    for i in range(len(ds)):
+        pcm, _, rows = ds[i]
+        t = (pcm.shape[0] // 600) * 600
+        audio = torch.from_numpy((pcm[:t].astype(np.float64) / 32768.0 + 1e-8).astype(np.float32)).to("cuda:0").view(1, t, 4)
+        feat = fx(audio.contiguous(), channels_last8=False)                   # reference layout (1, 7, T, 64)
+        loader.append((feat, audio_collate_fn([(pcm, 0, rows)])[2]))
+    loss_b = atest.test_epoch(loader, ds.get_filelist(), model, crit, post, "cuda:0", out_b)
+    assert abs(loss_a - loss_b) <= 1e-4 * abs(loss_b)
+    for nm in ds.get_filelist():
+        a = open(os.path.join(out_a, nm + ".csv")).read().splitlines()
+        b = open(os.path.join(out_b, nm + ".csv")).read().splitlines()
+        assert len(a) == len(b)
+        for la, lb in zip(a, b):
+            fa, fb = la.split(","), lb.split(",")
+            assert fa[:3] == fb[:3] and np.allclose([float(v) for v in fa[3:]], [float(v) for v in fb[3:]], atol=1e-4)
