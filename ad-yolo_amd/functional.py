@@ -202,8 +202,8 @@ class SEBlockFn(torch.autograd.Function):
             q, wd, gd, meand, invstdd = t[21:26]
             dq, dgd, dbd = ops.bn_bwd(dr, q, gd, meand, invstdd, relu_mask=False)
             rows = n * h * w_
-            splits = max(1, min(64, rows // 4096))
-            dwd = ops.gemm(dq, p, c, cin, rows, c, cin, trans_a=True, trans_b=True, splits=splits).view(c, cin, 1, 1)
+            dwd = ops.gemm(dq, p, c, cin, rows, c, cin, trans_a=True, trans_b=True,
+                           splits=ops.wgrad_splits(c, cin, rows)).view(c, cin, 1, 1)
             dp_res = ops.gemm(dq, wd, rows, cin, c, c, cin, trans_b=True).view(n, h, w_, cin)
             dp = ops.conv3x3(da, wpk1d, cin, addend=dp_res)
         else:
@@ -267,7 +267,7 @@ class BiGRULayerFn(torch.autograd.Function):
         x2 = x.view(rows, cin)
         dgx, dgh = ops.gru_bwd(_c(dout), gates, hprev, whh)
         dgx2, dgh2, hp2 = dgx.view(rows, 768), dgh.view(rows, 768), hprev.view(rows, 256)
-        splits = max(1, min(64, rows // 2048))
+        splits = ops.wgrad_splits(384, 128, rows)
         grads = []
         dx = torch.empty_like(x2)
         for d, wih in enumerate((wih_f, wih_r)):
@@ -420,8 +420,8 @@ class ConvFn(torch.autograd.Function):
         rows = dy2.shape[0]
         col, _, _ = ops.im2col(x, kh, kw, stride[0], stride[1], padding[0], padding[1])
         kp = col.shape[1]
-        splits = max(1, min(64, rows // 4096))
-        dwk = ops.gemm(dy2, col, cout, kp, rows, cout, kp, trans_a=True, trans_b=True, splits=splits)
+        dwk = ops.gemm(dy2, col, cout, kp, rows, cout, kp, trans_a=True, trans_b=True,
+                       splits=ops.wgrad_splits(cout, kp, rows))
         dw = ops.unpack_wk(dwk, cout, cin, kh, kw)
         dx = None
         if ctx.needs_input_grad[0]:

@@ -143,6 +143,14 @@ def gemm(a, b, m, n, k, lda, ldb, trans_a=False, trans_b=False, bias=None, out=N
     return out
 
 
+def wgrad_splits(m, n, k):
+    """Split-K factor for a weight-gradient GEMM (m x n output, contraction k = rows of the batch): enough 128 x 64 output
+    tiles x splits to put ~2 workgroups on each of the 256 CUs, at least 512 contraction rows per split, at most 64."""
+    tiles = ((m + 127) // 128) * ((n + 63) // 64)
+    want = (512 + tiles - 1) // tiles
+    return max(1, min(64, want, k // 512))
+
+
 def linear(x2d, w, bias=None):
     """x2d [R][K] @ w[N][K]^T + bias."""
     _chk(x2d, w, bias)
@@ -156,8 +164,7 @@ def linear_bwd(x2d, w, dy2d, need_dx=True):
     r, k = x2d.shape
     n = w.shape[0]
     dx = gemm(dy2d, w, r, k, n, n, k, trans_b=True) if need_dx else None
-    splits = max(1, min(64, r // 2048))
-    dw = gemm(dy2d, x2d, n, k, r, n, k, trans_a=True, trans_b=True, splits=splits)
+    dw = gemm(dy2d, x2d, n, k, r, n, k, trans_a=True, trans_b=True, splits=wgrad_splits(n, k, r))
     db = colsum(dy2d)
     return dx, dw, db
 
