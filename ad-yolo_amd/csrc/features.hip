@@ -9,7 +9,8 @@
 // lanes; auto-sorting, ping-pong in LDS, twiddles from an LDS-resident table built in double
 // on the host), untangled into the four 601-bin spectra, turned into the 7 per-bin quantities
 // (|W|^2,|Y|^2,|Z|^2,|X|^2, Iy/E, Iz/E, Ix/E) in LDS, and contracted with the sparse (1165 non-zero)
-// triangular mel filters.  Audio samples are read once as float4 (all four channels of a sample).
+// triangular mel filters (per-piece partial sums in LDS, combined per filter in a fixed order: bit-reproducible).
+// Audio samples are read once as float4 (all four channels of a sample).
 // power_to_db's top_db=80 clip is relative to the maximum over the whole clip and channel, so the
 // un-clipped log-mel is written first with a float atomic-max per (clip, channel); adyolo_feat_finish
 // applies the clip and the z-score of the four log-mel channels.
@@ -133,7 +134,7 @@ __device__ __forceinline__ void atomic_max_float(float *addr, float val) {
     else atomicMin(reinterpret_cast<unsigned *>(addr), __float_as_uint(val));
 }
 
-constexpr int MAX_MELW = 1280, SPS8 = 8;
+constexpr int MAX_MELW = 1280, SPS8 = 8, MAX_CHUNKS = 160;
 
 __global__ __launch_bounds__(256, 3) void feat_stft_mel_kernel(
     const float *__restrict__ audio, const float *__restrict__ twiddle, const float *__restrict__ window,
@@ -147,13 +148,21 @@ __global__ __launch_bounds__(256, 3) void feat_stft_mel_kernel(
     __shared__ float2 bufA[2 * FN + 4];          // doubles as the [601][8] per-bin feature table after the last FFT stage
     __shared__ float2 bufB[2 * FN];
     __shared__ float melw[MAX_MELW];
-    __shared__ float melacc[NMEL * 8];
+    __shared__ float melpart[MAX_CHUNKS * 8];    // per-piece partial sums, combined per filter in piece order (deterministic)
+    __shared__ int mel_first[NMEL + 1];
     __shared__ float cmax[4][4];
     float *spec = reinterpret_cast<float *>(bufA);
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * FR;
     for (int i = tid; i < n_melw; i += 256) melw[i] = mel_w[i];
+    // pieces are stored filter after filter: first piece of every filter (filters without a piece get an empty range)
+    for (int m = tid; m <= NMEL; m += 256) {
+        int f = n_chunks;
+        for (int ck = n_chunks - 1; ck >= 0; --ck)
+            if (chunk_mel[ck] >= m) f = ck;
+        mel_first[m] = f;
+    }
     float lmax = -INFINITY;                       // lanes with (tid & 7) < 4 track channel tid & 7 (layout-independent)
     const float4 *aud = reinterpret_cast<const float4 *>(audio) + (size_t)b * n_samples;
     // audio of the next frame is prefetched into registers while the current frame is transformed
@@ -183,7 +192,6 @@ __global__ __launch_bounds__(256, 3) void feat_stft_mel_kernel(
                 bufA[FN + n] = make_float2(av[i].z * w, av[i].w * w);
             }
         }
-        for (int i = tid; i < NMEL * 8; i += 256) melacc[i] = 0.f;
         __syncthreads();
         if (fr + 1 < FR && t + 1 < T) load_frame(t + 1);
         fft_stage<10, 1>(bufA, bufB, tw, tid);
@@ -214,17 +222,20 @@ __global__ __launch_bounds__(256, 3) void feat_stft_mel_kernel(
             float s = 0.f;
 #pragma unroll 4
             for (int i = 0; i < ln; ++i) s += melw[of + i] * spec[(st + i) * SPS8 + c];
-            atomicAdd(&melacc[chunk_mel[ck] * 8 + c], s);
+            melpart[ck * 8 + c] = s;
         }
         __syncthreads();
         for (int o = tid; o < 512; o += 256) {
             const int m = o >> 3, c = o & 7;
+            float acc = 0.f;
+            if (c < 7)
+                for (int ck = mel_first[m]; ck < mel_first[m + 1]; ++ck) acc += melpart[ck * 8 + c];
             float v = 0.f;
             if (c < 4) {
-                v = 10.0f * log10f(fmaxf(melacc[o], 1e-10f));
+                v = 10.0f * log10f(fmaxf(acc, 1e-10f));
                 lmax = fmaxf(lmax, v);
             } else if (c < 7) {
-                v = (melacc[o] - sc_mean[c * NMEL + m]) * sc_rstd[c * NMEL + m];
+                v = (acc - sc_mean[c * NMEL + m]) * sc_rstd[c * NMEL + m];
             }
             if (layout == 1) out[(((size_t)b * T + t) * NMEL + m) * 8 + c] = v;
             else if (c < 7) out[(((size_t)b * 7 + c) * T + t) * NMEL + m] = v;
@@ -282,8 +293,9 @@ extern "C" int adyolo_feat_stft_mel(const float *audio, const float *twiddle, co
                    ADYOLO_EINVAL, "feat_stft_mel: null pointer");
     ADYOLO_REQUIRE(B > 0 && n_samples >= 1200 && n_samples % FHOP == 0 && (layout == 0 || layout == 1), ADYOLO_EINVAL,
                    "feat_stft_mel: n_samples=%d must be a multiple of 600 and >= 1200", n_samples);
-    ADYOLO_REQUIRE(n_chunks > 0 && n_mel_w > 0 && n_mel_w <= MAX_MELW, ADYOLO_ENOSUP,
-                   "feat_stft_mel: %d mel weights exceed the LDS table (%d)", n_mel_w, MAX_MELW);
+    ADYOLO_REQUIRE(n_chunks > 0 && n_chunks <= MAX_CHUNKS && n_mel_w > 0 && n_mel_w <= MAX_MELW, ADYOLO_ENOSUP,
+                   "feat_stft_mel: %d mel weights / %d pieces exceed the LDS tables (%d / %d)", n_mel_w, n_chunks, MAX_MELW,
+                   MAX_CHUNKS);
     hipStream_t st = as_stream(stream);
     const int T = n_samples / FHOP;
     hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(chan_max), (int)0xFF800000, (size_t)B * 4, st);

@@ -4,7 +4,7 @@
 //   1. assign : one lane per target row -> decode its cell's anchors, great-circle distance D[m][a],
 //               arg-min, threshold masks; marks anchors (bit sets), counts distinct positives per
 //               threshold with the value returned by atomicOr, accumulates the angular term and its
-//               (un-normalised) gradient on the u,v logits.
+//               (un-normalised) gradient on the u,v logits (fixed-point atomics: order-independent).
 //   2. main   : ONE pass over the logits, one lane per logit (coalesced): BCE terms of the three
 //               thresholds and dlogit written in the same pass (HBM traffic = read logits + write dlogits
 //               + 6 words per anchor of assignment state).
@@ -25,10 +25,20 @@ struct LossGeom {
 __device__ __forceinline__ float deg2rad_(float d) { return d * 0.017453292519943295f; }
 __device__ __forceinline__ float rad2deg_(float r) { return r * 57.29577951308232f; }
 
+// 32.32 fixed point for the order-independent accumulation of the angular gradient (|value| < 2^31, step 2.3e-10)
+__device__ __forceinline__ unsigned long long to_fixed(float v) {
+    const double c = fmin(fmax((double)v, -2147483000.0), 2147483000.0);
+    return (unsigned long long)__double2ll_rn(c * 4294967296.0);
+}
+__device__ __forceinline__ float from_fixed(unsigned long long q) {
+    return (float)((double)(long long)q * (1.0 / 4294967296.0));
+}
+
 __global__ __launch_bounds__(256) void loss_assign_kernel(const float *__restrict__ logit,
                                                           const float *__restrict__ target, LossGeom g,
                                                           unsigned *__restrict__ hdr, unsigned *__restrict__ pos_bits,
-                                                          unsigned *__restrict__ cls_bits, float *__restrict__ ang_grad,
+                                                          unsigned *__restrict__ cls_bits,
+                                                          unsigned long long *__restrict__ ang_grad,
                                                           float *__restrict__ ang_partial, float *__restrict__ dist,
                                                           long NA) {
     __shared__ float red_sum[4];
@@ -93,8 +103,10 @@ __global__ __launch_bounds__(256) void loss_assign_kernel(const float *__restric
                 if (bits & 1u) {          // angular term uses the first threshold only (loss.py:241-243)
                     my_sum += D[a] / 180.f;
                     my_pairs += 1;
-                    atomicAdd(&ang_grad[anchor * 2 + 0], gu[a] / 180.f);
-                    atomicAdd(&ang_grad[anchor * 2 + 1], gv[a] / 180.f);
+                    // several targets can share an anchor: their gradients are summed in 32.32 fixed point, so the
+                    // result does not depend on the order the atomics land in (bit-reproducible training steps)
+                    atomicAdd(&ang_grad[anchor * 2 + 0], to_fixed(gu[a] / 180.f));
+                    atomicAdd(&ang_grad[anchor * 2 + 1], to_fixed(gv[a] / 180.f));
                 }
             }
         }
@@ -122,7 +134,8 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const float *__restrict_
                                                         const unsigned *__restrict__ hdr,
                                                         const unsigned *__restrict__ pos_bits,
                                                         const unsigned *__restrict__ cls_bits,
-                                                        const float *__restrict__ ang_grad, float *__restrict__ dlogit,
+                                                        const unsigned long long *__restrict__ ang_grad,
+                                                        float *__restrict__ dlogit,
                                                         float *__restrict__ partial, long NA, float grad_scale) {
     __shared__ float red[4][9];
     const int CH = g.C + 3;
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const float *__restrict_
                 }
             }
         } else {
-            grad = wang * ang_grad[anchor * 2 + (ch - g.C - 1)];
+            grad = wang * from_fixed(ang_grad[anchor * 2 + (ch - g.C - 1)]);
         }
         if (dlogit) dlogit[e] = grad * grad_scale;
     }
@@ -226,10 +239,10 @@ constexpr int LOSS_MAIN_BLOCKS = 2048;
 
 using namespace adyolo;
 
-// workspace (32-bit words): [hdr 64][pos_bits NA][cls_bits 3*NA][ang_grad 2*NA][ang_partial ceil(M/256)][partial 9*2048]
+// workspace (32-bit words): [hdr 64][pos_bits NA][cls_bits 3*NA][ang_grad 2*NA x int64][ang_partial ceil(M/256)][partial 9*2048]
 extern "C" long adyolo_loss_workspace_words(int BT, int G, int A, int M) {
     const long NA = (long)BT * G * A;
-    return LOSS_HDR + 6 * NA + (long)cdiv(M > 0 ? M : 1, 256) + 9L * LOSS_MAIN_BLOCKS + 64;
+    return LOSS_HDR + 8 * NA + (long)cdiv(M > 0 ? M : 1, 256) + 9L * LOSS_MAIN_BLOCKS + 64;
 }
 
 extern "C" int adyolo_loss_fwd_bwd(const float *logit, const float *target, float *ws, float *loss, float *dlogit,
@@ -251,12 +264,12 @@ extern "C" int adyolo_loss_fwd_bwd(const float *logit, const float *target, floa
     unsigned *hdr = reinterpret_cast<unsigned *>(ws);
     unsigned *pos_bits = hdr + LOSS_HDR;
     unsigned *cls_bits = pos_bits + NA;
-    float *ang_grad = reinterpret_cast<float *>(cls_bits + 3 * NA);
-    float *ang_partial = ang_grad + 2 * NA;
+    unsigned long long *ang_grad = reinterpret_cast<unsigned long long *>(cls_bits + 3 * NA);   // 8-byte aligned: 64 + 4 NA words
+    float *ang_partial = reinterpret_cast<float *>(ang_grad + 2 * NA);
     const int nang = cdiv(M, 256);
     float *partial = ang_partial + nang;
 
-    hipError_t e = hipMemsetAsync(ws, 0, (size_t)(LOSS_HDR + 6 * NA) * 4, st);
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)(LOSS_HDR + 8 * NA) * 4, st);
     if (e != hipSuccess) {
         set_error("loss: memset failed: %s", hipGetErrorString(e));
         return (int)e;

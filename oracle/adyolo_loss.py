@@ -11,7 +11,8 @@ Restates ``/root/reference/src/models/loss.py:156-251`` (``ADYOLOloss``):
                            (``nn.BCELoss``: log clamped at -100)
   * total      :241-251   i == 0 adds angular_gain * mean(D[mask] / 180) over (target, anchor) pairs;
                            every i adds (object*pos + nonobj*neg + class*cls) / len(train_unify)
-Pinned by ``tests/golden/adyolo_loss.npz`` (loss, dlogits, D, masks of the real reference).
+Pinned by ``tests/golden/adyolo_loss.npz`` (loss value and dlogits of the real reference for three cases; the distance
+matrix D and the masks are not stored -- they are pinned indirectly through the loss and its gradient).
 """
 import math
 import torch

@@ -216,6 +216,89 @@ def gen_init():
     print("init_seed100.npz", len(names))
 
 
+SEED100_GRAD_KEYS = (
+    "encoder.conv1.weight", "encoder.conv1.bias", "encoder.bn1.weight", "encoder.bn1.bias",
+    "encoder.layer1.0.conv1.weight", "encoder.layer1.0.bn1.weight", "encoder.layer1.1.conv2.weight",
+    "encoder.layer1.2.se.fc.0.weight", "encoder.layer1.2.se.fc.2.bias", "encoder.layer2.0.conv1.weight",
+    "encoder.layer2.0.downsample.0.weight", "encoder.layer2.0.downsample.1.weight", "encoder.layer2.3.conv2.weight",
+    "encoder.layer2.3.bn2.bias", "encoder.layer3.0.conv1.weight", "encoder.layer3.2.bn1.weight",
+    "encoder.layer3.5.conv2.weight", "encoder.layer3.5.se.fc.2.weight", "encoder.layer4.0.conv1.weight",
+    "encoder.layer4.0.downsample.0.weight", "encoder.layer4.2.conv2.weight", "encoder.layer4.2.bn2.weight",
+    "encoder.attention.W.weight", "encoder.lstm.weight_ih_l0", "encoder.lstm.weight_hh_l0_reverse",
+    "encoder.lstm.bias_hh_l1", "encoder.lstm.weight_ih_l1_reverse", "encoder.norm.weight", "encoder.norm.bias",
+    "head.yolo_head.0.weight", "head.yolo_head.1.weight", "head.yolo_head.1.bias")
+
+
+def strided_sample(numel, n=4096):
+    """Indices of the <= n elements a seed-100 gradient fixture keeps of a flattened tensor."""
+    step = max(1, numel // n)
+    return np.arange(0, numel, step)[:n]
+
+
+def gen_seed100_train():
+    """One training step's forward / loss / gradients of the REAL reference at its training shape (2, 7, 800, 64) with its
+    default initialisation under torch.manual_seed(100) (main.py:47; wrapper.py:26-47 builds the encoder, then the head),
+    in float32 and -- the same modules cast to float64 -- in float64 (the yardstick for fp32 round-off).  Inputs are
+    reproduced from seeds (x: torch.Generator 31; the weights: the seed-100 init the build reproduces bit for bit), the
+    target rows are stored."""
+    from models.backbones.resnet import SEResnet34
+    from models.linearheads import ADYOLOhead
+    from models.loss import ADYOLOloss
+    from adyolo_amd.datasets import synthetic_targets          # generator of the (M, 7) rows only; the rows are stored
+    params = make_params()
+    torch.manual_seed(100)
+    enc = SEResnet34((1, 7, 800, 64), (), params)
+    head = ADYOLOhead(256, 256, 12, [45, 45], 5)
+    model = _Wrap(enc, head)
+    model.train()
+    enc.lstm.dropout = 0.0
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 7, 800, 64, generator=g)
+    target = synthetic_targets(2, 200, 12, seed=31)
+    out = {"x_seed": np.asarray(31), "x_sum": np.asarray(float(x.double().sum())), "x_head": x.reshape(-1)[:16].numpy(),
+           "target": target.numpy()}
+    crit = ADYOLOloss(params)
+
+    def run(m, xin):
+        for p in m.parameters():
+            p.grad = None
+        y = m.encoder(xin)
+        logit = m.head(y)
+        loss = crit(logit, target.to(xin.dtype))
+        loss.backward()
+        return y.detach(), logit.detach(), loss.detach()
+
+    m64 = copy.deepcopy(model).double()
+    y32, l32, loss32 = run(model, x)
+    sd_after = {k: v.clone() for k, v in model.state_dict().items()}
+    torch.set_default_dtype(torch.float64)      # the reference loss allocates its label tensors in the default dtype
+    try:
+        y64, l64, loss64 = run(m64, x.double())
+    finally:
+        torch.set_default_dtype(torch.float32)
+    out["y_train"] = y32.numpy()
+    out["y_train64_dev"] = np.asarray(float((y32.double() - y64).abs().max()))
+    li = strided_sample(l32.numel(), 65536)
+    out["logit_sample"] = l32.reshape(-1)[li].numpy()
+    out["logit_sample64"] = l64.reshape(-1)[li].numpy()
+    out["loss"] = loss32.numpy()
+    out["loss64"] = loss64.numpy()
+    n32, n64 = dict(model.named_parameters()), dict(m64.named_parameters())
+    for k in SEED100_GRAD_KEYS:
+        g32, g64 = n32[k].grad.reshape(-1), n64[k].grad.reshape(-1)
+        idx = strided_sample(g32.numel())
+        out["grad_" + k] = g32[idx].numpy()
+        out["grad64_" + k] = g64[idx].numpy()
+        out["gabs64_" + k] = np.asarray(float(g64.abs().max()))
+        out["gnoise_" + k] = np.asarray(float((g32.double() - g64).abs().max()) / max(float(g64.abs().max()), 1e-300))
+    for k in ("encoder.bn1.running_mean", "encoder.layer2.0.downsample.1.running_var", "encoder.layer4.2.bn2.running_mean"):
+        out["stat_" + k] = sd_after[k].numpy()
+    np.savez_compressed(os.path.join(HERE, "seed100_train.npz"), **out)
+    worst = max(float(out["gnoise_" + k]) for k in SEED100_GRAD_KEYS)
+    print("seed100_train.npz loss %.6f (fp64 %.6f) y dev %.2e worst reference fp32-vs-fp64 gradient deviation %.2e of absmax"
+          % (float(loss32), float(loss64), float(out["y_train64_dev"]), worst))
+
+
 def gen_other_losses():
     """SEDDOA / masked-SEDDOA / ACCDOA / ADPIT: labels from the reference encoders, loss + gradient from the reference losses."""
     from datasets import FeatureLabelProcessor
@@ -438,10 +521,14 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     _install_shims()
+    if "--only" in sys.argv:                 # e.g. --only gen_seed100_train
+        globals()[sys.argv[sys.argv.index("--only") + 1]]()
+        sys.exit(0)
     flp = gen_labels()
     gen_loss(flp)
     gen_encoder()
     gen_init()
+    gen_seed100_train()
     gen_other_losses()
     gen_postprocess()
     gen_metrics()

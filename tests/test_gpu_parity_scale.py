@@ -1,0 +1,295 @@
+"""GPU parity tests at REALISTIC shapes (run with ``-m gpu`` on an MI355X).
+
+tests/test_gpu_kernels.py compares every kernel with the oracle at sizes the oracle finishes instantly (B <= 7, T <= 150).
+This file covers what those sizes cannot see: the reference's own training shape (2, 7, 800, 64) under its default
+initialisation (golden from the REAL reference, float32 and float64), the reference's evaluation shape (1, 7, 2400, 64),
+and the benchmark shape (64 clips x 60 s: ~1 M convolution patches per launch, XCD block dealing, adaptive
+weight-gradient segments) through slice checks against torch on the host.  Everything goes through the C ABI.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import adyolo_amd  # noqa: F401
+    from adyolo_amd import ops as _ops
+    return _ops
+
+
+def _params(nb_classes=12):
+    return {"args": {"device": "cuda:0", "encoder": "se-resnet34", "loss": "adyolo"},
+            "data_config": {"nb_classes": nb_classes},
+            "train_config": {"grid_size": [45, 45], "nb_anchors": 5, "train_unify": [45.0, 25.0, 10.0], "g_overlap": 0.5,
+                             "loss_gains": {"angular_gain": 5.0, "object_gain": 1.0, "nonobj_gain": 5.0, "class_gain": 3.0},
+                             "optim": "Adam", "lr": 1e-3, "weight_decay": 0.0}}
+
+
+def strided_sample(numel, n=4096):
+    """Same rule as tests/golden/make_golden.py::strided_sample."""
+    step = max(1, numel // n)
+    return np.arange(0, numel, step)[:n]
+
+
+def _rel(got, ref):
+    return float((got.double() - ref.double()).abs().max()) / max(float(ref.double().abs().max()), 1e-300)
+
+
+# ------------------------------------------------------------------------------ the reference's training shape, default init
+@pytest.mark.parametrize("algo", ["direct", "winograd"])
+def test_seed100_training_step_matches_reference(ops, monkeypatch, algo):
+    """One training step at the reference's training shape (2, 7, 800, 64) with the reference's default initialisation
+    under torch.manual_seed(100) (src/main.py:47; the build's init is bit-identical, test_host_cpu.py), against
+    tests/golden/seed100_train.npz = the REAL reference in float32 and in float64 (resnet.py:180-199, linearheads.py:101-104,
+    loss.py:189-251, train.py:49-55).
+
+    Bars: encoder output, logits 1e-3 (north_star); loss 1e-3 relative; every sampled gradient tensor deviates from the
+    float64 reference by at most max(1e-3, 2 x the deviation of the reference's OWN float32 run from float64) of the
+    tensor's absmax, cosine >= 0.9999.  Both convolution algorithms (Winograd is the default and the benchmarked one)
+    must meet the same bar."""
+    monkeypatch.setenv("ADYOLO_CONV_ALGO", algo)
+    from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
+    g = np.load(os.path.join(G, "seed100_train.npz"))
+    prm = _params()
+    torch.manual_seed(100)
+    model = WrapperModel((1, 7, 800, 64), (), prm).to("cuda:0")
+    model.train()
+    model.encoder.lstm.dropout = 0.0
+    x = torch.randn(2, 7, 800, 64, generator=torch.Generator().manual_seed(int(g["x_seed"])))
+    assert abs(float(x.double().sum()) - float(g["x_sum"])) < 1e-6 and np.array_equal(x.reshape(-1)[:16].numpy(), g["x_head"])
+    target = torch.from_numpy(g["target"])
+    y = model.encoder(x.to("cuda:0"))
+    logit = model.head(y)
+    loss = WrapperCriterion(prm)(logit, target)
+    loss.backward()
+    torch.cuda.synchronize()
+    y_ref = torch.from_numpy(g["y_train"])
+    assert float((y.detach().cpu() - y_ref).abs().max()) <= 1e-3, "encoder output (tanh range) vs reference"
+    li = strided_sample(logit.numel(), 65536)
+    lg = logit.detach().cpu().reshape(-1)[li]
+    lref = torch.from_numpy(g["logit_sample"])
+    assert float((lg - lref).abs().max()) <= 1e-3 * max(1.0, float(lref.abs().max())), "logits vs reference"
+    assert abs(float(loss) - float(g["loss"])) <= 1e-3 * abs(float(g["loss"])), (float(loss), float(g["loss"]))
+    assert abs(float(loss) - float(g["loss64"])) <= 1e-4 * abs(float(g["loss64"]))
+    named = dict(model.named_parameters())
+    bad, report = [], []
+    for key in g.files:
+        if not key.startswith("grad64_"):
+            continue
+        name = key[len("grad64_"):]
+        t64 = torch.from_numpy(g[key])
+        idx = strided_sample(named[name].numel())
+        got = named[name].grad.reshape(-1).cpu()[idx].double()
+        am = float(g["gabs64_" + name])
+        ref_noise = float(g["gnoise_" + name])
+        mine = float((got - t64).abs().max()) / am
+        cos = float(torch.dot(got, t64) / (got.norm() * t64.norm()))
+        limit = max(1e-3, 2.0 * ref_noise)
+        report.append("%s %.2e (ref %.2e) cos %.7f" % (name, mine, ref_noise, cos))
+        if mine > limit or cos < 0.9999:
+            bad.append("%s: %.2e of absmax vs float64 (limit %.2e, reference float32 %.2e), cosine %.7f"
+                       % (name, mine, limit, ref_noise, cos))
+    print("[%s] " % algo + "\n".join(report))
+    assert not bad, "; ".join(bad)
+    sd = model.state_dict()
+    for key in g.files:
+        if key.startswith("stat_"):
+            ref = torch.from_numpy(g[key])
+            assert float((sd[key[5:]].cpu() - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), key
+
+
+def test_training_trajectories_direct_vs_winograd(ops, monkeypatch):
+    """40 Adam steps on a fixed synthetic batch (8 x 10 s raw audio, K1 included) with the direct and the Winograd
+    convolutions: identical loss at step 0 (1e-5), never more than 2e-3 apart relative, both decreasing
+    (reference loop: src/train.py:40-62)."""
+    import bench
+    from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
+    from adyolo_amd.features import FeatureExtractor
+    from adyolo_amd.datasets import synthetic_audio, synthetic_targets
+    from adyolo_amd.train import TrainStep
+
+    def run(algo, steps=40):
+        monkeypatch.setenv("ADYOLO_CONV_ALGO", algo)
+        torch.manual_seed(100)
+        prm = bench.params("cuda:0")
+        b, n = 8, 24000 * 10
+        t = n // 600
+        model = WrapperModel((1, 7, t, 64), (), prm).to("cuda:0")
+        model.encoder.lstm.dropout = 0.0
+        tr = TrainStep(model, WrapperCriterion(prm), FeatureExtractor(None, "cuda:0"), prm)
+        audio = synthetic_audio(b, n, seed=7).to("cuda:0")
+        target = synthetic_targets(b, t // 4, 12, seed=7).to("cuda:0")
+        losses = torch.stack([tr.step(audio, target).reshape(()) for _ in range(steps)])
+        return losses.cpu().double().numpy()
+
+    a, w = run("direct"), run("winograd")
+    assert np.all(np.isfinite(a)) and np.all(np.isfinite(w))
+    assert abs(a[0] - w[0]) <= 1e-5 * abs(a[0])
+    rel = np.abs(a - w) / np.abs(a)
+    print("direct %.5f -> %.5f, winograd %.5f -> %.5f, worst relative gap %.2e" % (a[0], a[-1], w[0], w[-1], rel.max()))
+    assert rel.max() <= 2e-3, rel
+    assert a[-1] < 0.7 * a[0] and w[-1] < 0.7 * w[0]
+
+
+# ------------------------------------------------------------------------------ the reference's evaluation shape
+def test_eval_forward_at_reference_test_shape(ops):
+    """Whole-clip evaluation forward, B = 1, T = 2400 (60 s; src/test.py:81 feeds one file at a time), default (Winograd)
+    convolutions, against the float32 CPU oracle on the same seed-100 weights: encoder output and logits 1e-3."""
+    from adyolo_amd.wrapper import WrapperModel
+    from oracle import seresnet as onet
+    torch.manual_seed(100)
+    model = WrapperModel((1, 7, 2400, 64), (), _params()).to("cuda:0")
+    # non-trivial running statistics (fresh BatchNorm buffers are 0 / 1)
+    gen = torch.Generator().manual_seed(3)
+    for k, v in model.state_dict().items():
+        if k.endswith("running_mean"):
+            v.copy_((torch.rand(v.shape, generator=gen) * 0.2 - 0.1).to(v.device))
+        elif k.endswith("running_var"):
+            v.copy_((torch.rand(v.shape, generator=gen) * 0.5 + 0.75).to(v.device))
+    model.eval()
+    x = torch.randn(1, 7, 2400, 64, generator=gen)
+    with torch.no_grad():
+        y = model.encoder(x.to("cuda:0"))
+        logit = model.head(y)
+    torch.cuda.synchronize()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    enc, head = onet.split_state_dict(sd)
+    with torch.no_grad():
+        y_ref = onet.encoder_forward(enc, x, training=False)
+        l_ref = onet.adyolo_head(head, y_ref)
+    assert y.shape == (1, 600, 256) and logit.shape == (1, 600, 2400)
+    e_y = float((y.cpu() - y_ref).abs().max())
+    e_l = float((logit.cpu() - l_ref).abs().max())
+    print("T=2400 eval: encoder err %.2e, logit err %.2e (absmax %.2f)" % (e_y, e_l, float(l_ref.abs().max())))
+    assert e_y <= 1e-3 and e_l <= 1e-3 * max(1.0, float(l_ref.abs().max()))
+
+
+# ------------------------------------------------------------------------------ benchmark shape: convolution slice checks
+BENCH_STAGES = [  # (Cin, Cout, H, W) of the 3x3 convolutions of stages 1-4 at 64 clips x 60 s
+    (32, 32, 2400, 64), (64, 64, 1200, 32), (128, 128, 600, 16), (256, 256, 600, 16), (32, 64, 1200, 32)]
+
+
+@pytest.mark.parametrize("cin,cout,h,w", BENCH_STAGES)
+@pytest.mark.parametrize("algo", ["winograd", "direct"])
+def test_conv3x3_at_bench_shape_slices(ops, algo, cin, cout, h, w):
+    """conv3x3 forward, data-gradient and weight-gradient launched at the FULL benchmark shape (N = 64 clips); forward and
+    data-gradient are compared on two clips x 64 rows (first clip/top rows incl. the zero padding, last clip/an interior
+    window crossing patch boundaries) with F.conv2d on the slice (2e-5 of absmax), the weight-gradient on an 8 x 8
+    (Cout, Cin) block against a float64 contraction over ALL N*H*W pixels (5e-5 of absmax: 9.8 M-term fp32 sums)."""
+    n = 64
+    gen = torch.Generator(device="cuda:0").manual_seed(cin * 7 + cout)
+    x = torch.randn(n, h, w, cin, generator=gen, device="cuda:0")
+    dy = torch.randn(n, h, w, cout, generator=gen, device="cuda:0")
+    wt = (torch.randn(cout, cin, 3, 3, generator=gen, device="cuda:0") / np.sqrt(9 * cin)).contiguous()
+    wf, wd = ops.pack_w3x3(wt, cin, algo=algo)
+    y = ops.conv3x3(x, wf, cout)
+    dx = ops.conv3x3(dy, wd, cin)
+    dw = ops.conv3x3_wgrad(x, dy, cin, algo=algo)
+    torch.cuda.synchronize()
+    wc = wt.cpu()
+    wflip = wc.flip(2, 3).permute(1, 0, 2, 3).contiguous()            # data-gradient = convolution with flipped, transposed taps
+    for clip, r0 in ((0, 0), (n - 1, h // 2 - 29)):
+        lo, hi = max(r0 - 1, 0), min(r0 + 65, h)                      # one halo row each side where the image has one
+        for src, kern, out, what in ((x, wc, y, "forward"), (dy, wflip, dx, "data-gradient")):
+            xin = src[clip, lo:hi].cpu().permute(2, 0, 1)[None]       # (1, C, rows, W)
+            ref = F.conv2d(xin.double(), kern.double(), padding=1)[0].permute(1, 2, 0)
+            top = r0 - lo
+            ref = ref[top:top + 64]
+            # (the slice's own zero padding is only right at image borders: interior windows carry a halo row, dropped above)
+            got = out[clip, r0:r0 + 64].cpu()
+            e = _rel(got, ref)
+            assert e <= 2e-5, "%s %s clip %d rows %d..%d: %.2e of absmax" % (algo, what, clip, r0, r0 + 64, e)
+    # weight gradient block [co0:co0+8, ci0:ci0+8] over every pixel of the batch, float64 on the host
+    co0, ci0 = cout - 8, cin // 2
+    ref = torch.zeros(8, 8, 3, 3, dtype=torch.float64)
+    for b0 in range(0, n, 8):
+        xs = x[b0:b0 + 8, :, :, ci0:ci0 + 8].cpu().double()
+        ds = dy[b0:b0 + 8, :, :, co0:co0 + 8].cpu().double()
+        xp = F.pad(xs, (0, 0, 1, 1, 1, 1))
+        for kh in range(3):
+            for kw in range(3):
+                ref[:, :, kh, kw] += torch.einsum("nhwo,nhwi->oi", ds, xp[:, kh:kh + h, kw:kw + w, :])
+    e = _rel(dw[co0:co0 + 8, ci0:ci0 + 8].cpu(), ref)
+    assert e <= 5e-5, "%s weight-gradient block: %.2e of absmax" % (algo, e)
+
+
+def test_stem_conv_at_bench_shape_slices(ops):
+    """The 8-channel stem (direct kernel, bias + ReLU + per-patch BatchNorm sums) at N = 64, H = 2400, W = 64."""
+    n, h, w = 64, 2400, 64
+    gen = torch.Generator(device="cuda:0").manual_seed(5)
+    x = torch.randn(n, h, w, 8, generator=gen, device="cuda:0")
+    x[..., 7] = 0.0
+    wt = (torch.randn(32, 7, 3, 3, generator=gen, device="cuda:0") / np.sqrt(63)).contiguous()
+    b = torch.randn(32, generator=gen, device="cuda:0")
+    wpk, _ = ops.pack_w3x3(wt, 8, want_dgrad=False)
+    y, st = ops.conv3x3(x, wpk, 32, bias=b, relu=True, want_stats=True)
+    torch.cuda.synchronize()
+    for clip, r0 in ((0, 0), (n - 1, h - 64)):
+        lo, hi = max(r0 - 1, 0), min(r0 + 65, h)
+        xin = x[clip, lo:hi, :, :7].cpu().permute(2, 0, 1)[None].double()
+        ref = F.relu(F.conv2d(xin, wt.cpu().double(), b.cpu().double(), padding=1))[0].permute(1, 2, 0)
+        ref = ref[r0 - lo:r0 - lo + 64]
+        assert _rel(y[clip, r0:r0 + 64].cpu(), ref) <= 2e-5
+    # per-patch sums add up to the channel sums of the whole output (the BatchNorm statistics come from them)
+    tot = st[0].double().sum(0).cpu()
+    ref = y.double().sum(dim=(0, 1, 2)).cpu()
+    assert float((tot - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+
+
+# ------------------------------------------------------------------------------ benchmark shape: loss
+def test_adyolo_loss_at_bench_shape(ops):
+    """AD-YOLO loss + dlogit at B = 64, T' = 600 (M ~ 130 k rows, 92 M logits) against the CPU oracle (loss.py:189-251)."""
+    from adyolo_amd.datasets import synthetic_targets
+    from oracle import adyolo_loss as oloss
+    b, t = 64, 600
+    gen = torch.Generator().manual_seed(17)
+    logit = torch.randn(b, t, 2400, generator=gen) * 1.5
+    target = synthetic_targets(b, t, 12, seed=17)
+    loss, dlogit, _ = ops.adyolo_loss(logit.to("cuda:0"), target.to("cuda:0"), 12)
+    torch.cuda.synchronize()
+    lo = logit.clone().requires_grad_(True)
+    ref = oloss.adyolo_loss(lo, target, 12)
+    ref.backward()
+    print("M = %d rows; loss %.6f vs oracle %.6f" % (target.shape[0], float(loss), float(ref)))
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    g = lo.grad
+    am = float(g.abs().max())
+    assert float((dlogit.cpu() - g).abs().max()) <= 1e-3 * am
+
+
+def test_bench_shape_step_loss_direct_vs_winograd(ops, monkeypatch):
+    """First training-step loss at the benchmark workload (64 clips x 60 s raw audio, K1 -> encoder -> head -> loss) with
+    the Winograd (default, benchmarked) and the direct convolutions: 1e-3 relative (measured ~1e-6)."""
+    import bench
+    from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
+    from adyolo_amd.features import FeatureExtractor
+    from adyolo_amd.datasets import synthetic_audio, synthetic_targets
+    b, n = 64, 24000 * 60
+    t = n // 600
+    audio = synthetic_audio(b, n, seed=1234).to("cuda:0")
+    target = synthetic_targets(b, t // 4, 12, seed=1234).to("cuda:0")
+    fx = FeatureExtractor(None, "cuda:0")
+    vals = {}
+    for algo in ("winograd", "direct"):
+        monkeypatch.setenv("ADYOLO_CONV_ALGO", algo)
+        torch.manual_seed(100)
+        prm = bench.params("cuda:0")
+        model = WrapperModel((1, 7, t, 64), (), prm).to("cuda:0")
+        model.train()
+        with torch.no_grad():
+            out = model(fx(audio, channels_last8=True), channels_last8=True)
+            vals[algo] = float(WrapperCriterion(prm)(out, target))
+        del model, out
+        torch.cuda.empty_cache()
+    print(vals)
+    assert np.isfinite(vals["winograd"]) and abs(vals["winograd"] - vals["direct"]) <= 1e-3 * abs(vals["direct"])

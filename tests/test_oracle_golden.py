@@ -184,6 +184,55 @@ def test_feature_shapes_and_topdb():
     assert g["mel_mean"].shape == (1, 64, 4) and g["iv_std"].shape == (1, 64, 3)
 
 
+def test_logmel_end_to_end_matches_transformers_spectrogram():
+    """One independent END-TO-END check of STFT -> |.|^2 -> mel -> power_to_db(top_db=80): transformers' librosa-compatible
+    ``spectrogram(..., power=2, center=True, pad_mode='reflect', log_mel='dB', db_range=80)`` with its own Slaney filter
+    bank (datasets.py:252-267 + librosa 0.8.1 stft / filters.mel / power_to_db).  This does not pin the oracle to
+    librosa (it stays "parity unpinned"), it removes the chance of an error private to the restatement."""
+    au = pytest.importorskip("transformers.audio_utils")
+    rng = np.random.default_rng(8)
+    # a loud burst on a quiet floor: the top_db clip is active (dynamic range > 80 dB)
+    audio = rng.normal(0, 1e-5, size=(9600, 2))
+    audio[2400:3600] += rng.normal(0, 0.3, size=(1200, 2))
+    spec = ofeat.stft(audio)
+    mel = ofeat.logmel(spec, ofeat.mel_filterbank())                       # (T, 64, C)
+    filt = au.mel_filter_bank(601, 64, 0.0, 12000.0, 24000, norm="slaney", mel_scale="slaney").astype(np.float32)
+    win = au.window_function(1200, "hann", periodic=True)
+    clipped = 0
+    for ch in range(2):
+        ref = au.spectrogram(audio[:, ch], win, frame_length=1200, hop_length=600, fft_length=1200, power=2.0, center=True,
+                             pad_mode="reflect", onesided=True, mel_filters=filt, mel_floor=1e-10, log_mel="dB",
+                             reference=1.0, min_value=1e-10, db_range=None, dtype=np.float64)     # (64, T + 1)
+        ref = ref[:, :mel.shape[0]].T
+        # the clip is relative to the maximum of the frames the reference keeps (datasets.py:257 drops the last one first)
+        ref = np.maximum(ref, ref.max() - 80.0)
+        np.testing.assert_allclose(mel[:, :, ch], ref, rtol=0, atol=1e-6)
+        clipped += int((mel[:, :, ch] == mel[:, :, ch].max() - 80.0).sum())
+    assert clipped > 0, "the test signal must exercise the top_db clip"
+
+
+def test_power_to_db_hand_computed():
+    """librosa.power_to_db(S, ref=1.0, amin=1e-10, top_db=80) on three bins worked by hand: 10 log10(1e3) = 30,
+    10 log10(1e-3) = -30, amin floor 10 log10(1e-10) = -100 -> clipped to max - 80 = -50."""
+    s = np.array([[1e3, 1e-3, 1e-14]])
+    np.testing.assert_allclose(ofeat.power_to_db(s), [[30.0, -30.0, -50.0]], rtol=0, atol=1e-12)
+    # without a value within 80 dB of the floor nothing is clipped; the floor itself is amin
+    np.testing.assert_allclose(ofeat.power_to_db(np.array([1e-9, 0.0, 1e-12])), [-90.0, -100.0, -100.0], rtol=0, atol=1e-12)
+    # the clip follows the maximum of the WHOLE array handed in (one (T, 64) channel of one clip, datasets.py:265)
+    two = ofeat.power_to_db(np.array([[1.0, 1e-9], [1e2, 1e-9]]))
+    np.testing.assert_allclose(two, [[0.0, -60.0], [20.0, -60.0]], rtol=0, atol=1e-12)
+
+
+def test_intensity_vector_hand_computed():
+    """datasets.py:269-279 on one bin by hand: W = 1+1j, Y = 2, Z = -1j, X = 0: I = Re(conj(W) [Y, Z, X]) = [2, -1, 0],
+    E = 1e-8 + |W|^2 + (|Y|^2 + |Z|^2 + |X|^2) / 3 = 1e-8 + 2 + 5/3; an identity 'mel' matrix leaves I / E."""
+    spec = np.zeros((1, 1, 4), dtype=np.complex128)
+    spec[0, 0] = [1 + 1j, 2.0, -1j, 0.0]
+    iv = ofeat.foa_intensity(spec, np.ones((1, 1), dtype=np.float32))
+    e = 1e-8 + 2.0 + 5.0 / 3.0
+    np.testing.assert_allclose(iv[0, 0], [2.0 / e, -1.0 / e, 0.0], rtol=0, atol=1e-15)
+
+
 # ---- the other --loss plugins (SEDDOA / masked-SEDDOA / ACCDOA / ADPIT) -------------------------------------
 OTHER_EVENTS = {0: [[3, 0, 10.0, 5.0]], 1: [[3, 0, 10.0, 5.0], [7, 1, -170.0, 40.0]],
                 2: [[0, 0, 180.0, -30.0], [0, 1, 175.0, -35.0]],
