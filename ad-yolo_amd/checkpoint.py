@@ -13,16 +13,24 @@ import numpy as np
 import torch
 
 
-def get_rng_state(device):
+def get_rng_state(device, model=None):
+    """utility.py:32-39 plus, when ``model`` is given, the encoders' counter-based dropout streams (``rng.DropoutStream``:
+    they replace the draws the reference takes from torch's generator)."""
     dev = torch.device(device)
     state = {"rand_state": random.getstate(), "numpy_state": np.random.get_state(),
              "torch_state": torch.random.get_rng_state(), "os_hash_state": str(os.environ.get("PYTHONHASHSEED", "100"))}
+    if model is not None:
+        from . import rng
+        state["dropout_streams"] = rng.collect(model)
     state["cuda_state"] = torch.cuda.get_rng_state(device=dev) if dev.type == "cuda" and torch.cuda.is_available() else None
     return state
 
 
-def seed_resume(rng_state, device):
+def seed_resume(rng_state, device, model=None):
     dev = torch.device(device)
+    if model is not None and rng_state.get("dropout_streams"):
+        from . import rng
+        rng.restore(model, rng_state["dropout_streams"])
     random.setstate(rng_state["rand_state"])
     np.random.set_state(rng_state["numpy_state"])
     torch.random.set_rng_state(rng_state["torch_state"])
@@ -36,7 +44,7 @@ def optimizer_state_dict(optimizer, model):
     ``optimizer.state_dict()`` uses), independent of the flat buffer's internal (reversed) order."""
     flat = optimizer.flat
     where = {id(p): k for k, p in enumerate(flat.params)}
-    params = [p for p in model.parameters() if p.requires_grad]
+    params = [p for p in model.parameters() if p.requires_grad] if model is not None else flat.module_params
     state = {}
     for i, p in enumerate(params):
         off, n = flat.offsets[where[id(p)]]
@@ -53,7 +61,7 @@ def optimizer_state_dict(optimizer, model):
 def load_optimizer_state_dict(optimizer, model, sd):
     flat = optimizer.flat
     where = {id(p): k for k, p in enumerate(flat.params)}
-    params = [p for p in model.parameters() if p.requires_grad]
+    params = [p for p in model.parameters() if p.requires_grad] if model is not None else flat.module_params
     g = sd["param_groups"][0]
     if len(g["params"]) != len(params):
         raise ValueError("optimizer state has %d parameters, the model %d" % (len(g["params"]), len(params)))
@@ -83,7 +91,7 @@ def save_checkpoint(path, model, optimizer, start_epoch_nb, conf_thresh, best_lo
     torch.save({"start_epoch_nb": start_epoch_nb,
                 "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
                 "optim_state_dict": optimizer_state_dict(optimizer, model),
-                "confidence_thresh": float(conf_thresh), "rng_state": get_rng_state(device), "best_log": best_log,
+                "confidence_thresh": float(conf_thresh), "rng_state": get_rng_state(device, model), "best_log": best_log,
                 "train_remaining_file": train_remaining_file}, path)
 
 
@@ -100,5 +108,5 @@ def load_checkpoint(path, model, optimizer=None, device="cpu", restore_rng=True)
     if optimizer is not None and "optim_state_dict" in ck:
         load_optimizer_state_dict(optimizer, model, ck["optim_state_dict"])
     if restore_rng and ck.get("rng_state") is not None:
-        seed_resume(ck["rng_state"], device)
+        seed_resume(ck["rng_state"], device, model)
     return ck

@@ -177,6 +177,12 @@ class AudioStager:
         self.cur = 0
 
     def stage(self, clips):
+        if len(clips) != self.shape[0]:
+            raise ValueError("AudioStager: %d clips staged into a buffer of batch %d (a short final batch would leave "
+                             "stale audio in the tail rows; use drop_last or a stager of that size)" % (len(clips), self.shape[0]))
+        for clip in clips:
+            if tuple(clip.shape) != self.shape[1:]:
+                raise ValueError("AudioStager: clip of shape %s, expected %s" % (tuple(clip.shape), self.shape[1:]))
         i = self.cur ^ 1
         h = self.host[i]
         if self.consumed[i] is not None:
@@ -210,11 +216,22 @@ class FoaDataset(torch.utils.data.Dataset):
     features run on the GPU (``AudioStager`` -> ``rotate_audio`` -> ``FeatureExtractor``); the label half of the rotation
     and the AD-YOLO label encoding stay here on the host, as in the reference's DataLoader workers."""
 
-    def __init__(self, params: dict, set_type: str, is_valid=False):
+    def __init__(self, params: dict, set_type: str, is_valid=False, rank=None, world=None):
+        """rank / world: data-parallel shard (default: torch.distributed if initialised, else RANK / WORLD_SIZE, else 0 / 1).
+        Every rank draws the SAME global file list (``batch_size * world * nb_iters`` files from the shared ``random`` seed,
+        so ``remaining_file`` stays identical everywhere and the rank-0 checkpoint describes all ranks) and keeps the files
+        ``rank, rank + world, ...`` of it: the shards are disjoint and together equal the single-process draw."""
         import copy
         import os
         import random
         self._copy, self._os, self._random = copy, os, random
+        if world is None:
+            import torch.distributed as tdist
+            if tdist.is_available() and tdist.is_initialized():
+                rank, world = tdist.get_rank(), tdist.get_world_size()
+            else:
+                rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank, self.world = int(rank or 0), int(world)
         opj = os.path.join
         self.is_valid, self.is_infer, self.set_type = is_valid, set_type == "infer", set_type
         self.loss_nm = params["args"]["loss"]
@@ -224,7 +241,7 @@ class FoaDataset(torch.utils.data.Dataset):
             self.wav_pth, self.csv_pth = opj(dc["data_pth"], "foa_dev", sub), opj(dc["data_pth"], "metadata_dev", sub)
             self.total_filelist = [i.replace(".wav", "") for i in os.listdir(self.wav_pth)]
             self.remaining_file = copy.deepcopy(self.total_filelist)
-            self.nb_samples = params["train_config"]["batch_size"] * params["train_config"]["nb_iters"]
+            self.nb_samples = params["train_config"]["batch_size"] * params["train_config"]["nb_iters"] * self.world
             self.filelist = []
             self.sample_filelist_for_train_iter()
         else:
@@ -234,6 +251,8 @@ class FoaDataset(torch.utils.data.Dataset):
                 self.wav_pth = opj(dc["data_pth"], "foa_dev", "dev-{}".format(set_type))
                 self.csv_pth = opj(dc["data_pth"], "metadata_dev", "dev-{}".format(set_type))
             self.filelist = [i.replace(".wav", "") for i in os.listdir(self.wav_pth)]
+            if self.world > 1:                   # evaluation files are dealt round-robin over the ranks (sorted: listdir order is not a contract)
+                self.filelist = sorted(self.filelist)[self.rank::self.world]
         self.hop_label = int(dc.get("sr", 24000) * dc.get("label_hop_len_s", 0.1))
         self.rotate = bool(params.get("aug_config", {}).get("rotation_augment", False)) and not is_valid
         if self.loss_nm != "adyolo":
@@ -261,6 +280,8 @@ class FoaDataset(torch.utils.data.Dataset):
             for fnm in self.filelist:
                 self.remaining_file.remove(fnm)
             self.filelist.extend(pre_sampled)
+        if self.world > 1:                       # this rank's shard of the global draw
+            self.filelist = self.filelist[self.rank::self.world]
 
     def init_remaining_file_from_list(self, remaining_file: list):
         self.remaining_file = remaining_file

@@ -40,6 +40,8 @@ class FlatParameters:
 
     def __init__(self, module, reverse=True):
         params = [p for p in module.parameters() if p.requires_grad]
+        self.module_params = params             # module.parameters() order (= torch.optim state_dict indexing)
+        self.buffers = [b for b in module.buffers() if b.is_floating_point()]      # BatchNorm running statistics
         # backward produces gradients roughly in reverse registration order: put the last layers first so
         # that bucket 0 fills first
         self.params = list(reversed(params)) if reverse else params
@@ -58,6 +60,23 @@ class FlatParameters:
             p.grad = self.flat_grad[off:off + n].view_as(p.data)
             self.offsets.append((off, n))
             off += n
+
+    def broadcast(self, src=0, group=None):
+        """Start-up consistency under data parallelism: every rank takes rank ``src``'s parameters and floating-point
+        buffers (BatchNorm running statistics), so a differing seed or a partial load cannot diverge silently."""
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.broadcast(self.flat, src, group=group)
+            for b in self.buffers:
+                dist.broadcast(b, src, group=group)
+
+    def average_buffers(self, group=None):
+        """BatchNorm running statistics are per-rank under DDP-conventional semantics; average them over the ranks (e.g.
+        before rank 0 writes a checkpoint) so the saved statistics describe the whole data stream, not one shard."""
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            w = dist.get_world_size(group)
+            for b in self.buffers:
+                dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
+                b.div_(w)
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -92,6 +111,8 @@ class BucketedAllReduce:
         self._pending = [0] * len(self.buckets)
         self._works = []
         self._hooks = []
+        self.fired_from_hooks = 0            # buckets whose all-reduce was issued by a gradient hook (overlapped with backward)
+        self.fired_from_finish = 0           # buckets finish() had to launch (their gradients never all arrived)
         if self.active:
             for i, p in enumerate(flat.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
@@ -106,6 +127,7 @@ class BucketedAllReduce:
             b = self._bucket_of[idx]
             self._pending[b] -= 1
             if self._pending[b] == 0:
+                self.fired_from_hooks += 1
                 self._launch(b)
         return hook
 
@@ -118,9 +140,10 @@ class BucketedAllReduce:
         """Wait for all bucket reductions (launching any that never fired, e.g. unused parameters) and return
         the factor the optimizer must apply to the summed gradients (1/world)."""
         if self.active:
-            for b, left in enumerate(self._pending):
+            for b, left in enumerate(self._pending):          # bucket-index order: identical on every rank
                 if left > 0:
                     self._pending[b] = 0
+                    self.fired_from_finish += 1
                     self._launch(b)
             for w in self._works:
                 w.wait()

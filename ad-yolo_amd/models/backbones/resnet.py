@@ -14,6 +14,7 @@ import torch.nn as nn
 
 from ... import functional as Fn
 from ... import ops
+from ...rng import DropoutStream
 
 LAYERS = (3, 4, 6, 3)
 WIDTHS = (32, 64, 128, 256)
@@ -151,9 +152,9 @@ class SEResnet34(nn.Module):
         self.attention = AttentionParams(WIDTHS[-1])
         self.lstm = GRUParams(WIDTHS[-1], WIDTHS[-1] // 2, 2)
         self.norm = LayerNormParams(WIDTHS[-1])
-        # dropout stream of the inter-layer GRU dropout (counter based: seed, running offset)
-        self.dropout_seed = 0x5EED
-        self._dropout_offset = 0
+        # dropout stream of the inter-layer GRU dropout (counter based: seed from torch.initial_seed() and the rank,
+        # running offset; saved / restored with the checkpoint's rng_state)
+        self.dropout_stream = DropoutStream(0x5EED)
         self.dropout_mask_override = None       # tests inject a (B,T',256) mask here
 
     def _dropout(self, y):
@@ -163,8 +164,7 @@ class SEResnet34(nn.Module):
         if self.dropout_mask_override is not None:
             mask = self.dropout_mask_override.to(y.device, torch.float32).contiguous()
         else:
-            mask = ops.dropout_mask(y, p, self.dropout_seed, self._dropout_offset)
-            self._dropout_offset += y.numel()
+            mask = self.dropout_stream.mask(y, p)
         return Fn.DropoutFn.apply(y, mask)
 
     def forward(self, x, channels_last8=False):

@@ -18,19 +18,8 @@ import torch.nn as nn
 
 from ... import functional as Fn
 from ... import ops
+from ...rng import DropoutStream
 from .resnet import BatchNormParams, ConvParams, LayerNormParams, LinearParams
-
-
-class _Counter:
-    """Counter-based dropout stream shared by the encoder (seed, running offset)."""
-
-    def __init__(self, seed=0xC0F0):
-        self.seed, self.offset = seed, 0
-
-    def mask(self, like, p):
-        m = ops.dropout_mask(like, p, self.seed, self.offset)
-        self.offset += like.numel()
-        return m
 
 
 def _dropout(x, p, training, rng):
@@ -239,7 +228,7 @@ class ResnetConformer(nn.Module):
         self.conformer = ConformerEncoder(8, 256, 4, 4, 0.2, 0.2)
         self.t_pooling = PoolingModule(4, 256)
         self.enc_out_dim = 256
-        self._rng = _Counter()
+        self._rng = DropoutStream(0xC0F0)
 
     def forward(self, x, channels_last8=False):
         """x: (B, 7, T, F) float32 on the GPU (reference layout), or (B, T, F, 8) when ``channels_last8``."""

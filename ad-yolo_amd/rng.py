@@ -1,0 +1,57 @@
+"""Counter-based dropout streams of the encoders (the reference draws its dropout masks from torch's global generator,
+src/models/backbones/resnet.py:153, resnet_conformer.py:46-47,199-206; its checkpoints restore that generator,
+src/utils/utility.py:32-50).  A stream here is (seed, running offset): the seed follows ``torch.initial_seed()`` (what
+``torch.manual_seed`` / the reference's ``seed_init`` set) and the data-parallel rank, so ranks draw different masks;
+``state()`` / ``set_state()`` go into the checkpoint's ``rng_state`` so a resumed run replays the same masks."""
+import os
+
+import torch
+import torch.distributed as dist
+
+_MASK64 = (1 << 64) - 1
+
+
+class DropoutStream:
+    def __init__(self, salt):
+        self.salt = int(salt)
+        self.offset = 0
+        self._seed = None
+
+    @property
+    def seed(self):
+        """Bound at first use: torch.initial_seed() mixed with the stream's salt and the data-parallel rank."""
+        if self._seed is None:
+            rank = dist.get_rank() if dist.is_initialized() else int(os.environ.get("RANK", "0"))
+            s = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + self.salt) & _MASK64
+            self._seed = (s ^ ((rank * 0xD1B54A32D192ED03) & _MASK64)) & _MASK64
+        return self._seed
+
+    def mask(self, like, p):
+        from . import ops
+        m = ops.dropout_mask(like, p, self.seed, self.offset)
+        self.offset += like.numel()
+        return m
+
+    def state(self):
+        return {"seed": self.seed, "offset": self.offset}
+
+    def set_state(self, st):
+        self._seed, self.offset = int(st["seed"]), int(st["offset"])
+
+
+def collect(model):
+    """{module path: stream state} of every DropoutStream attribute in ``model`` (for the checkpoint's rng_state)."""
+    out = {}
+    for name, mod in model.named_modules():
+        for attr, val in vars(mod).items():
+            if isinstance(val, DropoutStream):
+                out["%s.%s" % (name, attr)] = val.state()
+    return out
+
+
+def restore(model, states):
+    for name, mod in model.named_modules():
+        for attr, val in vars(mod).items():
+            key = "%s.%s" % (name, attr)
+            if isinstance(val, DropoutStream) and key in states:
+                val.set_state(states[key])

@@ -31,28 +31,15 @@ class FusedAdam:
                       self.betas, self.eps, self.weight_decay, grad_scale)
 
     def state_dict(self):
-        """torch.optim.Adam-format state (parameter index = position in ``flat.params`` order reversed back to
-        module.parameters() order is NOT attempted: indices follow ``flat.params``)."""
-        state = {}
-        for i, (off, n) in enumerate(self.flat.offsets):
-            shape = self.flat.params[i].shape
-            state[i] = {"step": torch.tensor(float(self.step_count)),
-                        "exp_avg": self.exp_avg[off:off + n].view(shape).clone(),
-                        "exp_avg_sq": self.exp_avg_sq[off:off + n].view(shape).clone()}
-        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
-                 "amsgrad": False, "params": list(range(len(self.flat.params)))}
-        return {"state": state, "param_groups": [group]}
+        """torch.optim.Adam's layout with parameter indices in ``model.parameters()`` order -- the ONE format this build
+        reads and writes (``checkpoint.optimizer_state_dict``), interchangeable with the reference's
+        ``optimizer.state_dict()`` / ``load_state_dict`` (train.py:149, 236)."""
+        from . import checkpoint
+        return checkpoint.optimizer_state_dict(self, None)
 
     def load_state_dict(self, sd):
-        g = sd["param_groups"][0]
-        self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
-        for i, (off, n) in enumerate(self.flat.offsets):
-            st = sd["state"].get(i)
-            if st is None:
-                continue
-            self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
-            self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
-            self.step_count = int(st["step"])
+        from . import checkpoint
+        checkpoint.load_optimizer_state_dict(self, None, sd)
 
 
 def get_optimizers(params: dict, flat: FlatParameters):
@@ -72,6 +59,7 @@ class TrainStep:
     def __init__(self, model, criterion, feature_extractor, params=None, n_buckets=4, lr=1e-3):
         self.model, self.criterion, self.features = model, criterion, feature_extractor
         self.flat = FlatParameters(model)
+        self.flat.broadcast(0)                   # no-op on one rank: all ranks start from rank 0's parameters / buffers
         self.optimizer = get_optimizers(params, self.flat) if params is not None else FusedAdam(self.flat, lr=lr)
         self.reducer = BucketedAllReduce(self.flat, n_buckets=n_buckets)
 

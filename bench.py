@@ -9,24 +9,32 @@ Workload (BASELINE.json configs[1]): synthetic 4-ch 24 kHz 60 s clips, batch 64 
 processes its own 64 clips.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--seconds S]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+With --gpus N > 1 and no RANK in the environment this process only LAUNCHES: it starts N fresh worker processes
+(one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT), relays rank 0's JSON line
+and exits with the worst worker return code -- it never touches the GPU itself and never exec()s.  Under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the workers are the torchrun children.
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events (torch.cuda.Event on the stream the
 kernels are launched on) around every launch of the dominant kernel family (conv3x3 forward / data-gradient)
-inside the timed region; `cpu_baseline` times the CPU oracle (a port of the reference path, `oracle/`) on the
-host cores on a bounded sample of the same workload (N = 1, rank 0 only).
+inside the timed region: `achieved` = matrix FLOPs ISSUED per second (Winograd issues 16/36 of the algorithmic
+convolution FLOPs), `frac` = achieved / the exact-fp32 MFMA peak, `algorithmic_tflops` = the direct-convolution FLOPs
+per second the same launches stand for.  `stages` (HBM-bound passes: GB/s against 8 TB/s) are timed with HIP events in
+two extra, separately instrumented steps AFTER the timed region, so their events do not perturb `value`.
+`cpu_baseline` times the CPU oracle (a port of the reference path, `oracle/`) on the host cores on a bounded sample
+(8 x 20 s clips, 3 warm-ups, median of 5 steps; N = 1, rank 0 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
 PEAK_HBM_GBS = 8000.0
@@ -41,20 +49,52 @@ def params(device, nb_classes=12):
                              "optim": "Adam", "lr": 1e-3, "weight_decay": 0.0}}
 
 
+# ---------------------------------------------------------------------------------------------- launcher (N > 1, no RANK)
+def self_launch(n_gpus, argv):
+    """Start one fresh worker per GPU as CHILD processes and relay rank 0's line.  Nothing in this process has
+    touched (or will touch) the GPU: no torch.cuda call, no HIP call, no exec."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 600
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()                             # exactly the PID this launcher started
+            rcs.append(-9)
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [rc for rc in rcs if rc != 0]
+    return 0 if not bad else (max(abs(rc) for rc in bad) or 1)
+
+
+# ---------------------------------------------------------------------------------------------- HIP-event timers
 class KernelTimer:
     """HIP-event timing of selected op families on the launch stream, only while `active`."""
 
-    def __init__(self):
+    def __init__(self, torch):
+        self.torch = torch
         self.active = False
         self.records = {}          # family -> list of (start, end, work)
 
-    def wrap(self, module, name, family, work_fn):
+    def wrap(self, module, name, family, work_fn, gate=None):
         orig = getattr(module, name)
+        ev = self.torch.cuda.Event
 
         def timed(*a, **kw):
-            if not self.active:
+            if not (self.active if gate is None else gate()):
                 return orig(*a, **kw)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s, e = ev(enable_timing=True), ev(enable_timing=True)
             s.record()
             out = orig(*a, **kw)
             e.record()
@@ -71,58 +111,101 @@ class KernelTimer:
 
 
 def load_traffic(wino):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic.json: rocprofv3
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r0N_traffic.json: rocprofv3
     --pmc FETCH_SIZE and --pmc WRITE_SIZE over this same command, corrected as MI355X_MICROARCH.md prescribes);
     counters cannot be collected inside the timed run, so this is null when no PMC summary matches the algorithm."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        return t.get("winograd" if wino else "direct", {}).get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        return None
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                t = json.load(f)
+            v = t.get("winograd" if wino else "direct", {}).get("hbm_bytes_per_launch")
+            if v is not None:
+                return v
+        except (OSError, ValueError):
+            continue
+    return None
 
 
-def cpu_baseline(seconds_budget=12.0, clip_seconds=20, batch=2):
-    """Oracle (CPU port of the reference path) train step on a bounded sample: `batch` x 20 s chunks per step."""
+# ---------------------------------------------------------------------------------------------- CPU baseline (oracle)
+def cpu_baseline(batch=8, clip_seconds=20, warmups=3, timed=5, budget_s=75.0):
+    """Oracle (CPU port of the reference path) train step, BASELINE.md section 3: `batch` x 20 s clips per step
+    (BASELINE config 1 = the reference's own CPU-runnable case), `warmups` discarded steps, median of `timed` steps,
+    feature / model split, thread count chosen by a quick sweep.  Bounded: the sweep and the step counts shrink when a
+    step is slower than the budget allows."""
     import numpy as np
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import features as ofeat, seresnet as onet, adyolo_loss as oloss
     from oracle.filler import fill_state_dict
     from adyolo_amd.datasets import synthetic_audio, synthetic_targets
+    t_begin = time.time()
     torch.manual_seed(100)
-    threads = torch.get_num_threads()
+    ncpu = os.cpu_count() or 1
     sd = fill_state_dict(onet.state_dict_spec())
     plist = [v.requires_grad_(True) for k, v in sd.items()
              if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))]
     opt = torch.optim.Adam(plist, lr=1e-3)
     n = 24000 * clip_seconds
-    audio = synthetic_audio(batch, n, seed=4321)
-    target = synthetic_targets(batch, n // 2400, 12, seed=4321)
+    audio = synthetic_audio(batch, n, seed=1234)
+    target = synthetic_targets(batch, n // 2400, 12, seed=1234)
+    audio64 = [audio[b].double().numpy() for b in range(batch)]
     mel = ofeat.mel_filterbank()
+    pool = ThreadPoolExecutor(max_workers=min(batch, ncpu))      # the reference computes features in 16 loader workers
 
-    def step():
-        feats = np.stack([ofeat.get_feature(audio[b].double().numpy(), None, mel)[0] for b in range(batch)])
+    def features():
+        return np.stack(list(pool.map(lambda a: ofeat.get_feature(a, None, mel)[0], audio64)))
+
+    def model_step(feats):
         logits = onet.model_forward(sd, torch.from_numpy(feats), training=True, update_stats=True)
         opt.zero_grad()
         loss = oloss.adyolo_loss(logits, target, 12)
         loss.backward()
         opt.step()
-        return float(loss)
+        return float(loss.detach())
 
-    step()                                   # warm-up (allocator / oneDNN primitive caches)
-    t0, n_steps = time.time(), 0
-    while True:
-        step()
-        n_steps += 1
-        if time.time() - t0 >= seconds_budget or n_steps >= 20:
+    feats = features()
+    torch.set_num_threads(min(ncpu, 32))
+    model_step(feats)                                            # allocator / oneDNN primitive caches
+    # thread sweep: one model step per candidate, keep the fastest (oversubscription hurts on 128+ hardware threads)
+    # (ascending, stop at the first candidate that is slower than the best so far: 256 threads on B = 8 took 15 minutes)
+    cands = sorted({c for c in (8, 16, 32, 64) if 1 <= c <= ncpu})
+    sweep = {}
+    for c in cands:
+        torch.set_num_threads(c)
+        t0 = time.time()
+        model_step(feats)
+        sweep[c] = time.time() - t0
+        if sweep[c] > 1.15 * min(sweep.values()) or time.time() - t_begin > 0.4 * budget_s:
             break
-    dt = time.time() - t0
-    return {"value": round(batch * clip_seconds * n_steps / dt, 3), "unit": "audio-s/s", "cores": threads,
-            "kind": "port",
-            "sample": "%d train steps of %d x %d s clips (features+fwd+loss+bwd+Adam), PyTorch-CPU/NumPy oracle, "
-                      "%d threads of %d host cpus" % (n_steps, batch, clip_seconds, threads, os.cpu_count())}
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    left = budget_s - (time.time() - t_begin)
+    est = sweep[best] * 1.3 + 1.0
+    n_timed = max(1, min(timed, int(left / est) - 1))
+    n_warm = max(0, min(warmups, int(left / est) - n_timed))
+    for _ in range(n_warm):
+        model_step(features())
+    tf, tm = [], []
+    for _ in range(n_timed):
+        t0 = time.time()
+        feats = features()
+        t1 = time.time()
+        model_step(feats)
+        t2 = time.time()
+        tf.append(t1 - t0)
+        tm.append(t2 - t1)
+    pool.shutdown()
+    med = lambda v: float(sorted(v)[len(v) // 2])      # noqa: E731
+    step_s = med([a + b for a, b in zip(tf, tm)])
+    return {"value": round(batch * clip_seconds / step_s, 3), "unit": "audio-s/s", "cores": best, "kind": "port",
+            "features_s": round(med(tf), 4), "model_s": round(med(tm), 4), "step_s": round(step_s, 4),
+            "thread_sweep_s": {str(k): round(v, 3) for k, v in sweep.items()},
+            "sample": "median of %d train steps (after %d warm-ups) of %d x %d s clips (features on %d host threads + "
+                      "fwd+loss+bwd+Adam on %d torch threads), PyTorch-CPU/NumPy oracle, %d host cpus"
+                      % (n_timed, n_warm + 1, batch, clip_seconds, min(batch, ncpu), best, ncpu)}
 
 
+# ---------------------------------------------------------------------------------------------- worker
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,22 +214,26 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--seconds", type=int, default=60, help="clip length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stages", action="store_true", help="skip the two extra instrumented steps")
     ap.add_argument("--encoder", default="se-resnet34", choices=["se-resnet34", "resnet-conformer"],
                     help="se-resnet34 = the headline workload (BASELINE configs[1]); resnet-conformer = config 4")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+
+    import torch
     import adyolo_amd  # noqa: F401
     from adyolo_amd import ops, dist as adist
     from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
     from adyolo_amd.features import FeatureExtractor
     from adyolo_amd.datasets import synthetic_audio, synthetic_targets
     from adyolo_amd.train import TrainStep
-    import adyolo_amd.functional as Fn
     import torch.distributed as dist
 
     rank, world, local_rank = adist.init_from_env("nccl")
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
 
@@ -156,13 +243,36 @@ def main():
     prm = params(device)
     prm["args"]["encoder"] = args.encoder
     model = WrapperModel((1, 7, T, 64), (), prm).to(device)
-    trainer = TrainStep(model, WrapperCriterion(prm), FeatureExtractor(None, device), prm)
+    criterion = WrapperCriterion(prm)
+    fx = FeatureExtractor(None, device)
     audio = synthetic_audio(B, n_samples, seed=1234 + rank).to(device)
     target = synthetic_targets(B, T // 4, 12, seed=1234 + rank).to(device)
-
-    timer = KernelTimer()
-    # work = (algorithmic FLOPs of the 3x3 convolution, matrix FLOPs actually issued: 16/36 of that in Winograd form)
     wino = ops.conv_algo() == "winograd"
+
+    # parity gate at the benchmark shape: the first forward loss with the benchmarked (Winograd) convolutions must equal
+    # the direct implicit-GEMM path within 1e-3 (both are checked against torch / the oracle in tests/)
+    parity = None
+    if args.encoder == "se-resnet34" and wino and rank == 0:
+        model.train()
+        vals = {}
+        with torch.no_grad():
+            feat = fx(audio, channels_last8=True)
+            for algo in ("winograd", "direct"):
+                os.environ["ADYOLO_CONV_ALGO"] = algo
+                model.encoder.dropout_stream.offset = 0    # same inter-layer GRU dropout mask for both runs
+                vals[algo] = float(criterion(model(feat, channels_last8=True), target))
+            del feat
+        os.environ["ADYOLO_CONV_ALGO"] = "winograd"
+        rel = abs(vals["winograd"] - vals["direct"]) / abs(vals["direct"])
+        parity = {"first_loss_winograd": round(vals["winograd"], 6), "first_loss_direct": round(vals["direct"], 6),
+                  "rel_diff": float("%.3g" % rel), "tol": 1e-3}
+        assert rel <= 1e-3, "Winograd vs direct loss at the bench shape: %r" % (vals,)
+        torch.manual_seed(100)                     # BatchNorm running statistics moved: rebuild the model
+        model = WrapperModel((1, 7, T, 64), (), prm).to(device)
+    trainer = TrainStep(model, criterion, fx, prm)
+
+    timer = KernelTimer(torch)
+    # work = (algorithmic FLOPs of the 3x3 convolution, matrix FLOPs actually issued: 16/36 of that in Winograd form)
 
     def conv_work(x, wpk, cout, **kw):
         alg = 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * cout * 9 * x.shape[3]
@@ -187,6 +297,29 @@ def main():
         return out
     trainer.features = timed_features
 
+    # HBM-bound passes, timed only in the extra instrumented steps (work = (algorithmic bytes, 0)): every distinct operand
+    # tensor read once + every output written once, whatever number of passes the implementation makes
+    stage = {"on": False}
+    gate = lambda: stage["on"]                                                        # noqa: E731
+    nb = lambda t: float(t.numel() * 4)                                               # noqa: E731
+    timer.wrap(ops, "bn_bwd", "bn_bwd (reduce + apply)", lambda dy, x, *a, **k: (3 * nb(x), 0.0), gate)
+    timer.wrap(ops, "se_tail_fwd", "se_tail_fwd", lambda c, r, *a, **k: (3 * nb(c), 0.0), gate)
+    timer.wrap(ops, "se_tail_bwd", "se_tail_bwd (reduce + fc + apply)",
+               lambda de, e, c, *a, **k: ((5 if k.get("want_dr", True) else 4) * nb(c), 0.0), gate)
+    timer.wrap(ops, "affine", "affine", lambda x, *a, **k: (2 * nb(x), 0.0), gate)
+    timer.wrap(ops, "avgpool2", "avgpool2_fwd", lambda x, *a, **k: (1.25 * nb(x), 0.0), gate)
+    timer.wrap(ops, "avgpool2_bwd", "avgpool2_bwd", lambda dy, *a, **k: (5 * nb(dy), 0.0), gate)
+    timer.wrap(ops, "adyolo_loss", "adyolo_loss (assign + main + final)",
+               lambda logit, tgt, *a, **k: (2 * nb(logit) + nb(tgt), 0.0), gate)
+    timer.wrap(ops, "adam_step", "adam", lambda p, *a, **k: (7 * nb(p), 0.0), gate)
+    timer.wrap(ops, "bn_stats_tiles", "bn_stats_tiles", lambda st, *a, **k: (nb(st), 0.0), gate)
+    timer.wrap(ops, "sap_fwd", "sap_fwd", lambda x, *a, **k: (nb(x), 0.0), gate)
+    timer.wrap(ops, "sap_bwd", "sap_bwd", lambda dy, x, *a, **k: (2 * nb(x), 0.0), gate)
+    timer.wrap(ops, "gemm", "gemm (1x1 conv, GRU / head projections) [FLOPs]",
+               lambda a_, b_, m, n, k_, *r, **kw: (2.0 * m * n * k_, 1.0), gate)
+    timer.wrap(ops, "gru_fwd", "gru_fwd", lambda gx, *a, **k: (nb(gx), 0.0), gate)
+    timer.wrap(ops, "gru_bwd", "gru_bwd", lambda d, g_, *a, **k: (nb(g_), 0.0), gate)
+
     def sync():
         if world > 1:
             dist.barrier()
@@ -206,38 +339,72 @@ def main():
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
+    step_ms = dt / args.steps * 1e3
+
+    stages = {}
+    if rank == 0 and not args.no_stages:
+        n_inst = 2
+        stage["on"] = True
+        t1 = time.perf_counter()
+        for _ in range(n_inst):
+            trainer.step(audio, target)
+        torch.cuda.synchronize()
+        inst_ms = (time.perf_counter() - t1) / n_inst * 1e3
+        stage["on"] = False
+        ew_ms = 0.0
+        for fam in list(timer.records):
+            if fam.startswith("conv3x3"):
+                continue
+            n_l, ms, work, is_flops = timer.summary(fam)
+            per_step = ms / n_inst
+            ent = {"launches_per_step": n_l // n_inst, "ms_per_step": round(per_step, 3),
+                   "share_of_step": round(per_step / step_ms, 4)}
+            if is_flops > 0:
+                ent["achieved_tflops"] = round(work / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0
+                ent["frac_of_mfma_peak"] = round(ent["achieved_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
+            else:
+                gbs = work / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+                ent.update({"algorithmic_GB_per_step": round(work / n_inst / 1e9, 3), "achieved_GBps": round(gbs, 1),
+                            "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4)})
+                if not fam.startswith("gru"):
+                    ew_ms += per_step
+            stages[fam] = ent
+        stages["_elementwise_total"] = {"ms_per_step": round(ew_ms, 3), "share_of_step": round(ew_ms / step_ms, 4),
+                                        "instrumented_step_ms": round(inst_ms, 3)}
 
     if rank == 0:
         n_f, ms_f, fl_f, ex_f = timer.summary("conv3x3_fwd_dgrad")
         n_w, ms_w, fl_w, ex_w = timer.summary("conv3x3_wgrad")
-        executed = ex_f / (ms_f * 1e-3) / 1e12 if ms_f > 0 else 0.0
+        issued = ex_f / (ms_f * 1e-3) / 1e12 if ms_f > 0 else 0.0
+        algorithmic = fl_f / (ms_f * 1e-3) / 1e12 if ms_f > 0 else 0.0
         k1_ms = sum(s.elapsed_time(e) for s, e in k1_rec) / max(1, len(k1_rec))
         k1_bytes = FeatureExtractor.algorithmic_bytes(B, n_samples)
-        achieved = fl_f / (ms_f * 1e-3) / 1e12 if ms_f > 0 else 0.0
         value = world * B * args.seconds * args.steps / dt
         line = {
             "metric": "train-step audio-sec/s (4ch, %s+adyolo)" % args.encoder,
             "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(step_ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.encoder + " + adyolo loss, synthetic 4ch 24kHz %ds clips, bs=%d per GPU, "
                                    "12 classes, features+fwd+loss+bwd+allreduce+Adam" % (args.seconds, B),
                        "global_batch": world * B, "clip_seconds": args.seconds, "parallelism": "dp%d" % world},
-            # achieved = ALGORITHMIC 3x3-convolution FLOPs / time; the Winograd kernels issue 16/36 of
-            # them, so frac can exceed 1 -- `mfma_issued` / `mfma_util` is the matrix-pipe utilisation proper
+            # achieved = matrix FLOPs ISSUED per second by the dominant kernel family (what the MFMA pipe executes);
+            # algorithmic_tflops = the direct-convolution FLOPs the same launches stand for, 36/16 of it in
+            # Winograd form
             "roofline": {"bound": "mfma",
                          "kernel": ("wino_fwd_kernel (Winograd F(2x2,3x3)" if wino else "conv3x3_fwd_kernel (direct") +
                                    "; forward + data-gradient launches)",
-                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": load_traffic(wino),
-                         "mfma_issued": round(executed, 2), "mfma_util": round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "achieved": round(issued, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(issued / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": load_traffic(wino),
+                         "algorithmic_tflops": round(algorithmic, 2),
                          "launches": n_f, "avg_launch_ms": round(ms_f / max(1, n_f), 4),
                          "share_of_step": round(ms_f / (dt * 1e3), 4)},
             "stages": {
                 "conv3x3_wgrad": {"launches": n_w, "avg_launch_ms": round(ms_w / max(1, n_w), 4),
-                                  "achieved_tflops": round(fl_w / (ms_w * 1e-3) / 1e12, 2) if ms_w > 0 else 0.0,
                                   "mfma_issued_tflops": round(ex_w / (ms_w * 1e-3) / 1e12, 2) if ms_w > 0 else 0.0,
+                                  "frac_of_mfma_peak": round(ex_w / (ms_w * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if ms_w > 0 else 0.0,
+                                  "algorithmic_tflops": round(fl_w / (ms_w * 1e-3) / 1e12, 2) if ms_w > 0 else 0.0,
                                   "share_of_step": round(ms_w / (dt * 1e3), 4)},
                 "k1_features": {"ms": round(k1_ms, 4), "algorithmic_GB": round(k1_bytes / 1e9, 4),
                                 "achieved_GBps": round(k1_bytes / (k1_ms * 1e-3) / 1e9, 1) if k1_ms > 0 else 0.0,
@@ -246,6 +413,9 @@ def main():
             "final_loss": round(loss_val, 6),
             "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
         }
+        line["stages"].update(stages)
+        if parity is not None:
+            line["parity_check"] = parity
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -240,7 +240,8 @@ def gen_seed100_train():
     default initialisation under torch.manual_seed(100) (main.py:47; wrapper.py:26-47 builds the encoder, then the head),
     in float32 and -- the same modules cast to float64 -- in float64 (the yardstick for fp32 round-off).  Inputs are
     reproduced from seeds (x: torch.Generator 31; the weights: the seed-100 init the build reproduces bit for bit), the
-    target rows are stored."""
+    target rows are stored.  ``gnoise_*`` = the reference's own float32-vs-float64 deviation per gradient tensor (max over
+    all elements and over its two convolution back ends, oneDNN and native), as a fraction of the tensor's absmax."""
     from models.backbones.resnet import SEResnet34
     from models.linearheads import ADYOLOhead
     from models.loss import ADYOLOloss
@@ -259,6 +260,30 @@ def gen_seed100_train():
            "target": target.numpy()}
     crit = ADYOLOloss(params)
 
+    FRAGILE_TAU = 1e-4            # |pre-activation| < tau x absmax: ~20 x the float32 round-off of the activations
+
+    def fragile_hooks(m, store):
+        """Per ReLU site (call order = reference forward, resnet.py:34,46,184): elements of the float64 pre-activation that
+        lie within FRAGILE_TAU x absmax of zero -- flat NCHW index and whether the float64 value is positive."""
+        hooks = []
+
+        def mk(name):
+            calls = []
+
+            def pre(mod, inp):
+                t = inp[0].detach()
+                site = name if name == "stem" else name + (".a" if len(calls) == 0 else ".e")
+                calls.append(1)
+                flat = t.reshape(-1)
+                idx = torch.nonzero(flat.abs() < FRAGILE_TAU * float(flat.abs().max())).reshape(-1)
+                store[site] = (idx.to(torch.int32).numpy(), (flat[idx] > 0).numpy())
+            return pre
+        hooks.append(m.encoder.relu.register_forward_pre_hook(mk("stem")))
+        for li in range(1, 5):
+            for bi, blk in enumerate(getattr(m.encoder, "layer%d" % li)):
+                hooks.append(blk.relu.register_forward_pre_hook(mk("layer%d.%d" % (li, bi))))
+        return hooks
+
     def run(m, xin):
         for p in m.parameters():
             p.grad = None
@@ -269,13 +294,27 @@ def gen_seed100_train():
         return y.detach(), logit.detach(), loss.detach()
 
     m64 = copy.deepcopy(model).double()
+    sd0 = copy.deepcopy(model.state_dict())
+    with torch.backends.mkldnn.flags(enabled=False):       # second realisation of the reference's float32 round-off
+        run(model, x)
+    native = {k: p.grad.clone() for k, p in model.named_parameters()}
+    model.load_state_dict(sd0)
     y32, l32, loss32 = run(model, x)
     sd_after = {k: v.clone() for k, v in model.state_dict().items()}
     torch.set_default_dtype(torch.float64)      # the reference loss allocates its label tensors in the default dtype
+    fragile = {}
+    hooks = fragile_hooks(m64, fragile)
     try:
         y64, l64, loss64 = run(m64, x.double())
     finally:
         torch.set_default_dtype(torch.float32)
+        for h in hooks:
+            h.remove()
+    for site, (idx, pos) in fragile.items():
+        out["fragile_idx_" + site] = idx
+        out["fragile_pos_" + site] = np.packbits(pos)
+    print("fragile ReLU elements (|pre-activation| < %.0e x absmax) per site:" % FRAGILE_TAU,
+          {k: len(v[0]) for k, v in fragile.items()})
     out["y_train"] = y32.numpy()
     out["y_train64_dev"] = np.asarray(float((y32.double() - y64).abs().max()))
     li = strided_sample(l32.numel(), 65536)
@@ -290,7 +329,9 @@ def gen_seed100_train():
         out["grad_" + k] = g32[idx].numpy()
         out["grad64_" + k] = g64[idx].numpy()
         out["gabs64_" + k] = np.asarray(float(g64.abs().max()))
-        out["gnoise_" + k] = np.asarray(float((g32.double() - g64).abs().max()) / max(float(g64.abs().max()), 1e-300))
+        am = max(float(g64.abs().max()), 1e-300)
+        out["gnoise_" + k] = np.asarray(max(float((g32.double() - g64).abs().max()),
+                                            float((native[k].reshape(-1).double() - g64).abs().max())) / am)
     for k in ("encoder.bn1.running_mean", "encoder.layer2.0.downsample.1.running_var", "encoder.layer4.2.bn2.running_mean"):
         out["stat_" + k] = sd_after[k].numpy()
     np.savez_compressed(os.path.join(HERE, "seed100_train.npz"), **out)

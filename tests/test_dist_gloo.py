@@ -85,3 +85,75 @@ def test_flat_parameters_keep_module_semantics():
         assert p.grad.data_ptr() >= flat.flat_grad.data_ptr()
     flat.zero_grad()
     assert float(flat.flat_grad.abs().sum()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------- start-up / sharding / state
+def _worker_startup(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from adyolo_amd.rng import DropoutStream
+    torch.manual_seed(100 + 7 * rank)                  # ranks that (wrongly) seeded differently ...
+    model = nn.Sequential(nn.Linear(6, 5), nn.BatchNorm1d(5), nn.Linear(5, 3))
+    model[1].running_mean.fill_(float(rank + 1))
+    flat = FlatParameters(model)
+    flat.broadcast(0)                                  # ... start from rank 0's parameters and buffers anyway
+    red = BucketedAllReduce(flat, n_buckets=2)
+    # only the LAST layer gets a gradient: the other bucket never fires from a hook and finish() must launch it
+    flat.zero_grad()
+    model[2](torch.ones(2, 5) * (rank + 1)).sum().backward()
+    scale = red.finish()
+    torch.manual_seed(100)
+    stream = DropoutStream(0x5EED)
+    model[1].running_mean.fill_(float(rank + 1))
+    flat.average_buffers()
+    out.put((rank, flat.flat.clone(), flat.flat_grad.clone() * scale, red.fired_from_hooks, red.fired_from_finish,
+             stream.seed, model[1].running_mean.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_startup_broadcast_leftover_buckets_and_rank_seeds():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_startup, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, p0, g0, h0, f0, s0, rm0), (_, p1, g1, h1, f1, s1, rm1) = got
+    assert torch.equal(p0, p1), "ranks must start from rank 0's parameters"
+    assert torch.equal(g0, g1), "averaged gradients must be identical on every rank"
+    assert h0 + f0 == 2 and f0 >= 1 and (h0, f0) == (h1, f1)
+    assert s0 != s1, "dropout streams must differ between the data-parallel ranks"
+    assert torch.equal(rm0, rm1) and float(rm0[0]) == 1.5          # running statistics averaged over the ranks
+
+
+def test_fused_adam_state_dict_uses_module_parameter_order():
+    """ONE optimizer-state format: torch.optim.Adam's, indexed like model.parameters() (reference train.py:149, 236)."""
+    from adyolo_amd import checkpoint
+
+    class _Opt:                                        # FusedAdam without the HIP step: only the state containers
+        def __init__(self, flat):
+            self.flat, self.lr, self.betas, self.eps, self.weight_decay = flat, 1e-3, (0.9, 0.999), 1e-8, 0.0
+            self.exp_avg, self.exp_avg_sq, self.step_count = torch.zeros_like(flat.flat), torch.zeros_like(flat.flat), 0
+    m = _model()
+    ref_params = [p.detach().clone().requires_grad_(True) for p in m.parameters()]
+    adam = torch.optim.Adam(ref_params, lr=1e-3)
+    for p in ref_params:
+        p.grad = torch.randn_like(p)
+    adam.step()
+    flat = FlatParameters(m)
+    opt = _Opt(flat)
+    checkpoint.load_optimizer_state_dict(opt, None, adam.state_dict())
+    back = checkpoint.optimizer_state_dict(opt, None)
+    ref_sd = adam.state_dict()
+    assert back["param_groups"][0]["params"] == ref_sd["param_groups"][0]["params"]
+    for i, p in enumerate(ref_params):
+        assert back["state"][i]["exp_avg"].shape == p.shape
+        torch.testing.assert_close(back["state"][i]["exp_avg"], ref_sd["state"][i]["exp_avg"])
+        torch.testing.assert_close(back["state"][i]["exp_avg_sq"], ref_sd["state"][i]["exp_avg_sq"])
+    adam2 = torch.optim.Adam(ref_params, lr=1e-3)
+    adam2.load_state_dict(back)                        # and torch's own optimizer accepts what we write

@@ -46,17 +46,48 @@ def _rel(got, ref):
 
 
 # ------------------------------------------------------------------------------ the reference's training shape, default init
+def _align_relu_masks(model, captured, g):
+    """Give the fragile ReLU elements (golden: float64 pre-activation within 1e-4 x absmax of zero) the float64 mask.
+    The build derives every ReLU mask in backward from a saved ReLU OUTPUT (`a > 0`, `e > 0`), so a fragile element that
+    must count as positive becomes 1e-30 and one that must not becomes 0 -- a change of at most the activation round-off
+    in value, and exactly the reference's subgradient in backward.  Returns the number of masks that had to change."""
+    flips = 0
+    for site, t in captured.items():
+        idx = torch.from_numpy(g["fragile_idx_" + site].astype(np.int64))
+        pos = torch.from_numpy(np.unpackbits(g["fragile_pos_" + site])[:idx.numel()].astype(bool))
+        n, h, w, c = t.shape                                   # ours: channels-last; golden indices: flat NCHW
+        ww, hh, cc, nn_ = idx % w, (idx // w) % h, (idx // (w * h)) % c, idx // (w * h * c)
+        flat = (((nn_ * h + hh) * w + ww) * c + cc).to(t.device)
+        pos = pos.to(t.device)
+        v = t.data.view(-1)
+        cur = v[flat]
+        flips += int(((cur > 0) != pos).sum())
+        v[flat] = torch.where(pos, torch.where(cur > 0, cur, torch.full_like(cur, 1e-30)), torch.zeros_like(cur))
+    return flips
+
+
 @pytest.mark.parametrize("algo", ["direct", "winograd"])
 def test_seed100_training_step_matches_reference(ops, monkeypatch, algo):
     """One training step at the reference's training shape (2, 7, 800, 64) with the reference's default initialisation
     under torch.manual_seed(100) (src/main.py:47; the build's init is bit-identical, test_host_cpu.py), against
     tests/golden/seed100_train.npz = the REAL reference in float32 and in float64 (resnet.py:180-199, linearheads.py:101-104,
-    loss.py:189-251, train.py:49-55).
+    loss.py:189-251, train.py:49-55).  Both convolution algorithms (Winograd is the default and the benchmarked one)
+    meet the same bars:
 
-    Bars: encoder output, logits 1e-3 (north_star); loss 1e-3 relative; every sampled gradient tensor deviates from the
-    float64 reference by at most max(1e-3, 2 x the deviation of the reference's OWN float32 run from float64) of the
-    tensor's absmax, cosine >= 0.9999.  Both convolution algorithms (Winograd is the default and the benchmarked one)
-    must meet the same bar."""
+      * encoder output and logits 1e-3 (north_star), loss 1e-3 relative (1e-4 vs float64), running statistics 1e-4;
+      * gradients with the ReLU masks of the fragile elements aligned to the float64 reference: EVERY sampled tensor
+        within 1e-4 of its absmax of float64, cosine >= 0.999999 (measured ~1e-5; the reference's own float32 run,
+        aligned the same way, gives 0.5-12e-6);
+      * gradients as they come (no alignment): cosine >= 0.9999 and max deviation <= max(1e-3, 5 x the reference's own
+        float32-vs-float64 deviation), with at most 100 flipped masks.
+
+    Why two gradient checks: hooking the REAL reference (float32 vs float64, this shape) shows the gradient at the
+    output of layer4.2 agreeing to 4e-6 (relative L2) and, right behind that block's ReLU, single elements off by 10 % of
+    absmax: pre-activations within float32 round-off (5e-6) of zero get the other mask -- a different, equally valid
+    subgradient.  23 such flips (of 44 M ReLU elements) move the reference's own gradients by 2e-3 .. 9e-2 of absmax
+    depending on which elements they hit (oneDNN vs native convolution back end); with the 23 masks aligned the same
+    float32 run agrees with float64 to 1.2e-5.  Which elements flip is a property of each implementation's rounding, so
+    the un-aligned comparison can only be statistical; the aligned one is exact arithmetic parity."""
     monkeypatch.setenv("ADYOLO_CONV_ALGO", algo)
     from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
     g = np.load(os.path.join(G, "seed100_train.npz"))
@@ -68,10 +99,25 @@ def test_seed100_training_step_matches_reference(ops, monkeypatch, algo):
     x = torch.randn(2, 7, 800, 64, generator=torch.Generator().manual_seed(int(g["x_seed"])))
     assert abs(float(x.double().sum()) - float(g["x_sum"])) < 1e-6 and np.array_equal(x.reshape(-1)[:16].numpy(), g["x_head"])
     target = torch.from_numpy(g["target"])
+    captured, hooks = {}, []
+
+    def grab(site_a, site_e, is_first):
+        def hook(mod, inp, out):
+            saved = out.grad_fn.saved_tensors                  # SEBlockFn: [p, src (= relu(conv1)), scale1, cc, e, ...]
+            assert saved[4].data_ptr() == out.data_ptr()
+            captured[site_a], captured[site_e] = saved[1], out
+            if is_first:
+                captured["stem"] = inp[0].grad_fn.saved_tensors[1]     # StemFn: [x8, a (= relu(conv + bias)), ...]
+        return hook
+    for li in range(1, 5):
+        for bi, blk in enumerate(getattr(model.encoder, "layer%d" % li)):
+            hooks.append(blk.register_forward_hook(grab("layer%d.%d.a" % (li, bi), "layer%d.%d.e" % (li, bi), li == 1 and bi == 0)))
     y = model.encoder(x.to("cuda:0"))
     logit = model.head(y)
     loss = WrapperCriterion(prm)(logit, target)
-    loss.backward()
+    for h in hooks:
+        h.remove()
+    assert len(captured) == 33
     torch.cuda.synchronize()
     y_ref = torch.from_numpy(g["y_train"])
     assert float((y.detach().cpu() - y_ref).abs().max()) <= 1e-3, "encoder output (tanh range) vs reference"
@@ -79,33 +125,48 @@ def test_seed100_training_step_matches_reference(ops, monkeypatch, algo):
     lg = logit.detach().cpu().reshape(-1)[li]
     lref = torch.from_numpy(g["logit_sample"])
     assert float((lg - lref).abs().max()) <= 1e-3 * max(1.0, float(lref.abs().max())), "logits vs reference"
-    assert abs(float(loss) - float(g["loss"])) <= 1e-3 * abs(float(g["loss"])), (float(loss), float(g["loss"]))
-    assert abs(float(loss) - float(g["loss64"])) <= 1e-4 * abs(float(g["loss64"]))
-    named = dict(model.named_parameters())
-    bad, report = [], []
-    for key in g.files:
-        if not key.startswith("grad64_"):
-            continue
-        name = key[len("grad64_"):]
-        t64 = torch.from_numpy(g[key])
-        idx = strided_sample(named[name].numel())
-        got = named[name].grad.reshape(-1).cpu()[idx].double()
-        am = float(g["gabs64_" + name])
-        ref_noise = float(g["gnoise_" + name])
-        mine = float((got - t64).abs().max()) / am
-        cos = float(torch.dot(got, t64) / (got.norm() * t64.norm()))
-        limit = max(1e-3, 2.0 * ref_noise)
-        report.append("%s %.2e (ref %.2e) cos %.7f" % (name, mine, ref_noise, cos))
-        if mine > limit or cos < 0.9999:
-            bad.append("%s: %.2e of absmax vs float64 (limit %.2e, reference float32 %.2e), cosine %.7f"
-                       % (name, mine, limit, ref_noise, cos))
-    print("[%s] " % algo + "\n".join(report))
-    assert not bad, "; ".join(bad)
+    lv = float(loss.detach())
+    assert abs(lv - float(g["loss"][0])) <= 1e-3 * abs(float(g["loss"][0])), (lv, float(g["loss"][0]))
+    assert abs(lv - float(g["loss64"][0])) <= 1e-4 * abs(float(g["loss64"][0]))
     sd = model.state_dict()
     for key in g.files:
         if key.startswith("stat_"):
             ref = torch.from_numpy(g[key])
             assert float((sd[key[5:]].cpu() - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), key
+
+    named = dict(model.named_parameters())
+
+    def compare(tag, max_limit, cos_limit):
+        bad, report = [], []
+        for key in g.files:
+            if not key.startswith("grad64_"):
+                continue
+            name = key[len("grad64_"):]
+            t64 = torch.from_numpy(g[key])
+            idx = strided_sample(named[name].numel())
+            got = named[name].grad.reshape(-1).cpu()[idx].double()
+            ref_noise = float(g["gnoise_" + name])
+            mine = float((got - t64).abs().max()) / float(g["gabs64_" + name])
+            cos = float(torch.dot(got, t64) / (got.norm() * t64.norm()))
+            limit = max_limit(ref_noise)
+            report.append("%-42s %.2e (reference float32, un-aligned: %.2e) cos %.8f" % (name, mine, ref_noise, cos))
+            if mine > limit or cos < cos_limit:
+                bad.append("%s: %.2e of absmax vs float64 (limit %.2e), cosine %.8f" % (name, mine, limit, cos))
+        print("[%s, %s]\n" % (algo, tag) + "\n".join(report))
+        assert not bad, "%s gradients: " % tag + "; ".join(bad)
+
+    loss.backward(retain_graph=True)
+    torch.cuda.synchronize()
+    compare("as they come", lambda ref_noise: max(1e-3, 5.0 * ref_noise), 0.9999)
+    for p in model.parameters():
+        p.grad = None
+    flips = _align_relu_masks(model, captured, g)
+    loss.backward()
+    torch.cuda.synchronize()
+    print("[%s] %d of the %d fragile ReLU masks differed from float64" % (algo, flips, sum(v.numel() for v in captured.values()) and
+          sum(int(g["fragile_idx_" + s_].shape[0]) for s_ in captured)))
+    assert flips <= 100
+    compare("masks aligned", lambda ref_noise: 1e-4, 0.999999)
 
 
 def test_training_trajectories_direct_vs_winograd(ops, monkeypatch):
@@ -248,23 +309,49 @@ def test_stem_conv_at_bench_shape_slices(ops):
 
 # ------------------------------------------------------------------------------ benchmark shape: loss
 def test_adyolo_loss_at_bench_shape(ops):
-    """AD-YOLO loss + dlogit at B = 64, T' = 600 (M ~ 130 k rows, 92 M logits) against the CPU oracle (loss.py:189-251)."""
+    """AD-YOLO loss + dlogit at B = 64, T' = 600 (M ~ 137 k rows, 683 k (target, anchor) pairs, 92 M logits) against the CPU
+    oracle (loss.py:189-251): loss 1e-5 relative, dlogit 1e-3 of absmax.
+
+    With 683 k pairs the discrete decisions of the loss meet float32 round-off, in the reference as here; the anchors they
+    touch are compared loosely (bounded by the largest regular entry) and must be rare (< 0.5 % of the anchors):
+      * D within 1e-3 degree of a threshold 45 / 25 / 10 (loss.py:225 `D < thr`): the pair is positive or not;
+      * the two closest anchors of a target within 1e-3 degree (loss.py:226 arg-min; typical at the poles, where the clamped
+        elevation makes the azimuth irrelevant): a different anchor is forced positive;
+      * D within 0.5 degree of 0 or 180 (loss.py:187 clips the acos argument at +-(1 - 1e-7)): 1 - |cos D| < 4e-5 carries
+        round-off of its own order, so the direction of dD/d(u, v) is decided by rounding."""
     from adyolo_amd.datasets import synthetic_targets
     from oracle import adyolo_loss as oloss
-    b, t = 64, 600
+    b, t, a, ch = 64, 600, 5, 15
     gen = torch.Generator().manual_seed(17)
     logit = torch.randn(b, t, 2400, generator=gen) * 1.5
     target = synthetic_targets(b, t, 12, seed=17)
     loss, dlogit, _ = ops.adyolo_loss(logit.to("cuda:0"), target.to("cuda:0"), 12)
     torch.cuda.synchronize()
     lo = logit.clone().requires_grad_(True)
-    ref = oloss.adyolo_loss(lo, target, 12)
+    ref, aux = oloss.adyolo_loss(lo, target, 12, return_aux=True)
     ref.backward()
     print("M = %d rows; loss %.6f vs oracle %.6f" % (target.shape[0], float(loss), float(ref)))
     assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
-    g = lo.grad
-    am = float(g.abs().max())
-    assert float((dlogit.cpu() - g).abs().max()) <= 1e-3 * am
+    g = lo.grad.view(-1, ch)                                            # [anchor][obj, cls x 12, u, v]
+    got = dlogit.cpu().view(-1, ch)
+    d = aux["D"]                                                        # (M, A) degrees
+    tb, tt, gi, gj = (target[:, k].long() for k in range(4))
+    cell = ((tb * t + tt) * 8 + gi) * 4 + gj
+    anchors = cell[:, None] * a + torch.arange(a)[None, :]             # (M, A) anchor rows of every pair
+    near_thr = ((d - 45.0).abs() < 1e-3) | ((d - 25.0).abs() < 1e-3) | ((d - 10.0).abs() < 1e-3)
+    srt, _ = d.sort(dim=1)
+    tie = ((srt[:, 1] - srt[:, 0]) < 1e-3)[:, None].expand_as(d)
+    singular = (d < 0.5) | (d > 179.5)
+    fragile = torch.zeros(g.shape[0], dtype=torch.bool)
+    fragile[anchors[near_thr | tie | singular]] = True
+    n_frag = int(fragile.sum())
+    assert n_frag <= 5e-3 * g.shape[0], n_frag
+    am = float(g[~fragile].abs().max())
+    err = float((got[~fragile] - g[~fragile]).abs().max())
+    print("%d fragile anchors of %d (threshold %d, arg-min tie %d, singular %d pairs); regular entries: %.2e of absmax %.2e"
+          % (n_frag, g.shape[0], int(near_thr.sum()), int(tie[:, 0].sum()), int(singular.sum()), err / am, am))
+    assert err <= 1e-3 * am
+    assert float(got[fragile].abs().max()) <= 1.5 * float(g.abs().max())
 
 
 def test_bench_shape_step_loss_direct_vs_winograd(ops, monkeypatch):
@@ -293,3 +380,67 @@ def test_bench_shape_step_loss_direct_vs_winograd(ops, monkeypatch):
         torch.cuda.empty_cache()
     print(vals)
     assert np.isfinite(vals["winograd"]) and abs(vals["winograd"] - vals["direct"]) <= 1e-3 * abs(vals["direct"])
+
+
+# ------------------------------------------------------------------------------ data-parallel path on one GPU (RCCL, 1 rank)
+_DP_CHILD = r"""
+import hashlib, json, os, sys
+sys.path.insert(0, os.environ["ADYOLO_REPO"])
+import torch
+import adyolo_amd
+import bench
+from adyolo_amd import dist as adist
+from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
+from adyolo_amd.features import FeatureExtractor
+from adyolo_amd.datasets import synthetic_audio, synthetic_targets
+from adyolo_amd.train import TrainStep
+rank, world, local = adist.init_from_env("nccl")
+torch.manual_seed(100)
+prm = bench.params("cuda:0")
+b, n = 4, 24000 * 4
+model = WrapperModel((1, 7, n // 600, 64), (), prm).to("cuda:0")
+tr = TrainStep(model, WrapperCriterion(prm), FeatureExtractor(None, "cuda:0"), prm)
+audio = synthetic_audio(b, n, seed=3).to("cuda:0")
+target = synthetic_targets(b, n // 2400, 12, seed=3).to("cuda:0")
+fired = []
+losses = []
+for _ in range(3):
+    h0, f0 = tr.reducer.fired_from_hooks, tr.reducer.fired_from_finish
+    losses.append(float(tr.step(audio, target)))
+    fired.append((tr.reducer.fired_from_hooks - h0, tr.reducer.fired_from_finish - f0))
+torch.cuda.synchronize()
+digest = hashlib.sha256(tr.flat.flat.cpu().numpy().tobytes()).hexdigest()
+print(json.dumps({"digest": digest, "fired": fired, "buckets": len(tr.reducer.buckets), "active": tr.reducer.active,
+                  "losses": losses, "dist": torch.distributed.is_initialized()}))
+if torch.distributed.is_initialized():
+    torch.distributed.destroy_process_group()
+"""
+
+
+def test_bucketed_allreduce_hooks_on_the_real_model(ops):
+    """The N > 1 code path on ONE GPU: a FRESH child process with WORLD_SIZE=1 ADYOLO_FORCE_DP_HOOKS=1 initialises RCCL
+    (backend nccl), registers the post-accumulate-grad hooks on the real SE-ResNet34 + AD-YOLO model and runs 3 TrainSteps:
+    all 4 buckets must be launched from hooks (overlapped with backward; none left to finish()'s straggler path) and the
+    parameters must be BIT-equal to a child without the hooks (the step is bit-reproducible, see test_raw_audio_epoch)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+
+    def child(force):
+        env = dict(os.environ, ADYOLO_REPO=repo, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("ADYOLO_FORCE_DP_HOOKS", None)
+        if force:
+            env["ADYOLO_FORCE_DP_HOOKS"] = "1"
+        r = subprocess.run([sys.executable, "-c", _DP_CHILD], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    hooked, plain = child(True), child(False)
+    assert hooked["dist"] and hooked["active"] and not plain["active"]
+    assert hooked["buckets"] == 4 and all(f == [4, 0] for f in hooked["fired"]), hooked["fired"]
+    assert hooked["losses"] == plain["losses"] and hooked["digest"] == plain["digest"]

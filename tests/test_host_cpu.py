@@ -336,3 +336,30 @@ def test_raw_audio_dataset_mirrors_the_reference_harness(tmp_path):
     pcm_b, combs, target = audio_collate_fn([te[0], te[1]])
     assert pcm_b.shape == (2, 48000, 4) and pcm_b.dtype == torch.int16 and combs == [0, 0]
     assert target.shape[1] == 7 and set(target[:, 0].tolist()) == {0.0, 1.0}
+
+
+def test_raw_audio_dataset_shards_by_rank(tmp_path):
+    """Data parallelism: every rank performs the SAME global draw (so ``remaining_file`` agrees everywhere) and keeps the
+    files rank, rank + world, ...: disjoint shards whose union is the single-process draw of batch_size * world files."""
+    import random
+    from adyolo_amd.datasets import FoaDataset
+    rs = np.random.RandomState(0)
+    _write_split(str(tmp_path), "dev-train-chunked_1s_1s", ["clip%02d" % i for i in range(12)], 24000, rs)
+    _write_split(str(tmp_path), "dev-test", ["t0", "t1", "t2"], 24000, rs)
+    params = {"args": {"loss": "adyolo"}, "aug_config": {"rotation_augment": False},
+              "data_config": {"data_pth": str(tmp_path), "chunk_window_s": 1, "chunk_stride_s": 1, "nb_classes": 12},
+              "train_config": {"batch_size": 2, "nb_iters": 2, "grid_size": [45, 45], "g_overlap": 0.5}}
+    shards, rests = [], []
+    for rank in range(2):
+        random.seed(4)
+        ds = FoaDataset(params, "train", rank=rank, world=2)
+        shards.append(ds.get_filelist())
+        rests.append(sorted(ds.get_remaining_file()))
+    assert len(shards[0]) == len(shards[1]) == 4 and not set(shards[0]) & set(shards[1])
+    assert rests[0] == rests[1] and len(rests[0]) == 4
+    random.seed(4)
+    single = dict(params, train_config=dict(params["train_config"], batch_size=4))
+    whole = FoaDataset(single, "train", rank=0, world=1).get_filelist()
+    assert whole[0::2] == shards[0] and whole[1::2] == shards[1]
+    te = [FoaDataset(params, "test", is_valid=True, rank=r, world=2).get_filelist() for r in range(2)]
+    assert te == [["t0", "t2"], ["t1"]]
