@@ -36,7 +36,7 @@ SIGNATURES = {
     "adyolo_gemm_batched": (I, [P] * 3 + [I] * 10 + [L] * 6 + [F, I, P]),
     "adyolo_colsum": (I, [P, P, P, I, I, I, I, P]),
     "adyolo_bn_stats": (I, [P] * 7 + [I, I, I, F, F, P]),
-    "adyolo_bn_stats_tiles": (I, [P] * 7 + [I, I, I, I, F, F, P]),
+    "adyolo_bn_stats_tiles": (I, [P] * 11 + [I, I, I, I, F, F, P]),
     "adyolo_bn_eval_stats": (I, [P] * 4 + [I, F, P]),
     "adyolo_bn_scale_shift": (I, [P] * 6 + [I, P]),
     "adyolo_affine_nhwc": (I, [P] * 4 + [L, I, P]),
@@ -44,12 +44,13 @@ SIGNATURES = {
     "adyolo_bn_bwd_tiles": (I, [P, P, P, P, I, I, P]),
     "adyolo_bn_bwd_apply": (I, [P] * 10 + [L, I, I, P]),
     "adyolo_se_fc_fwd": (I, [P] * 10 + [I, I, I, I, P]),
-    "adyolo_se_tail_fwd": (I, [P] * 6 + [I, I, I, P]),
-    "adyolo_se_tail_bwd_reduce": (I, [P] * 8 + [I, I, I, P]),
+    "adyolo_relu_mask_words": (L, [I, I, I]),
+    "adyolo_se_tail_fwd": (I, [P] * 7 + [I, I, I, P]),
+    "adyolo_se_tail_bwd_reduce": (I, [P] * 9 + [I, I, I, P]),
     "adyolo_se_tail_bwd_tiles": (I, [P, P, P, I, I, I, P]),
     "adyolo_se_fc_bwd_words": (L, [I, I]),
     "adyolo_se_fc_bwd": (I, [P] * 16 + [I, I, I, I, P]),
-    "adyolo_se_tail_bwd_apply": (I, [P] * 12 + [I, I, I, P]),
+    "adyolo_se_tail_bwd_apply": (I, [P] * 13 + [I, I, I, P]),
     "adyolo_avgpool2_fwd": (I, [P, P, I, I, I, I, P]),
     "adyolo_avgpool2_bwd": (I, [P, P, I, I, I, I, P]),
     "adyolo_add": (I, [P, P, P, L, P]),

@@ -67,17 +67,33 @@ struct BnBwdF {          // (dy, dy * xhat)
                         a.w * (xv.w - m.w) * is.w);
     }
 };
-struct SeBwdF {          // g = de * (e > 0): (g, g * xhat(c))
-    const float *de, *e, *c, *mean, *invstd; int HW, C;
+// ReLU mask of a tensor as bits: the float4 with global index i (4 consecutive channels) owns bit (i & 63) of the four
+// 64-bit words mask[(i >> 6) * 4 + k], k = component -- one wave-wide ballot per component when a wave covers 64
+// consecutive, 64-aligned float4s.  Reading the mask moves 1/32 of the bytes of reading the tensor itself.
+__device__ __forceinline__ void mask_bits4(const unsigned long long *__restrict__ mask, size_t i, bool &x, bool &y,
+                                           bool &z, bool &w) {
+    const ulonglong2 lo = *reinterpret_cast<const ulonglong2 *>(mask + (i >> 6) * 4);
+    const ulonglong2 hi = *reinterpret_cast<const ulonglong2 *>(mask + (i >> 6) * 4 + 2);
+    const int b = (int)(i & 63);
+    x = (lo.x >> b) & 1ull; y = (lo.y >> b) & 1ull; z = (hi.x >> b) & 1ull; w = (hi.y >> b) & 1ull;
+}
+
+struct SeBwdF {          // g = de * (e > 0): (g, g * xhat(c)); the mask comes from `mask` bits when given, else from e
+    const float *de, *e, *c, *mean, *invstd; const unsigned long long *mask; int HW, C;
     __device__ void operator()(int n, int r, int cx, float4 &a, float4 &b) const {
         const size_t o = ((size_t)n * HW + r) * C + cx * 4;
         const float4 d = *reinterpret_cast<const float4 *>(de + o);
-        const float4 ev = *reinterpret_cast<const float4 *>(e + o);
         const float4 cv = *reinterpret_cast<const float4 *>(c + o);
         const float4 m = *reinterpret_cast<const float4 *>(mean + cx * 4);
         const float4 is = *reinterpret_cast<const float4 *>(invstd + cx * 4);
-        a = make_float4(ev.x > 0.f ? d.x : 0.f, ev.y > 0.f ? d.y : 0.f, ev.z > 0.f ? d.z : 0.f,
-                        ev.w > 0.f ? d.w : 0.f);
+        bool px, py, pz, pw;
+        if (mask) {
+            mask_bits4(mask, o >> 2, px, py, pz, pw);
+        } else {
+            const float4 ev = *reinterpret_cast<const float4 *>(e + o);
+            px = ev.x > 0.f; py = ev.y > 0.f; pz = ev.z > 0.f; pw = ev.w > 0.f;
+        }
+        a = make_float4(px ? d.x : 0.f, py ? d.y : 0.f, pz ? d.z : 0.f, pw ? d.w : 0.f);
         b = make_float4(a.x * (cv.x - m.x) * is.x, a.y * (cv.y - m.y) * is.y, a.z * (cv.z - m.z) * is.z,
                         a.w * (cv.w - m.w) * is.w);
     }
@@ -122,6 +138,39 @@ __global__ void bn_stats_final_kernel(const float *__restrict__ ps0, const float
     if (rvar) {
         const double unbiased = R > 1.0 ? var * R / (R - 1.0) : var;
         rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    }
+}
+
+// stage 3, parallel form: 32 channels x 8 sample-groups per workgroup (double), then mean / invstd, the running
+// statistics update and -- when gamma / beta are given -- the affine (scale, shift) the consumers apply, in ONE launch
+// grid ceil(C/32)
+__global__ __launch_bounds__(256) void bn_finish_kernel(const float *__restrict__ ps0, const float *__restrict__ ps1,
+                                                        float *__restrict__ mean, float *__restrict__ invstd,
+                                                        float *__restrict__ rmean, float *__restrict__ rvar,
+                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                        float *__restrict__ scale, float *__restrict__ shift, int N, int C,
+                                                        double R, float momentum, float eps) {
+    __shared__ double red[256];
+    const int c0 = blockIdx.x * 32;
+    const double t0 = block_colsum32(ps0, N, (size_t)C, c0, C, red);
+    const double t1 = block_colsum32(ps1, N, (size_t)C, c0, C, red);
+    const int c = c0 + (threadIdx.x & 31);
+    if ((threadIdx.x >> 5) != 0 || c >= C) return;
+    const double m = t0 / R;
+    double var = t1 / R - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)m, is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = mf;
+    invstd[c] = is;
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * mf;
+    if (rvar) {
+        const double unbiased = R > 1.0 ? var * R / (R - 1.0) : var;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    }
+    if (scale) {
+        const float sc = gamma[c] * is;
+        scale[c] = sc;
+        shift[c] = beta[c] - mf * sc;
     }
 }
 
@@ -226,8 +275,9 @@ __global__ __launch_bounds__(256) void se_fc_fwd_kernel(
 
 __global__ __launch_bounds__(256) void se_tail_fwd_kernel(
     const float *__restrict__ c, const float *__restrict__ r, const float *__restrict__ scale,
-    const float *__restrict__ shift, const float *__restrict__ s, float *__restrict__ e, long hw4, int c4n) {
-    // grid (blocks, N): hw4 = HW * C/4 float4 per sample
+    const float *__restrict__ shift, const float *__restrict__ s, float *__restrict__ e,
+    unsigned long long *__restrict__ mask, long hw4, int c4n) {
+    // grid (blocks, N): hw4 = HW * C/4 float4 per sample; mask (optional, needs hw4 % 64 == 0): bits of (e > 0)
     const int n = blockIdx.y;
     const size_t base = (size_t)n * hw4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw4; i += (long)gridDim.x * blockDim.x) {
@@ -243,6 +293,12 @@ __global__ __launch_bounds__(256) void se_tail_fwd_kernel(
         o.z = fmaxf((cv.z * sc.z + sh.z) * sv.z + rv.z, 0.f);
         o.w = fmaxf((cv.w * sc.w + sh.w) * sv.w + rv.w, 0.f);
         reinterpret_cast<float4 *>(e)[base + i] = o;
+        if (mask) {      // the whole wave is here: i runs over 64-aligned groups of 64 and hw4 % 64 == 0
+            const unsigned long long bx = __ballot(o.x > 0.f), by = __ballot(o.y > 0.f);
+            const unsigned long long bz = __ballot(o.z > 0.f), bw = __ballot(o.w > 0.f);
+            const int lane = threadIdx.x & 63;
+            if (lane < 4) mask[((base + i) >> 6) * 4 + lane] = lane == 0 ? bx : (lane == 1 ? by : (lane == 2 ? bz : bw));
+        }
     }
 }
 
@@ -310,14 +366,20 @@ __global__ __launch_bounds__(256) void se_tail_bwd_apply_kernel(
     const float *__restrict__ de, const float *__restrict__ e, const float *__restrict__ c,
     const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ invstd,
     const float *__restrict__ s, const float *__restrict__ dpool, const float *__restrict__ sdd,
-    const float *__restrict__ sddx, float *__restrict__ dc, float *__restrict__ dr, long hw4, int c4n,
-    float invHW, float invR) {
+    const float *__restrict__ sddx, float *__restrict__ dc, float *__restrict__ dr,
+    const unsigned long long *__restrict__ mask, long hw4, int c4n, float invHW, float invR) {
     const int n = blockIdx.y;
     const size_t base = (size_t)n * hw4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw4; i += (long)gridDim.x * blockDim.x) {
         const int cx = (int)(i % c4n);
         const float4 d = reinterpret_cast<const float4 *>(de)[base + i];
-        const float4 ev = reinterpret_cast<const float4 *>(e)[base + i];
+        bool px, py, pz, pw;
+        if (mask) {
+            mask_bits4(mask, base + i, px, py, pz, pw);
+        } else {
+            const float4 ev = reinterpret_cast<const float4 *>(e)[base + i];
+            px = ev.x > 0.f; py = ev.y > 0.f; pz = ev.z > 0.f; pw = ev.w > 0.f;
+        }
         const float4 cv = reinterpret_cast<const float4 *>(c)[base + i];
         const float4 ga = reinterpret_cast<const float4 *>(gamma)[cx];
         const float4 m = reinterpret_cast<const float4 *>(mean)[cx];
@@ -327,10 +389,10 @@ __global__ __launch_bounds__(256) void se_tail_bwd_apply_kernel(
         const float4 a = reinterpret_cast<const float4 *>(sdd)[cx];
         const float4 b = reinterpret_cast<const float4 *>(sddx)[cx];
         float4 g, o;
-        g.x = ev.x > 0.f ? d.x : 0.f;
-        g.y = ev.y > 0.f ? d.y : 0.f;
-        g.z = ev.z > 0.f ? d.z : 0.f;
-        g.w = ev.w > 0.f ? d.w : 0.f;
+        g.x = px ? d.x : 0.f;
+        g.y = py ? d.y : 0.f;
+        g.z = pz ? d.z : 0.f;
+        g.w = pw ? d.w : 0.f;
         o.x = ga.x * is.x * (g.x * sv.x + dp.x * invHW - a.x * invR - (cv.x - m.x) * is.x * b.x * invR);
         o.y = ga.y * is.y * (g.y * sv.y + dp.y * invHW - a.y * invR - (cv.y - m.y) * is.y * b.y * invR);
         o.z = ga.z * is.z * (g.z * sv.z + dp.z * invHW - a.z * invR - (cv.z - m.z) * is.z * b.z * invR);
@@ -407,24 +469,27 @@ extern "C" int adyolo_bn_stats(const float *x, float *ssum, float *mean, float *
     hipLaunchKernelGGL(persample_reduce_kernel, dim3(cdiv(C, 32), N), dim3(256), 0, st, partial, ps0, ps1, N, G, C);
     rc = check_launch("bn_stats_persample");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, ps0, ps1, mean, invstd, running_mean,
-                       running_var, N, C, (double)N * (double)HW, momentum, eps);
+    hipLaunchKernelGGL(bn_finish_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, ps0, ps1, mean, invstd, running_mean,
+                       running_var, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, (float *)nullptr, N, C,
+                       (double)N * (double)HW, momentum, eps);
     return check_launch("bn_stats_final");
 }
 
 extern "C" int adyolo_bn_stats_tiles(const float *tile_stats, float *ssum, float *mean, float *invstd,
-                                     float *running_mean, float *running_var, float *partial, int N, int G, int HW,
-                                     int C, float momentum, float eps, void *stream) {
+                                     float *running_mean, float *running_var, const float *gamma, const float *beta,
+                                     float *scale, float *shift, float *partial, int N, int G, int HW, int C,
+                                     float momentum, float eps, void *stream) {
     ADYOLO_REQUIRE(tile_stats && mean && invstd && partial && N > 0 && G > 0 && HW > 0 && C > 0 && N <= 1024,
                    ADYOLO_EINVAL, "bn_stats_tiles: bad arguments");
+    ADYOLO_REQUIRE(!scale || (gamma && beta && shift), ADYOLO_EINVAL, "bn_stats_tiles: scale needs gamma, beta and shift");
     hipStream_t st = as_stream(stream);
     float *ps0 = ssum ? ssum : partial;
     float *ps1 = partial + (size_t)1024 * C;
     hipLaunchKernelGGL(persample_reduce_kernel, dim3(cdiv(C, 32), N), dim3(256), 0, st, tile_stats, ps0, ps1, N, G, C);
     int rc = check_launch("bn_stats_tiles_persample");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, ps0, ps1, mean, invstd, running_mean,
-                       running_var, N, C, (double)N * (double)HW, momentum, eps);
+    hipLaunchKernelGGL(bn_finish_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, ps0, ps1, mean, invstd, running_mean,
+                       running_var, gamma, beta, scale, shift, N, C, (double)N * (double)HW, momentum, eps);
     return check_launch("bn_stats_tiles_final");
 }
 
@@ -521,27 +586,33 @@ extern "C" int adyolo_se_fc_fwd(const float *ssum, const float *scale, const flo
     return check_launch("se_fc_fwd");
 }
 
+extern "C" long adyolo_relu_mask_words(int N, int HW, int C) {
+    const long hw4 = (long)HW * (C / 4);
+    return (C % 4 == 0 && hw4 % 64 == 0) ? (long)N * hw4 / 64 * 4 : 0;
+}
+
 extern "C" int adyolo_se_tail_fwd(const float *c, const float *r, const float *scale, const float *shift,
-                                  const float *s, float *e, int N, int HW, int C, void *stream) {
+                                  const float *s, float *e, uint64_t *mask, int N, int HW, int C, void *stream) {
     ADYOLO_REQUIRE(c && r && scale && shift && s && e && N > 0 && HW > 0 && C % 4 == 0, ADYOLO_EINVAL,
                    "se_tail_fwd: bad arguments");
     const long hw4 = (long)HW * (C / 4);
+    ADYOLO_REQUIRE(!mask || hw4 % 64 == 0, ADYOLO_ENOSUP, "se_tail_fwd: mask bits need HW*C/4 %% 64 == 0 (HW=%d C=%d)", HW, C);
     int gx = ew_grid(hw4);
     if ((long)gx * N > 16384) gx = (int)(16384 / N > 0 ? 16384 / N : 1);
-    hipLaunchKernelGGL(se_tail_fwd_kernel, dim3(gx, N), dim3(256), 0, as_stream(stream), c, r, scale, shift, s, e, hw4,
-                       C / 4);
+    hipLaunchKernelGGL(se_tail_fwd_kernel, dim3(gx, N), dim3(256), 0, as_stream(stream), c, r, scale, shift, s, e,
+                       reinterpret_cast<unsigned long long *>(mask), hw4, C / 4);
     return check_launch("se_tail_fwd");
 }
 
-extern "C" int adyolo_se_tail_bwd_reduce(const float *de, const float *e, const float *c, const float *mean,
-                                         const float *invstd, float *sg, float *sgx, float *partial, int N, int HW,
-                                         int C, void *stream) {
-    ADYOLO_REQUIRE(de && e && c && mean && invstd && sg && sgx && partial && N > 0 && HW > 0, ADYOLO_EINVAL,
+extern "C" int adyolo_se_tail_bwd_reduce(const float *de, const float *e, const uint64_t *mask, const float *c,
+                                         const float *mean, const float *invstd, float *sg, float *sgx, float *partial,
+                                         int N, int HW, int C, void *stream) {
+    ADYOLO_REQUIRE(de && (e || mask) && c && mean && invstd && sg && sgx && partial && N > 0 && HW > 0, ADYOLO_EINVAL,
                    "se_tail_bwd_reduce: bad arguments");
     ADYOLO_REQUIRE(chan_ok(C) && N <= 1024, ADYOLO_ENOSUP, "se_tail_bwd_reduce: unsupported C=%d or N=%d", C, N);
     hipStream_t st = as_stream(stream);
     const int G = pick_G(N, HW);
-    SeBwdF f{de, e, c, mean, invstd, HW, C};
+    SeBwdF f{de, e, c, mean, invstd, reinterpret_cast<const unsigned long long *>(mask), HW, C};
     hipLaunchKernelGGL((reduce2_partial_kernel<SeBwdF>), dim3(G, N), dim3(256), 0, st, f, partial, HW, C, G);
     int rc = check_launch("se_tail_bwd_reduce_partial");
     if (rc) return rc;
@@ -577,18 +648,19 @@ extern "C" int adyolo_se_fc_bwd(const float *sg, const float *sgx, const float *
     return adyolo_colsum(part, packed, colsum_ws, N, (int)P, (int)P, 0, stream);
 }
 
-extern "C" int adyolo_se_tail_bwd_apply(const float *de, const float *e, const float *c, const float *gamma,
-                                        const float *mean, const float *invstd, const float *s, const float *dpool,
-                                        const float *sdd, const float *sddx, float *dc, float *dr, int N, int HW,
-                                        int C, void *stream) {
-    ADYOLO_REQUIRE(de && e && c && gamma && mean && invstd && s && dpool && sdd && sddx && dc && N > 0 &&
+extern "C" int adyolo_se_tail_bwd_apply(const float *de, const float *e, const uint64_t *mask, const float *c,
+                                        const float *gamma, const float *mean, const float *invstd, const float *s,
+                                        const float *dpool, const float *sdd, const float *sddx, float *dc, float *dr,
+                                        int N, int HW, int C, void *stream) {
+    ADYOLO_REQUIRE(de && (e || mask) && c && gamma && mean && invstd && s && dpool && sdd && sddx && dc && N > 0 &&
                        HW > 0 && C % 4 == 0,
                    ADYOLO_EINVAL, "se_tail_bwd_apply: bad arguments");
     const long hw4 = (long)HW * (C / 4);
     int gx = ew_grid(hw4);
     if ((long)gx * N > 16384) gx = (int)(16384 / N > 0 ? 16384 / N : 1);
     hipLaunchKernelGGL(se_tail_bwd_apply_kernel, dim3(gx, N), dim3(256), 0, as_stream(stream), de, e, c, gamma, mean,
-                       invstd, s, dpool, sdd, sddx, dc, dr, hw4, C / 4, 1.0f / (float)HW,
+                       invstd, s, dpool, sdd, sddx, dc, dr, reinterpret_cast<const unsigned long long *>(mask), hw4,
+                       C / 4, 1.0f / (float)HW,
                        (float)(1.0 / ((double)N * (double)HW)));
     return check_launch("se_tail_bwd_apply");
 }

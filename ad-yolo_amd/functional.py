@@ -25,6 +25,9 @@ FUSE_BNBWD = os.environ.get("ADYOLO_FUSE_BNBWD", "1") != "0"
 # of the 16 blocks, bit-compatible with the unfused path in the golden tests, but the two extra tensors the epilogue
 # reads cost what the removed pass saved (168.5 vs 168.3 ms per step): off by default, kept as an A/B switch.
 FUSE_SEBWD = os.environ.get("ADYOLO_FUSE_SEBWD", "0") != "0"
+# The block's final ReLU mask (e > 0) is written as bits by se_tail_fwd (1/32 of the bytes of e) and the two backward passes
+# of the SE tail read the bits instead of e: 7 -> 5.06 tensor passes for se_tail_bwd.
+FUSE_MASKBITS = os.environ.get("ADYOLO_FUSE_MASKBITS", "1") != "0"
 
 
 class BlockLink:
@@ -55,16 +58,18 @@ class _BNState:
             mean, invstd = ops.bn_eval_stats(m.running_mean, m.running_var, m.eps)
         return ssum, mean, invstd
 
-    def stats_tiles(self, tile_stats, x, update=True):
-        """Training-mode statistics from the per-patch sums a conv epilogue produced (no extra read pass)."""
+    def stats_tiles(self, tile_stats, x, update=True, affine=None):
+        """Training-mode statistics from the per-patch sums a conv epilogue produced (no extra read pass).
+        affine=(gamma, beta): the same finishing launch also returns (scale, shift)."""
         m = self.mod
         n, c = x.shape[0], x.shape[-1]
         hw = x.numel() // (n * c)
+        g, b = affine if affine is not None else (None, None)
         if update:
-            out = ops.bn_stats_tiles(tile_stats, n, hw, m.running_mean, m.running_var, m.momentum, m.eps)
+            out = ops.bn_stats_tiles(tile_stats, n, hw, m.running_mean, m.running_var, m.momentum, m.eps, g, b)
             m.num_batches_tracked += 1
             return out
-        return ops.bn_stats_tiles(tile_stats, n, hw, None, None, m.momentum, m.eps)
+        return ops.bn_stats_tiles(tile_stats, n, hw, None, None, m.momentum, m.eps, g, b)
 
 
 class StemFn(torch.autograd.Function):
@@ -75,11 +80,11 @@ class StemFn(torch.autograd.Function):
         wpk, _ = ops.pack_w3x3(w, 8, want_dgrad=False)
         if training and FUSE_STATS:
             a, st = ops.conv3x3(x8, wpk, w.shape[0], bias=b, relu=True, want_stats=True)
-            _, mean, invstd = _BNState(bn).stats_tiles(st, a)
+            _, mean, invstd, scale, shift = _BNState(bn).stats_tiles(st, a, affine=(gamma, beta))
         else:
             a = ops.conv3x3(x8, wpk, w.shape[0], bias=b, relu=True)
             _, mean, invstd = _BNState(bn).stats(a, False)
-        scale, shift = ops.bn_scale_shift(gamma, beta, mean, invstd)
+            scale, shift = ops.bn_scale_shift(gamma, beta, mean, invstd)
         out = ops.affine(a, scale, shift)
         ctx.training = training
         ctx.cin_real = w.shape[1]
@@ -115,11 +120,11 @@ class SEBlockFn(torch.autograd.Function):
         wpk1, wpk1d = ops.pack_w3x3(w1, cin)
         if training and FUSE_STATS:
             a, st1 = ops.conv3x3(p, wpk1, c, relu=True, want_stats=True)
-            _, mean1, invstd1 = _BNState(bn1).stats_tiles(st1, a)
+            _, mean1, invstd1, scale1, shift1 = _BNState(bn1).stats_tiles(st1, a, affine=(g1, b1))
         else:
             a = ops.conv3x3(p, wpk1, c, relu=True)
             _, mean1, invstd1 = _BNState(bn1).stats(a, training)
-        scale1, shift1 = ops.bn_scale_shift(g1, b1, mean1, invstd1)
+            scale1, shift1 = ops.bn_scale_shift(g1, b1, mean1, invstd1)
         wpk2, wpk2d = ops.pack_w3x3(w2, c)
         if FUSE_AFFINE:
             # BN1's affine is applied while conv2 stages its input: bn1(a) is never written to HBM
@@ -128,19 +133,22 @@ class SEBlockFn(torch.autograd.Function):
             src, aff = ops.affine(a, scale1, shift1), None
         if FUSE_STATS:
             cc, st2 = ops.conv3x3(src, wpk2, c, in_affine=aff, want_stats=True)
+            scale2 = None
             if training:
-                ssum2, mean2, invstd2 = _BNState(bn2).stats_tiles(st2, cc)
+                ssum2, mean2, invstd2, scale2, shift2 = _BNState(bn2).stats_tiles(st2, cc, affine=(g2, b2))
             else:
                 ssum2, _, _ = _BNState(bn2).stats_tiles(st2, cc, update=False)
                 _, mean2, invstd2 = _BNState(bn2).stats(cc, False)
         else:
+            scale2 = None
             cc = ops.conv3x3(src, wpk2, c, in_affine=aff)
             if training:
                 ssum2, mean2, invstd2 = _BNState(bn2).stats(cc, True)
             else:
                 ssum2, _, _ = ops.bn_stats(cc, None, None)
                 _, mean2, invstd2 = _BNState(bn2).stats(cc, False)
-        scale2, shift2 = ops.bn_scale_shift(g2, b2, mean2, invstd2)
+        if scale2 is None:
+            scale2, shift2 = ops.bn_scale_shift(g2, b2, mean2, invstd2)
         pooled, hid, s = ops.se_fc_fwd(ssum2, scale2, shift2, fw1, fb1, fw2, fb2, h * w_)
         q = None
         meand = invstdd = None
@@ -151,7 +159,10 @@ class SEBlockFn(torch.autograd.Function):
             r = ops.affine(q, scaled, shiftd)
         else:
             r = p
-        e = ops.se_tail_fwd(cc, r, scale2, shift2, s)
+        if training and FUSE_MASKBITS:
+            e, ebits = ops.se_tail_fwd(cc, r, scale2, shift2, s, want_mask=True)
+        else:
+            e, ebits = ops.se_tail_fwd(cc, r, scale2, shift2, s), None
         ctx.link_in = link_in if (FUSE_SEBWD and FUSE_DR and training and link_in is not None and not pool
                                   and wd is None and link_in.cc is not None) else None
         ctx.link_out = link_out if (FUSE_SEBWD and training) else None
@@ -161,8 +172,11 @@ class SEBlockFn(torch.autograd.Function):
         ctx.in_hw = (x.shape[1], x.shape[2])
         ctx.fused_affine = aff is not None
         ctx.a_unfused = None if aff is not None else a      # (A/B switch only; keeps `a` alive for BN1's backward)
+        ctx.has_bits = ebits is not None
         tensors = [p, src, scale1, cc, e, g1, mean1, invstd1, g2, b2, mean2, invstd2, ssum2, pooled, hid, s, fw1, fw2,
                    wpk1d, wpk2d, shift1]
+        if ebits is not None:
+            tensors.append(ebits)
         if wd is not None:
             tensors += [q, wd, gd, meand, invstdd]
         ctx.save_for_backward(*tensors)
@@ -181,9 +195,14 @@ class SEBlockFn(torch.autograd.Function):
         tiles = None
         if ctx.link_out is not None and ctx.link_out.tiles is not None:
             tiles, ctx.link_out.tiles = ctx.link_out.tiles, None      # left by the block above (its dgrad produced `de`)
+        nb = 21
+        ebits = None
+        if ctx.has_bits:
+            ebits, nb = t[21], 22
         dc, dr, dg2, db2, dfw1, dfb1, dfw2, dfb2 = ops.se_tail_bwd(de, e, cc, g2, b2, mean2, invstd2, ssum2, pooled,
                                                                    hid, s, fw1, fw2,
-                                                                   want_dr=ctx.has_down or not FUSE_DR, tile_stats=tiles)
+                                                                   want_dr=ctx.has_down or not FUSE_DR, tile_stats=tiles,
+                                                                   mask=ebits)
         if ctx.fused_affine:
             a = src
             dw2 = ops.conv3x3_wgrad(a, dc, c, in_affine=(scale1, shift1))
@@ -199,7 +218,7 @@ class SEBlockFn(torch.autograd.Function):
         dw1 = ops.conv3x3_wgrad(p, da, cin)
         dwd = dgd = dbd = None
         if ctx.has_down:
-            q, wd, gd, meand, invstdd = t[21:26]
+            q, wd, gd, meand, invstdd = t[nb:nb + 5]
             dq, dgd, dbd = ops.bn_bwd(dr, q, gd, meand, invstdd, relu_mask=False)
             rows = n * h * w_
             dwd = ops.gemm(dq, p, c, cin, rows, c, cin, trans_a=True, trans_b=True,

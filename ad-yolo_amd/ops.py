@@ -214,14 +214,19 @@ def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
     return ssum, mean, invstd
 
 
-def bn_stats_tiles(tile_stats, n, hw, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
-    """BatchNorm statistics from the per-patch sums of a convolution epilogue ([2][tiles][C])."""
-    _chk(tile_stats, running_mean, running_var)
+def bn_stats_tiles(tile_stats, n, hw, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, gamma=None,
+                   beta=None):
+    """BatchNorm statistics from the per-patch sums of a convolution epilogue ([2][tiles][C]) -> ssum, mean, invstd
+    (+ scale = gamma*invstd, shift = beta - mean*scale from the same finishing launch when gamma / beta are given)."""
+    _chk(tile_stats, running_mean, running_var, gamma, beta)
     tiles, c = tile_stats.shape[1], tile_stats.shape[2]
     ssum, mean, invstd = _new(tile_stats, n, c), _new(tile_stats, c), _new(tile_stats, c)
+    scale, shift = (_new(tile_stats, c), _new(tile_stats, c)) if gamma is not None else (None, None)
     partial = _new(tile_stats, 2 * 1024 * c)
     _c("adyolo_bn_stats_tiles", _p(tile_stats), _p(ssum), _p(mean), _p(invstd), _p(running_mean), _p(running_var),
-       _p(partial), n, tiles // n, hw, c, momentum, eps, _stream())
+       _p(gamma), _p(beta), _p(scale), _p(shift), _p(partial), n, tiles // n, hw, c, momentum, eps, _stream())
+    if gamma is not None:
+        return ssum, mean, invstd, scale, shift
     return ssum, mean, invstd
 
 
@@ -279,20 +284,29 @@ def se_fc_fwd(ssum, scale, shift, w1, b1, w2, b2, hw):
     return pooled, hid, s
 
 
-def se_tail_fwd(c_t, r_t, scale, shift, s):
+def se_tail_fwd(c_t, r_t, scale, shift, s, want_mask=False):
+    """e = relu((c*scale+shift)*s + r).  want_mask: also return the ReLU mask (e > 0) as bits (int64 words, 1/32 of the
+    bytes of e) for ``se_tail_bwd(..., mask=)``; None when the shape does not support it (HW*C/4 % 64 != 0)."""
     _chk(c_t, r_t, scale, shift, s)
     n, ch = c_t.shape[0], c_t.shape[-1]
     hw = c_t.numel() // (n * ch)
     e = torch.empty_like(c_t)
-    _c("adyolo_se_tail_fwd", _p(c_t), _p(r_t), _p(scale), _p(shift), _p(s), _p(e), n, hw, ch, _stream())
-    return e
+    mask = None
+    if want_mask:
+        words = _lib.load().adyolo_relu_mask_words(n, hw, ch)
+        if words > 0:
+            mask = torch.empty(words, dtype=torch.int64, device=c_t.device)
+    _c("adyolo_se_tail_fwd", _p(c_t), _p(r_t), _p(scale), _p(shift), _p(s), _p(e), _p(mask), n, hw, ch, _stream())
+    return (e, mask) if want_mask else e
 
 
-def se_tail_bwd(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1, w2, want_dr=True, tile_stats=None):
+def se_tail_bwd(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1, w2, want_dr=True, tile_stats=None,
+                mask=None):
     """Backward of  e = relu(bn2(c) * s + r)  incl. the SE FCs.
     -> dc, dr, dgamma, dbeta, dw1, db1, dw2, db2
     tile_stats: per-patch sums [2][tiles][C] of de * (e > 0) and de * (e > 0) * xhat(c) from the convolution epilogue
-    that produced ``de`` (``conv3x3(..., stat_bn=(c, mean, invstd), stat_mask=e)``): the reduction pass is skipped."""
+    that produced ``de`` (``conv3x3(..., stat_bn=(c, mean, invstd), stat_mask=e)``): the reduction pass is skipped.
+    mask: the bits ``se_tail_fwd(..., want_mask=True)`` returned; both passes then read them instead of e."""
     _chk(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1, w2)
     n, ch = c_t.shape[0], c_t.shape[-1]
     hw = c_t.numel() // (n * ch)
@@ -302,8 +316,8 @@ def se_tail_bwd(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1,
         _c("adyolo_se_tail_bwd_tiles", _p(tile_stats), _p(sg), _p(sgx), n, tile_stats.shape[1] // n, ch, _stream())
     else:
         partial = _new(c_t, 2 * 1024 * ch)
-        _c("adyolo_se_tail_bwd_reduce", _p(de), _p(e), _p(c_t), _p(mean), _p(invstd), _p(sg), _p(sgx), _p(partial), n, hw,
-           ch, _stream())
+        _c("adyolo_se_tail_bwd_reduce", _p(de), _p(e), _p(mask), _p(c_t), _p(mean), _p(invstd), _p(sg), _p(sgx), _p(partial),
+           n, hw, ch, _stream())
     pw = 2 * ch * cr + cr + 3 * ch
     part, packed, cws = _new(c_t, n, pw), _new(c_t, pw), _new(c_t, 1024, pw)
     dpool = _new(c_t, n, ch)
@@ -319,8 +333,8 @@ def se_tail_bwd(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1,
     dgamma, dbeta = sddx, sdd
     dc = torch.empty_like(c_t)
     dr = torch.empty_like(c_t) if want_dr else None
-    _c("adyolo_se_tail_bwd_apply", _p(de), _p(e), _p(c_t), _p(gamma), _p(mean), _p(invstd), _p(s), _p(dpool), _p(sdd),
-       _p(sddx), _p(dc), _p(dr), n, hw, ch, _stream())
+    _c("adyolo_se_tail_bwd_apply", _p(de), _p(e), _p(mask), _p(c_t), _p(gamma), _p(mean), _p(invstd), _p(s), _p(dpool),
+       _p(sdd), _p(sddx), _p(dc), _p(dr), n, hw, ch, _stream())
     return dc, dr, dgamma, dbeta, dw1, db1, dw2, db2
 
 

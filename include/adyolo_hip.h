@@ -148,10 +148,11 @@ int adyolo_bn_stats(const float *x, float *ssum, float *mean, float *invstd, flo
                     float *running_var, float *partial, int N, int HW, int C, float momentum,
                     float eps, void *stream);
 /* same as adyolo_bn_stats but from the per-patch sums a convolution epilogue wrote (tiles = G*N, patch index
- * n*G + g); partial: workspace of 2*1024*C floats */
+ * n*G + g); partial: workspace of 2*1024*C floats.  With gamma / beta / scale / shift (all or none) the same finishing
+ * launch also writes scale = gamma*invstd, shift = beta - mean*scale (what adyolo_bn_scale_shift would compute). */
 int adyolo_bn_stats_tiles(const float *tile_stats, float *ssum, float *mean, float *invstd, float *running_mean,
-                          float *running_var, float *partial, int N, int G, int HW, int C, float momentum,
-                          float eps, void *stream);
+                          float *running_var, const float *gamma, const float *beta, float *scale, float *shift,
+                          float *partial, int N, int G, int HW, int C, float momentum, float eps, void *stream);
 int adyolo_bn_eval_stats(const float *running_mean, const float *running_var, float *mean,
                          float *invstd, int C, float eps, void *stream);
 int adyolo_bn_scale_shift(const float *gamma, const float *beta, const float *mean,
@@ -184,10 +185,15 @@ int adyolo_bn_bwd_apply(const float *dy, const float *x, const float *gamma, con
 int adyolo_se_fc_fwd(const float *ssum, const float *scale, const float *shift, const float *w1,
                      const float *b1, const float *w2, const float *b2, float *pooled, float *hid,
                      float *s, int N, int HW, int C, int Cr, void *stream);
+/* mask (optional): the ReLU mask (e > 0) as bits -- float4 i (4 consecutive channels) of the flattened tensor owns bit
+ * (i & 63) of the 64-bit words mask[(i >> 6) * 4 + k], k = component; adyolo_relu_mask_words(N, HW, C) words (0 = shape
+ * not supported: HW*C/4 must be a multiple of 64).  The backward passes then read the bits (1/32 of the bytes) instead
+ * of e; with mask given, e may be NULL there. */
+long adyolo_relu_mask_words(int N, int HW, int C);
 int adyolo_se_tail_fwd(const float *c, const float *r, const float *scale, const float *shift,
-                       const float *s, float *e, int N, int HW, int C, void *stream);
-int adyolo_se_tail_bwd_reduce(const float *de, const float *e, const float *c, const float *mean,
-                              const float *invstd, float *sg, float *sgx, float *partial, int N,
+                       const float *s, float *e, uint64_t *mask /*or NULL*/, int N, int HW, int C, void *stream);
+int adyolo_se_tail_bwd_reduce(const float *de, const float *e, const uint64_t *mask /*or NULL*/, const float *c,
+                              const float *mean, const float *invstd, float *sg, float *sgx, float *partial, int N,
                               int HW, int C, void *stream);
 /* sg, sgx from per-patch sums [2][N*G][C] of a convolution epilogue run with stat_mask = e, stat_aux = c */
 int adyolo_se_tail_bwd_tiles(const float *tile_stats, float *sg, float *sgx, int N, int G, int C, void *stream);
@@ -197,8 +203,8 @@ int adyolo_se_fc_bwd(const float *sg, const float *sgx, const float *ssum, const
                      const float *hid, const float *s, const float *w1, const float *w2, float *dpool,
                      float *part /*[N][P]*/, float *packed /*[P]*/, float *colsum_ws /*[1024][P]*/, int N,
                      int HW, int C, int Cr, void *stream);
-int adyolo_se_tail_bwd_apply(const float *de, const float *e, const float *c, const float *gamma,
-                             const float *mean, const float *invstd, const float *s,
+int adyolo_se_tail_bwd_apply(const float *de, const float *e, const uint64_t *mask /*or NULL*/, const float *c,
+                             const float *gamma, const float *mean, const float *invstd, const float *s,
                              const float *dpool, const float *sdd, const float *sddx, float *dc,
                              float *dr, int N, int HW, int C, void *stream);
 

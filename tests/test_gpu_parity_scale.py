@@ -46,11 +46,12 @@ def _rel(got, ref):
 
 
 # ------------------------------------------------------------------------------ the reference's training shape, default init
-def _align_relu_masks(model, captured, g):
+def _align_relu_masks(model, captured, g, bits=None):
     """Give the fragile ReLU elements (golden: float64 pre-activation within 1e-4 x absmax of zero) the float64 mask.
-    The build derives every ReLU mask in backward from a saved ReLU OUTPUT (`a > 0`, `e > 0`), so a fragile element that
-    must count as positive becomes 1e-30 and one that must not becomes 0 -- a change of at most the activation round-off
-    in value, and exactly the reference's subgradient in backward.  Returns the number of masks that had to change."""
+    The build derives every ReLU mask in backward from a saved ReLU OUTPUT (`a > 0`, `e > 0`) -- or, for the SE tail, from
+    the mask BITS the forward stored (``bits[site]``) -- so a fragile element that must count as positive becomes 1e-30
+    (bit set) and one that must not becomes 0 (bit cleared): a change of at most the activation round-off in value, and
+    exactly the reference's subgradient in backward.  Returns the number of masks that had to change."""
     flips = 0
     for site, t in captured.items():
         idx = torch.from_numpy(g["fragile_idx_" + site].astype(np.int64))
@@ -63,6 +64,16 @@ def _align_relu_masks(model, captured, g):
         cur = v[flat]
         flips += int(((cur > 0) != pos).sum())
         v[flat] = torch.where(pos, torch.where(cur > 0, cur, torch.full_like(cur, 1e-30)), torch.zeros_like(cur))
+        if bits is not None and site in bits:                  # float4 i = flat >> 2 owns bit (i & 63) of word (i >> 6) * 4 + k
+            words = bits[site].cpu().numpy().view(np.uint64)
+            f = flat.cpu().numpy().astype(np.uint64)
+            i4, k = f >> np.uint64(2), f & np.uint64(3)
+            w = ((i4 >> np.uint64(6)) * np.uint64(4) + k).astype(np.int64)
+            one = np.uint64(1) << (i4 & np.uint64(63))
+            p = pos.cpu().numpy()
+            np.bitwise_or.at(words, w[p], one[p])
+            np.bitwise_and.at(words, w[~p], ~one[~p])
+            bits[site].copy_(torch.from_numpy(words.view(np.int64)))
     return flips
 
 
@@ -99,13 +110,15 @@ def test_seed100_training_step_matches_reference(ops, monkeypatch, algo):
     x = torch.randn(2, 7, 800, 64, generator=torch.Generator().manual_seed(int(g["x_seed"])))
     assert abs(float(x.double().sum()) - float(g["x_sum"])) < 1e-6 and np.array_equal(x.reshape(-1)[:16].numpy(), g["x_head"])
     target = torch.from_numpy(g["target"])
-    captured, hooks = {}, []
+    captured, bits, hooks = {}, {}, []
 
     def grab(site_a, site_e, is_first):
         def hook(mod, inp, out):
             saved = out.grad_fn.saved_tensors                  # SEBlockFn: [p, src (= relu(conv1)), scale1, cc, e, ...]
             assert saved[4].data_ptr() == out.data_ptr()
             captured[site_a], captured[site_e] = saved[1], out
+            if out.grad_fn.has_bits:
+                bits[site_e] = saved[21]                       # (e > 0) as bits, read by the SE-tail backward
             if is_first:
                 captured["stem"] = inp[0].grad_fn.saved_tensors[1]     # StemFn: [x8, a (= relu(conv + bias)), ...]
         return hook
@@ -117,7 +130,7 @@ def test_seed100_training_step_matches_reference(ops, monkeypatch, algo):
     loss = WrapperCriterion(prm)(logit, target)
     for h in hooks:
         h.remove()
-    assert len(captured) == 33
+    assert len(captured) == 33 and len(bits) == 16
     torch.cuda.synchronize()
     y_ref = torch.from_numpy(g["y_train"])
     assert float((y.detach().cpu() - y_ref).abs().max()) <= 1e-3, "encoder output (tanh range) vs reference"
@@ -160,7 +173,7 @@ def test_seed100_training_step_matches_reference(ops, monkeypatch, algo):
     compare("as they come", lambda ref_noise: max(1e-3, 5.0 * ref_noise), 0.9999)
     for p in model.parameters():
         p.grad = None
-    flips = _align_relu_masks(model, captured, g)
+    flips = _align_relu_masks(model, captured, g, bits)
     loss.backward()
     torch.cuda.synchronize()
     print("[%s] %d of the %d fragile ReLU masks differed from float64" % (algo, flips, sum(v.numel() for v in captured.values()) and
@@ -439,7 +452,9 @@ def test_bucketed_allreduce_hooks_on_the_real_model(ops):
             env["ADYOLO_FORCE_DP_HOOKS"] = "1"
         r = subprocess.run([sys.executable, "-c", _DP_CHILD], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
-        return json.loads(r.stdout.strip().splitlines()[-1])
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"digest"')]
+        assert lines, "child printed no result line: %r / %r" % (r.stdout[-1000:], r.stderr[-1000:])
+        return json.loads(lines[-1])
     hooked, plain = child(True), child(False)
     assert hooked["dist"] and hooked["active"] and not plain["active"]
     assert hooked["buckets"] == 4 and all(f == [4, 0] for f in hooked["fired"]), hooked["fired"]
