@@ -59,18 +59,17 @@ class FeatureExtractor:
         self.device = torch.device(device)
         n = np.arange(N_FFT, dtype=np.float64)
         tw = np.stack([np.cos(2.0 * np.pi * n / N_FFT), -np.sin(2.0 * np.pi * n / N_FFT)], axis=1)
-        win = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / N_FFT)
         mel = slaney_mel_matrix()
-        # non-zero weights filter after filter, each (contiguous, triangular) filter cut into pieces of <= 16 bins so
+        # non-zero weights filter after filter, each (contiguous, triangular) filter cut into pieces of <= 8 bins so
         # that the kernel's work items are balanced (filters span 2 .. ~70 bins)
         ck_mel, ck_start, ck_len, ck_off, weights = [], [], [], [], []
         for m in range(N_MELS):
             nz = np.nonzero(mel[m])[0]
             s, e = int(nz[0]), int(nz[-1]) + 1
-            for c0 in range(s, e, 16):
+            for c0 in range(s, e, 8):
                 ck_mel.append(m)
                 ck_start.append(c0)
-                ck_len.append(min(16, e - c0))
+                ck_len.append(min(8, e - c0))
                 ck_off.append(len(weights) + (c0 - s))
             weights.extend(mel[m, s:e].tolist())
         mean = np.zeros((7, N_MELS), dtype=np.float64)
@@ -83,28 +82,40 @@ class FeatureExtractor:
         dev = self.device
         f32 = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev).contiguous()   # noqa: E731
         i32 = lambda a: torch.tensor(np.asarray(a, dtype=np.int32), device=dev).contiguous()     # noqa: E731
-        self.twiddle, self.window = f32(tw), f32(win)
+        self.twiddle = f32(tw)
         self.ck_mel, self.ck_start, self.ck_len, self.ck_off = i32(ck_mel), i32(ck_start), i32(ck_len), i32(ck_off)
         self.n_chunks = len(ck_mel)
         self.mel_w = f32(weights)
         self.sc_mean, self.sc_rstd = f32(mean), f32(1.0 / std)
         self.mel_nnz = len(weights)
 
-    def __call__(self, audio, channels_last8=True):
+    def __call__(self, audio, channels_last8=True, chunk_offsets=None, chunk_samples=None):
         """-> (B, T, 64, 8) float32 channels-last (8th channel zero) when ``channels_last8`` (what the
-        encoder consumes), else (B, 7, T, 64) in the reference's layout (datasets.py:158-160)."""
+        encoder consumes), else (B, 7, T, 64) in the reference's layout (datasets.py:158-160).
+
+        chunk_offsets (int64 tensor on the device, sample offsets into the flattened (B * n_samples) audio) with
+        chunk_samples: features of the CHUNKS ``audio.view(-1, 4)[off : off + chunk_samples]`` instead (one output row
+        per offset) -- the reference's offline chunking (src/preprocess.py:13-84: 20 s windows at 1 s stride, each chunk
+        its own file, hence its own reflect padding and top_db reference) without materialising the chunk audio."""
         if not audio.is_cuda or audio.dtype != torch.float32 or not audio.is_contiguous():
             raise _lib.AdyoloHipError("FeatureExtractor needs contiguous float32 audio (B, n_samples, 4) on the GPU")
         b, n, ch = audio.shape
         if ch != 4 or n % HOP != 0:
             raise _lib.AdyoloHipError("audio must be (B, n_samples, 4) with n_samples %% 600 == 0")
+        offs = None
+        if chunk_offsets is not None:
+            if (chunk_offsets.dtype != torch.int64 or not chunk_offsets.is_cuda or not chunk_offsets.is_contiguous()
+                    or chunk_samples is None or chunk_samples % HOP != 0 or chunk_samples < N_FFT):
+                raise _lib.AdyoloHipError("chunk_offsets must be a contiguous int64 device tensor and chunk_samples a "
+                                          "multiple of 600 (>= 1200)")
+            offs, b, n = chunk_offsets, chunk_offsets.numel(), int(chunk_samples)
         t = n // HOP
         layout = 1 if channels_last8 else 0
         out = torch.empty((b, t, N_MELS, 8) if channels_last8 else (b, 7, t, N_MELS), dtype=torch.float32,
                           device=audio.device)
         chan_max = torch.empty(b * 4, dtype=torch.float32, device=audio.device)
         st = _stream()
-        _lib.call("adyolo_feat_stft_mel", _p(audio), _p(self.twiddle), _p(self.window), _p(self.ck_mel),
+        _lib.call("adyolo_feat_stft_mel", _p(audio), _p(offs), _p(self.twiddle), _p(self.ck_mel),
                   _p(self.ck_start), _p(self.ck_len), _p(self.ck_off), _p(self.mel_w), self.n_chunks, self.mel_nnz,
                   _p(self.sc_mean), _p(self.sc_rstd), _p(out), _p(chan_max), b, n, layout, st)
         _lib.call("adyolo_feat_finish", _p(out), _p(chan_max), _p(self.sc_mean), _p(self.sc_rstd), b, t, layout, st)

@@ -35,10 +35,14 @@ const char *adyolo_last_error(void);
  *     replaces src/datasets.py:252-292 (librosa.core.stft :255, mel GEMM :264/:275, power_to_db :265,
  *     scaler :289-290) and the tensorise/concat step :158-160.
  *   audio   [B][n_samples][4] float32, already int16/32768 + 1e-8 (datasets.py:147), channels W,Y,Z,X
- *   twiddle [1200][2]  exp(-2 pi i n/1200) (re,im);  window [1200];
- *   mel_w   [n_mel_w <= 1280] float32 non-zero weights of the 64 (contiguous, triangular) mel filters, filter
- *           after filter; the filters are cut into n_chunks pieces of <= 16 bins for load balance:
- *           chunk_mel[i] = filter index, chunk_start[i] = first FFT bin, chunk_len[i], chunk_off[i] = offset in mel_w
+ *   clip_offset  NULL, or [B] int64 sample offsets into `audio`: "virtual clip" b is then the n_samples samples starting
+ *           at clip_offset[b] -- the 20 s / 1 s-stride training chunks of src/preprocess.py:13-84 (chunking), computed
+ *           from the whole recording in place; every virtual clip gets its own reflect padding (np.pad at the chunk
+ *           start, preprocess.py writes the chunk as its own file) and its own top_db reference (chan_max row b)
+ *   twiddle [1200][2]  exp(-2 pi i n/1200) (re,im) (the periodic Hann window is generated in the kernel)
+ *   mel_w   [n_mel_w <= 1200] float32 non-zero weights of the 64 (contiguous, triangular) mel filters, filter
+ *           after filter; the filters are cut into n_chunks (<= 224) pieces of a few bins for load balance:
+ *           chunk_mel[i] = filter index (non-decreasing, every filter 0..63 present), chunk_start[i] = first FFT bin, chunk_len[i], chunk_off[i] = offset in mel_w
  *   scaler_mean/scaler_rstd [7][64]: (x-mean)*rstd per (feature channel, mel bin)
  *   out     layout 0: [B][7][T][64]  (reference order, datasets.py:160)
  *           layout 1: [B][T][64][8]  (channels-last, 8th channel zero) -- what the encoder consumes
@@ -47,7 +51,7 @@ const char *adyolo_last_error(void);
  * Two launches: adyolo_feat_stft_mel (writes IV final, log-mel un-clipped + chan_max) then
  * adyolo_feat_finish (top_db clip relative to chan_max + z-score of the 4 log-mel channels).
  * ---------------------------------------------------------------------------------------------- */
-int adyolo_feat_stft_mel(const float *audio, const float *twiddle, const float *window,
+int adyolo_feat_stft_mel(const float *audio, const int64_t *clip_offset, const float *twiddle,
                          const int32_t *chunk_mel, const int32_t *chunk_start, const int32_t *chunk_len,
                          const int32_t *chunk_off, const float *mel_w, int n_chunks, int n_mel_w,
                          const float *scaler_mean, const float *scaler_rstd, float *out, float *chan_max, int B,

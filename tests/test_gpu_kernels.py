@@ -460,6 +460,40 @@ def test_features_match_oracle(ops):
         assert float(out_cl8[b, :, :, 7].abs().max()) == 0.0
 
 
+def test_chunk_features_match_oracle_per_window(ops):
+    """Offline chunking on the GPU (reference src/preprocess.py:13-84: windows of chunk_window_s at chunk_stride_s, each
+    written as its own file and featurised on its own): ``chunk_offsets`` computes every window's features from the
+    recording in place.  Each window must equal (a) the same kernel run on the materialised window, bit for bit, and
+    (b) the float64 oracle applied to that window (own reflect padding at the window start, own top_db reference), 1e-3."""
+    from oracle import features as ofeat
+    from adyolo_amd.features import FeatureExtractor, load_scaler_npz
+    from adyolo_amd.datasets import synthetic_audio
+    scaler = load_scaler_npz(os.path.join(G, "scaler_DCASE2021.npz"))
+    audio = synthetic_audio(2, 24000 * 6, seed=21)                   # 2 recordings x 6 s
+    audio[0, 24000 * 2:24000 * 3] *= 30.0                            # a loud second: windows see different top_db references
+    audio[1, :, 1] *= 1e-3
+    win, stride, n = 24000 * 2, 24000, audio.shape[1]
+    offs = [rec * n + o for rec in range(2) for o in range(0, n - win + 1, stride)]       # 5 windows per recording
+    fx = FeatureExtractor(scaler, "cuda:0")
+    dev_audio = dev(audio)
+    got = fx(dev_audio, channels_last8=False, chunk_offsets=torch.tensor(offs, dtype=torch.int64, device="cuda:0"),
+             chunk_samples=win)
+    torch.cuda.synchronize()
+    assert got.shape == (len(offs), 7, win // 600, 64)
+    flat = audio.view(-1, 4)
+    for i, o in enumerate(offs):
+        chunk = flat[o:o + win].contiguous()
+        same = fx(dev(chunk[None]), channels_last8=False)[0]
+        assert torch.equal(got[i], same), "window %d differs from the kernel on the materialised window" % i
+        ref = torch.from_numpy(ofeat.get_feature(chunk.double().numpy(), scaler)[0])
+        assert_close(got[i, :4].cpu(), ref[:4], 1e-3, "log-mel of window %d" % i)
+        assert float((got[i, 4:].cpu() - ref[4:]).abs().max()) < 1e-3
+    # the windows are NOT slices of the recording's features: frame 0 is reflect-padded at the window start and the
+    # top_db clip follows the window's own maximum (DESIGN.md, chunking)
+    whole = fx(dev_audio, channels_last8=False)
+    assert not torch.equal(got[1][:, :40], whole[0][:, 40:80])
+
+
 # ------------------------------------------------------------------------------------------------ whole model
 def _params(nb_classes=12):
     return {"args": {"device": "cuda:0", "encoder": "se-resnet34", "loss": "adyolo"},

@@ -73,7 +73,7 @@ def _align_relu_masks(model, captured, g, bits=None):
             p = pos.cpu().numpy()
             np.bitwise_or.at(words, w[p], one[p])
             np.bitwise_and.at(words, w[~p], ~one[~p])
-            bits[site].copy_(torch.from_numpy(words.view(np.int64)))
+            bits[site].data.copy_(torch.from_numpy(words.view(np.int64)))      # .data: no version bump on a saved tensor
     return flips
 
 
