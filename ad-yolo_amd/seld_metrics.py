@@ -132,8 +132,25 @@ class SELDScorer:
         return er, f.mean(), le.mean(), lr.mean(), seld.mean(), classwise
 
 
+def jackknife_estimation(global_value, partial_estimates, significance_level=0.05):
+    """seld_metrics.py:149-186: bias-corrected jackknife estimate, bias, standard error and the t-test confidence interval
+    of a statistic from its leave-one-out estimates."""
+    from scipy import stats
+    partial_estimates = np.asarray(partial_estimates, dtype=float)
+    mean_jack = np.mean(partial_estimates)
+    n = len(partial_estimates)
+    bias = (n - 1) * (mean_jack - global_value)
+    std_err = np.sqrt((n - 1) * np.mean((partial_estimates - mean_jack) * (partial_estimates - mean_jack), axis=0))
+    estimate = global_value - bias
+    if not (0 < significance_level < 1):
+        raise ValueError("confidence level must be in (0, 1).")
+    t_value = stats.t.ppf(1 - significance_level / 2, n - 1)
+    return estimate, bias, std_err, estimate + t_value * np.array((-std_err, std_err))
+
+
 class ComputeSELDResults(object):
-    """``ComputeSELDResults(params, ref_files_folder).get_SELD_Results(pred_files_path)`` like the reference."""
+    """``ComputeSELDResults(params, ref_files_folder).get_SELD_Results(pred_files_path[, is_jackknife])`` like the reference
+    (seld_metrics.py:374-476)."""
 
     def __init__(self, params, ref_files_folder=None):
         dc = params["data_config"]
@@ -145,9 +162,83 @@ class ComputeSELDResults(object):
             nb = max(list(gt.keys()))
             self._ref[name] = (segment(gt, nb, self._fpb), nb)
 
-    def get_SELD_Results(self, pred_files_path):
+    def _pred_labels(self, pred_files_path, name):
+        """Segmented predictions of one file, or None when the file does not take part in this evaluation."""
+        pred = cartesian_to_polar(load_output_format_file(os.path.join(pred_files_path, name)))
+        return segment(pred, self._ref[name][1], self._fpb)
+
+    def get_SELD_Results(self, pred_files_path, is_jackknife=False):
         scorer = SELDScorer(self._nb_classes, 20.0)
+        kept = {}
         for name in os.listdir(pred_files_path):
-            pred = cartesian_to_polar(load_output_format_file(os.path.join(pred_files_path, name)))
-            scorer.update(segment(pred, self._ref[name][1], self._fpb), self._ref[name][0])
-        return scorer.scores()
+            labels = self._pred_labels(pred_files_path, name)
+            if labels is None:
+                continue
+            scorer.update(labels, self._ref[name][0])
+            kept[name] = labels
+        out = scorer.scores()
+        if not is_jackknife:
+            return out
+        return self._jackknife(out, kept)
+
+    def _jackknife(self, global_scores, kept):
+        """Leave-one-file-out confidence intervals (seld_metrics.py:441-476 / :640-676).  Reference quirk kept: the point
+        values returned next to the intervals are those of the LAST leave-one-out pass (the loop reuses the variable
+        names of the global scores), not the global scores; the intervals themselves are built around the global ones."""
+        er, f, le, lr, seld, cw = global_scores
+        global_values = [er, f, le, lr, seld] + cw.reshape(-1).tolist()
+        partial, last = [], global_scores
+        names = list(kept.keys())
+        for leave in names:
+            scorer = SELDScorer(self._nb_classes, 20.0)
+            for name in names:
+                if name != leave:
+                    scorer.update(kept[name], self._ref[name][0])
+            last = scorer.scores()
+            partial.append([last[0], last[1], last[2], last[3], last[4]] + last[5].reshape(-1).tolist())
+        partial = np.asarray(partial)
+        conf = [jackknife_estimation(global_values[i], partial[:, i], 0.05)[3] for i in range(len(global_values))]
+        return ([last[0], conf[0]], [last[1], conf[1]], [last[2], conf[2]], [last[3], conf[3]], [last[4], conf[4]],
+                [last[5], np.array(conf)[5:].reshape(5, self._nb_classes, 2)])
+
+
+class ComputeSELDResultsFromEventOverlap(ComputeSELDResults):
+    """Scores restricted to the reference frames with overlapping events (seld_metrics.py:522-717; printed by the
+    reference's test.py:125-133 as "class-independent polyphony" and, with ``classwise_overlap_test=True``, as
+    "class-homogenous polyphony"): a frame counts when it holds more than one event (or more than one event of the SAME
+    class); reference files without such a frame are left out, predictions are cut down to those frames, the recording
+    length stays ``max(frame index)`` of the full reference file."""
+
+    def __init__(self, params, ref_files_folder=None, use_polar_format=True, classwise_overlap_test=False):
+        if not use_polar_format:
+            raise NotImplementedError("cartesian reference format (seld_metrics.py:547-548) is not used by the reference's callers")
+        dc = params["data_config"]
+        self._nb_classes = dc["nb_classes"]
+        self._fpb = int(dc["sr"] / float(int(dc["sr"] * dc["label_hop_len_s"])))
+        self._ref, self._ov_frames = {}, {}
+        for name in os.listdir(ref_files_folder):
+            gt = load_output_format_file(os.path.join(ref_files_folder, name))
+            nb = max(list(gt.keys()))
+            keep = {}
+            for frame, events in gt.items():
+                if classwise_overlap_test:
+                    cnt = np.zeros(self._nb_classes)
+                    for ev in events:
+                        cnt[ev[0]] += 1
+                    hit = cnt.max() > 1
+                else:
+                    hit = len(events) > 1
+                if hit:
+                    keep[frame] = events
+            self._ov_frames[name] = list(keep.keys())
+            if keep:
+                self._ref[name] = (segment(keep, nb, self._fpb), nb)
+        self.nb_overlap_files = len(self._ref)
+        self.nb_overlap_frames = sum(len(v) for v in self._ov_frames.values())
+
+    def _pred_labels(self, pred_files_path, name):
+        if name not in self._ref:
+            return None
+        pred = cartesian_to_polar(load_output_format_file(os.path.join(pred_files_path, name)))
+        pred = {fr: pred[fr] for fr in self._ov_frames[name] if fr in pred}
+        return segment(pred, self._ref[name][1], self._fpb)

@@ -88,3 +88,16 @@ def test_epoch_audio(dataset, model, features, criterion, postprocessor, device,
                 n += 1
             write_seld_output_file(os.path.join(output_pth, names[i] + ".csv"), postprocessor.postprocess(output))
     return float(total) / max(n, 1) if total is not None else 0.0
+
+
+def score_output_folder(params, ref_dir, output_pth, is_jackknife=False):
+    """The three score sets the reference prints for one evaluated folder (src/test.py:104-133): all frames, frames with
+    overlapping events ("class-independent polyphony") and frames with overlapping events of one class
+    ("class-homogenous polyphony").  -> {'all' | 'polyphony' | 'homogenous': (ER, F, LE, LR, SELD, classwise)}."""
+    from .seld_metrics import ComputeSELDResults, ComputeSELDResultsFromEventOverlap
+    return {
+        "all": ComputeSELDResults(params, ref_dir).get_SELD_Results(output_pth, is_jackknife),
+        "polyphony": ComputeSELDResultsFromEventOverlap(params, ref_dir).get_SELD_Results(output_pth, is_jackknife),
+        "homogenous": ComputeSELDResultsFromEventOverlap(params, ref_dir, classwise_overlap_test=True)
+        .get_SELD_Results(output_pth, is_jackknife),
+    }

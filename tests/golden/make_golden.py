@@ -467,8 +467,27 @@ def gen_metrics():
             files[name] = (np.asarray(ref_rows, dtype=np.float64), np.asarray(pred_rows, dtype=np.float64))
         prm["data_config"]["sr"], prm["data_config"]["label_hop_len_s"] = 24000, 0.1
         res = ComputeSELDResults(prm, ref_dir).get_SELD_Results(pred_dir)
+        # overlap-only variants (seld_metrics.py:522-717, printed by test.py:125-133) and the jackknife intervals
+        from utils.seld_metrics import ComputeSELDResultsFromEventOverlap, jackknife_estimation
+        ov = {}
+        for tag, flag in (("poly", False), ("homog", True)):
+            obj = ComputeSELDResultsFromEventOverlap(prm, ref_dir, classwise_overlap_test=flag)
+            r = obj.get_SELD_Results(pred_dir)
+            ov["ov_%s_scores" % tag] = np.asarray([float(v) for v in r[:5]])
+            ov["ov_%s_classwise" % tag] = np.asarray(r[5], dtype=np.float64)
+            ov["ov_%s_nfiles" % tag] = np.asarray(obj._nb_ref_files)
+            ov["ov_%s_nframes" % tag] = np.asarray(sum(len(v) for v in obj._ref_ov_frame_keys.values()))
+        jk = ComputeSELDResults(prm, ref_dir).get_SELD_Results(pred_dir, is_jackknife=True)
+        ov["jk_points"] = np.asarray([float(jk[i][0]) for i in range(5)])
+        ov["jk_conf"] = np.asarray([np.asarray(jk[i][1], dtype=np.float64) for i in range(5)])
+        ov["jk_classwise"] = np.asarray(jk[5][0], dtype=np.float64)
+        ov["jk_classwise_conf"] = np.asarray(jk[5][1], dtype=np.float64)
+        ov["jk_order"] = np.asarray(os.listdir(pred_dir))
+        est = jackknife_estimation(0.37, np.asarray([0.35, 0.36, 0.41, 0.39]), 0.05)
+        ov["jk_unit"] = np.asarray([est[0], est[1], est[2], est[3][0], est[3][1]], dtype=np.float64)
     out = {"scores": np.asarray([float(v) for v in res[:5]]), "classwise": np.asarray(res[5], dtype=np.float64),
            "names": np.asarray(list(files.keys()))}
+    out.update(ov)
     for i, (name, (r, p)) in enumerate(files.items()):
         out["ref_%d" % i], out["pred_%d" % i] = r, p
     np.savez_compressed(os.path.join(HERE, "metrics.npz"), **out)

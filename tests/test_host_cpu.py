@@ -152,6 +152,28 @@ def test_seld_metrics_match_reference(tmp_path):
     res = ComputeSELDResults(prm, str(ref_dir)).get_SELD_Results(str(pred_dir))
     np.testing.assert_allclose(np.asarray([float(v) for v in res[:5]]), g["scores"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(res[5], g["classwise"], rtol=1e-9, atol=1e-9)
+    # overlap-only variants the reference prints at test time (test.py:125-133; seld_metrics.py:522-717)
+    from adyolo_amd.seld_metrics import ComputeSELDResultsFromEventOverlap, jackknife_estimation
+    for tag, flag in (("poly", False), ("homog", True)):
+        obj = ComputeSELDResultsFromEventOverlap(prm, str(ref_dir), classwise_overlap_test=flag)
+        assert obj.nb_overlap_files == int(g["ov_%s_nfiles" % tag]) and obj.nb_overlap_frames == int(g["ov_%s_nframes" % tag])
+        r = obj.get_SELD_Results(str(pred_dir))
+        np.testing.assert_allclose(np.asarray([float(v) for v in r[:5]]), g["ov_%s_scores" % tag], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(r[5], g["ov_%s_classwise" % tag], rtol=1e-9, atol=1e-9)
+    # jackknife (seld_metrics.py:149-186, :441-476): the intervals do not depend on the file order, the point values the
+    # reference returns next to them are those of its LAST leave-one-out pass (a reference quirk, kept)
+    est = jackknife_estimation(0.37, np.asarray([0.35, 0.36, 0.41, 0.39]), 0.05)
+    np.testing.assert_allclose([est[0], est[1], est[2], est[3][0], est[3][1]], g["jk_unit"], rtol=1e-12, atol=1e-12)
+    jk = ComputeSELDResults(prm, str(ref_dir)).get_SELD_Results(str(pred_dir), is_jackknife=True)
+    np.testing.assert_allclose(np.asarray([np.asarray(jk[i][1]) for i in range(5)]), g["jk_conf"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(jk[5][1], g["jk_classwise_conf"], rtol=1e-8, atol=1e-9)
+    from adyolo_amd.test import score_output_folder
+    three = score_output_folder(prm, str(ref_dir), str(pred_dir))
+    np.testing.assert_allclose([float(v) for v in three["polyphony"][:5]], g["ov_poly_scores"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose([float(v) for v in three["homogenous"][:5]], g["ov_homog_scores"], rtol=1e-9, atol=1e-9)
+    if list(os.listdir(pred_dir)) == [str(n) for n in g["jk_order"]]:
+        np.testing.assert_allclose([float(jk[i][0]) for i in range(5)], g["jk_points"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(jk[5][0], g["jk_classwise"], rtol=1e-9, atol=1e-9)
 
 
 def test_rotation_labels_match_reference():
