@@ -620,41 +620,24 @@ class AvgPool1dFn(torch.autograd.Function):
 
 
 class AttentionCoreFn(torch.autograd.Function):
-    """softmax(scale * Q K^T) [* dropout mask] V per head; q, k, v: [B][T][heads*d] (reference resnet_conformer.py:57-85).
-    The T x T score matrices are materialised (B*heads*T*T floats); all products run on the batched fp32-MFMA GEMM."""
+    """dropout(softmax(scale * Q K^T), p) V per head; q, k, v: [B][T][heads*64] (reference resnet_conformer.py:57-85).
+    Flash style on the fp32 matrix cores (csrc/attention.hip): the T x T scores never reach HBM; backward recomputes the
+    probabilities from Q, K and the per-row log-sum-exp.  ``drop`` = (p, seed32) or None."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads, scale, mask):
-        b, t, e = q.shape
-        d = e // heads
+    def forward(ctx, q, k, v, heads, scale, drop):
         q, k, v = _c(q), _c(k), _c(v)
-        s = torch.empty(b, heads, t, t, dtype=torch.float32, device=q.device)
-        ops.gemm_batched(q, k, s, t, t, d, e, e, t, False, False, b, heads, t * e, d, t * e, d, heads * t * t, t * t)
-        p = ops.softmax_fwd(s.view(-1, t), scale).view(b, heads, t, t)
-        pd = ops.mul(p, mask) if mask is not None else p
-        ctxv = torch.empty(b, t, e, dtype=torch.float32, device=q.device)
-        ops.gemm_batched(pd, v, ctxv, t, d, t, t, e, e, False, True, b, heads, heads * t * t, t * t, t * e, d, t * e, d)
-        ctx.meta = (heads, scale)
-        ctx.save_for_backward(q, k, v, p, mask if mask is not None else torch.empty(0, device=q.device))
-        return ctxv
+        p, seed = drop if drop is not None else (0.0, 0)
+        need = any(ctx.needs_input_grad[:3])
+        out, lse = ops.attn_fwd(q, k, v, heads, scale, p, seed, want_lse=need)
+        ctx.meta = (heads, scale, p, seed)
+        if need:
+            ctx.save_for_backward(q, k, v, out, lse)
+        return out
 
     @staticmethod
     def backward(ctx, dctx):
-        q, k, v, p, mask = ctx.saved_tensors
-        heads, scale = ctx.meta
-        b, t, e = q.shape
-        d = e // heads
-        dctx = _c(dctx)
-        has_mask = mask.numel() > 0
-        pd = ops.mul(p, mask) if has_mask else p
-        dpd = torch.empty_like(p)
-        ops.gemm_batched(dctx, v, dpd, t, t, d, e, e, t, False, False, b, heads, t * e, d, t * e, d, heads * t * t, t * t)
-        dv = torch.empty_like(v)
-        ops.gemm_batched(pd, dctx, dv, t, d, t, t, e, e, True, True, b, heads, heads * t * t, t * t, t * e, d, t * e, d)
-        dp = ops.mul(dpd, mask) if has_mask else dpd
-        ds = ops.softmax_bwd(dp.view(-1, t), p.view(-1, t), scale).view(b, heads, t, t)
-        dq = torch.empty_like(q)
-        ops.gemm_batched(ds, k, dq, t, d, t, t, e, e, False, True, b, heads, heads * t * t, t * t, t * e, d, t * e, d)
-        dk = torch.empty_like(k)
-        ops.gemm_batched(ds, q, dk, t, d, t, t, e, e, True, True, b, heads, heads * t * t, t * t, t * e, d, t * e, d)
+        q, k, v, out, lse = ctx.saved_tensors
+        heads, scale, p, seed = ctx.meta
+        dq, dk, dv = ops.attn_bwd(q, k, v, out, _c(dctx), lse, heads, scale, p, seed)
         return dq, dk, dv, None, None, None

@@ -9,7 +9,8 @@ and the same 549 ``state_dict`` keys.  Quirks kept: ReLU *before* BatchNorm afte
 blocks (:373-384), ``PoolingModule.max_pool`` is an average pool (:289) so pooling is 2 x avg, attention ``mask`` path dead.
 
 This is the correctness-first version of the row: strided convolutions run as im2col + the fp32-MFMA GEMM, stride-1 3x3
-convolutions on the implicit-GEMM kernel, attention as batched GEMM + softmax kernels with materialised scores.
+convolutions on the implicit-GEMM / Winograd kernels; attention is the flash-style fp32-MFMA kernel of csrc/attention.hip
+(scores never written to HBM).
 """
 import math
 
@@ -117,11 +118,11 @@ class MultiHeadAttention(nn.Module):
         q = Fn.LinearFn.apply(x, self.query.weight, self.query.bias)
         k = Fn.LinearFn.apply(x, self.key.weight, self.key.bias)
         v = Fn.LinearFn.apply(x, self.value.weight, self.value.bias)
-        mask = None
+        drop = None
         if self.training and self.p > 0.0:
             b, t, _ = x.shape
-            mask = rng.mask(torch.empty(b, self.num_heads, t, t, dtype=torch.float32, device=x.device), self.p)
-        ctx = Fn.AttentionCoreFn.apply(q, k, v, self.num_heads, self.scaling, mask)
+            drop = (self.p, rng.seed32(b * self.num_heads * t * t))       # stateless in-kernel mask: no (B, H, T, T) tensor
+        ctx = Fn.AttentionCoreFn.apply(q, k, v, self.num_heads, self.scaling, drop)
         return Fn.LinearFn.apply(ctx, self.linear.weight, self.linear.bias)
 
 

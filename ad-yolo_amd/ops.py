@@ -680,6 +680,35 @@ def gemm_batched(a, b, c, m, n, k, lda, ldb, ldc, trans_a, trans_b, outer, inner
     return c
 
 
+# ---------------------------------------------------------------------------------------------- attention (flash style)
+def attn_fwd(q, k, v, heads, scale, dropout_p=0.0, seed=0, want_lse=True):
+    """q, k, v [B][T][heads*64] -> ctx [B][T][heads*64], lse2 [B][heads][T] (or None); scores never reach HBM."""
+    _chk(q, k, v)
+    b, t, e = q.shape
+    ctxv = torch.empty_like(q)
+    lse = _new(q, b, heads, t) if want_lse else None
+    _c("adyolo_attn_fwd", _p(q), _p(k), _p(v), _p(ctxv), _p(lse), b, t, heads, e // heads, float(scale), float(dropout_p),
+       ctypes.c_uint32(seed & 0xFFFFFFFF), _stream())
+    return ctxv, lse
+
+
+def attn_bwd(q, k, v, ctxv, dctx, lse, heads, scale, dropout_p=0.0, seed=0):
+    _chk(q, k, v, ctxv, dctx, lse)
+    b, t, e = q.shape
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = _new(q, b, heads, t)
+    _c("adyolo_attn_bwd", _p(q), _p(k), _p(v), _p(ctxv), _p(dctx), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), b, t, heads,
+       e // heads, float(scale), float(dropout_p), ctypes.c_uint32(seed & 0xFFFFFFFF), _stream())
+    return dq, dk, dv
+
+
+def attn_dropout_mask(like, b, t, heads, dropout_p, seed):
+    """The (B, heads, T, T) mask (0 or 1/(1-p)) that attn_fwd / attn_bwd apply for (dropout_p, seed) -- tests only."""
+    mask = torch.empty((b, heads, t, t), dtype=torch.float32, device=like.device)
+    _c("adyolo_attn_dropout_mask", _p(mask), b, t, heads, float(dropout_p), ctypes.c_uint32(seed & 0xFFFFFFFF), _stream())
+    return mask
+
+
 # ---------------------------------------------------------------------------------------------- input pipeline (8f rows 2-3)
 def pcm16_to_f32(pcm, out=None):
     """int16 samples (any shape, contiguous, on the GPU) -> float32 ``x / 32768 + 1e-8`` (datasets.py:105)."""

@@ -32,6 +32,14 @@ class DropoutStream:
         self.offset += like.numel()
         return m
 
+    def seed32(self, n):
+        """A 32-bit seed for a kernel that draws ``n`` values from its own stateless hash; advances the stream by n."""
+        x = (self.seed ^ ((self.offset * 0x9E3779B97F4A7C15) & _MASK64)) & _MASK64
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _MASK64
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _MASK64
+        self.offset += int(n)
+        return int((x ^ (x >> 31)) & 0xFFFFFFFF)
+
     def state(self):
         return {"seed": self.seed, "offset": self.offset}
 

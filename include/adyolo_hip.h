@@ -354,6 +354,24 @@ int adyolo_adam_step(float *param, const float *grad, float *exp_avg, float *exp
                      float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                      float grad_scale, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * K9a multi-head self-attention core, flash style on the exact-fp32 matrix cores (csrc/attention.hip).
+ *     replaces the energy / softmax / dropout / context products of MultiHeadAttention.forward
+ *     (src/models/backbones/resnet_conformer.py:57-85); the (B, H, T, T) scores are never written to HBM.
+ *   q, k, v, ctx, dq, dk, dv, dctx: [B][T][H*D] float32, head h in columns h*D .. h*D+D-1;  D must be 64
+ *   ctx = dropout(softmax(scale * q k^T), p) v    per (batch, head);  dropout_p = 0: none (eval)
+ *   lse2 [B][H][T]: per query row log2(sum_k exp(scale * q k)) (written by fwd when non-NULL, read by bwd)
+ *   delta [B][H][T]: workspace of bwd (sum_dv dctx * ctx)
+ *   seed: 32-bit seed of the stateless dropout hash keep(b, h, query, key); forward and backward of one call must use
+ *         the same (dropout_p, seed).  adyolo_attn_dropout_mask writes that mask ([B][H][T][T], values 0 or 1/(1-p)).
+ * ---------------------------------------------------------------------------------------------- */
+int adyolo_attn_fwd(const float *q, const float *k, const float *v, float *ctx, float *lse2, int B, int T, int H, int D,
+                    float scale, float dropout_p, uint32_t seed, void *stream);
+int adyolo_attn_bwd(const float *q, const float *k, const float *v, const float *ctx, const float *dctx,
+                    const float *lse2, float *delta, float *dq, float *dk, float *dv, int B, int T, int H, int D,
+                    float scale, float dropout_p, uint32_t seed, void *stream);
+int adyolo_attn_dropout_mask(float *mask, int B, int T, int H, float dropout_p, uint32_t seed, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -718,6 +718,40 @@ def test_postprocess_matches_reference_golden(ops, nms, tmp_path):
     assert len(open(f).read().strip().splitlines()) == len(rows)
 
 
+@pytest.mark.parametrize("b,t,p", [(2, 36, 0.0), (1, 50, 0.0), (3, 131, 0.2), (2, 800, 0.2), (1, 2400, 0.0)])
+def test_flash_attention_matches_torch(ops, b, t, p):
+    """Flash-style attention core (csrc/attention.hip) against the materialised PyTorch-CPU form of
+    MultiHeadAttention.forward (resnet_conformer.py:57-85: softmax(q k^T d^-1/2) -> dropout -> @ v), forward 2e-5 and
+    dq / dk / dv 5e-5 of absmax: ragged lengths (T not a multiple of the 32-key block or the 128-query tile), the
+    training length 800 with dropout (the in-kernel mask is materialised by adyolo_attn_dropout_mask for the reference)
+    and the evaluation length 2400."""
+    from adyolo_amd import functional as Fn
+    heads, d = 4, 64
+    g = torch.Generator().manual_seed(b * 1000 + t)
+    q, k, v = (torch.randn(b, t, heads * d, generator=g) for _ in range(3))
+    probe = torch.randn(b, t, heads * d, generator=g)
+    seed = 0xC0FFEE + t
+    mask = None
+    if p > 0:
+        mask = ops.attn_dropout_mask(dev(q), b, t, heads, p, seed).cpu()
+        keep = float((mask > 0).float().mean())
+        assert abs(keep - (1 - p)) < 0.01 and set(torch.unique(mask).tolist()) <= {0.0, float(np.float32(1.0 / (1.0 - p)))}
+    qo, ko, vo = (z.clone().requires_grad_(True) for z in (q, k, v))
+    qh, kh, vh = (z.view(b, t, heads, d).transpose(1, 2) for z in (qo, ko, vo))
+    w = torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, -1)
+    if mask is not None:
+        w = w * mask
+    ctx_o = (w @ vh).transpose(1, 2).reshape(b, t, heads * d)
+    (ctx_o * probe).sum().backward()
+    qg, kg, vg = (dev(z).requires_grad_(True) for z in (q, k, v))
+    ctx_g = Fn.AttentionCoreFn.apply(qg, kg, vg, heads, d ** -0.5, (p, seed) if p > 0 else None)
+    (ctx_g * dev(probe)).sum().backward()
+    torch.cuda.synchronize()
+    assert_close(ctx_g, ctx_o, 2e-5, "attention fwd (T=%d)" % t)
+    for name, a_, b_ in (("dq", qg, qo), ("dk", kg, ko), ("dv", vg, vo)):
+        assert_close(a_.grad, b_.grad, 5e-5, "attention %s (T=%d)" % (name, t))
+
+
 def test_train_one_epoch_and_test_epoch_entry_points(ops, tmp_path):
     """train_one_epoch / test_epoch mirrors on a tiny in-memory loader; CSVs are scored by the SELD evaluator."""
     from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
