@@ -61,8 +61,21 @@ __device__ __forceinline__ double block_colsum32(const float *__restrict__ parti
     const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
     const int c = c0 + cx;
     double s = 0.0;
-    if (c < C)
-        for (int p = py; p < nparts; p += 8) s += (double)partial[(size_t)p * ld + c];
+    if (c < C) {
+        // four independent chains: the loads of a step are in flight together (a single chain is one L2 latency per row)
+        double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int p = py;
+        for (; p + 24 < nparts; p += 32) {
+            const float a0 = partial[(size_t)p * ld + c], a1 = partial[(size_t)(p + 8) * ld + c];
+            const float a2 = partial[(size_t)(p + 16) * ld + c], a3 = partial[(size_t)(p + 24) * ld + c];
+            s += (double)a0;
+            s1 += (double)a1;
+            s2 += (double)a2;
+            s3 += (double)a3;
+        }
+        for (; p < nparts; p += 8) s += (double)partial[(size_t)p * ld + c];
+        s = (s + s1) + (s2 + s3);
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     if (py == 0) {

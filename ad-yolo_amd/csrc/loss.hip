@@ -159,8 +159,18 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const float *__restrict_
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = 0.f;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long anchor = e / CH;
-        const int ch = (int)(e - anchor * CH);
+        // 32-bit index arithmetic when it fits (always, at the shapes of this path): a 64-bit division per logit costs
+        // more than the rest of the loop body
+        long anchor;
+        int ch;
+        if (total <= 0xFFFFFFFFL) {
+            const unsigned eu = (unsigned)e, au = eu / (unsigned)CH;
+            anchor = (long)au;
+            ch = (int)(eu - au * (unsigned)CH);
+        } else {
+            anchor = e / CH;
+            ch = (int)(e - anchor * CH);
+        }
         const float xl = logit[e];
         float grad = 0.f;
         if (ch <= g.C) {

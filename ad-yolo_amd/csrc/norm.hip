@@ -303,7 +303,9 @@ __global__ __launch_bounds__(256) void se_tail_fwd_kernel(
 }
 
 // One workgroup per sample: dpool[n][:] and this sample's contribution to every parameter gradient / batch sum,
-// written to part[n][P] with P = 2*C*Cr + Cr + 3*C laid out [dw1 Cr*C | db1 Cr | dw2 C*Cr | db2 C | sdd C | sddx C];
+// written to part[n][P] with P = 2*C*Cr + Cr + 3*C laid out [db2 C | dw2 C*Cr | db1 Cr | dw1 Cr*C | sdd C | sddx C] -- the
+// order in which these six gradients (se.fc.2.bias, se.fc.2.weight, se.fc.0.bias, se.fc.0.weight, bn2.bias, bn2.weight) lie in
+// the flat gradient buffer of dist.FlatParameters (reverse registration order), so `packed` can BE that slice of it;
 // a deterministic column sum over the N rows finishes the job.
 __global__ __launch_bounds__(256) void se_fc_bwd_sample_kernel(
     const float *__restrict__ sg, const float *__restrict__ sgx, const float *__restrict__ ssum,
@@ -317,11 +319,11 @@ __global__ __launch_bounds__(256) void se_fc_bwd_sample_kernel(
     __shared__ float dz1[128];
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t P = (size_t)2 * C * Cr + Cr + 3 * (size_t)C;
-    float *p_dw1 = part + (size_t)n * P;
-    float *p_db1 = p_dw1 + (size_t)Cr * C;
-    float *p_dw2 = p_db1 + Cr;
-    float *p_db2 = p_dw2 + (size_t)C * Cr;
-    float *p_sdd = p_db2 + C;
+    float *p_db2 = part + (size_t)n * P;
+    float *p_dw2 = p_db2 + C;
+    float *p_db1 = p_dw2 + (size_t)C * Cr;
+    float *p_dw1 = p_db1 + Cr;
+    float *p_sdd = p_dw1 + (size_t)Cr * C;
     float *p_sddx = p_sdd + C;
     const float invHW = 1.0f / (float)HW;
     for (int c = tid; c < C; c += 256) {

@@ -131,6 +131,15 @@ class BucketedAllReduce:
                 self._launch(b)
         return hook
 
+    def notify(self, idx):
+        """Gradient ``idx`` (position in flat.params) is complete although autograd never saw it (functional.GradSink)."""
+        if self.active:
+            b = self._bucket_of[idx]
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self.fired_from_hooks += 1
+                self._launch(b)
+
     def _launch(self, b):
         s, e, _ = self.buckets[b]
         view = self.flat.flat_grad[s:e]

@@ -42,6 +42,67 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+class GradSink:
+    """While a ``TrainStep`` runs backward, the big gradient producers write STRAIGHT into the parameter's slice of the flat
+    gradient buffer (``dist.FlatParameters``) and return None to autograd for that input: no ``grad += new`` launch per
+    parameter (~170 per step), and a data-parallel bucket is complete exactly when its last producer has run
+    (``done`` calls the reducer's hook by hand, since autograd's post-accumulate hook does not fire for a None gradient).
+    Inactive (views is None) everywhere else: plain autograd semantics, e.g. for ``torch.optim.Adam`` loops and tests."""
+
+    def __init__(self):
+        self.views = None          # {param data_ptr: (index in flat.params, grad view)}
+        self.notify = None         # index -> None, or None when there is no active reducer
+        self.step = 4              # element size
+
+    def begin(self, flat, reducer=None):
+        self.views = {p.data_ptr(): (i, p.grad) for i, p in enumerate(flat.params)}
+        self.notify = reducer.notify if (reducer is not None and reducer.active) else None
+
+    def end(self):
+        self.views = self.notify = None
+
+    def view(self, ptr, shape=None):
+        """Gradient slice of the parameter whose storage starts at ``ptr`` (or None when inactive / unknown)."""
+        if self.views is None:
+            return None
+        ent = self.views.get(ptr)
+        return None if ent is None else (ent[1] if shape is None else ent[1].view(shape))
+
+    def span(self, ptrs):
+        """ONE contiguous gradient view covering the parameters ``ptrs`` if they lie back to back, in this order, in the
+        flat buffer; else None."""
+        if self.views is None:
+            return None
+        ents = [self.views.get(q) for q in ptrs]
+        if any(e is None for e in ents):
+            return None
+        base = ents[0][1]
+        off = base.data_ptr()
+        for _, g in ents:
+            if g.data_ptr() != off:
+                return None
+            off += g.numel() * 4
+        n = (off - base.data_ptr()) // 4
+        return torch.as_strided(base, (n,), (1,))
+
+    def done(self, *ptrs):
+        if self.notify is not None:
+            for q in ptrs:
+                self.notify(self.views[q][0])
+
+
+SINK = GradSink()
+_PENDING_COUNTERS = []
+
+
+def flush_bn_counters():
+    """``num_batches_tracked += 1`` of every BatchNorm that took a training-mode step since the last flush, as ONE
+    multi-tensor launch (36 single-element launches per step otherwise).  The encoders call it at the end of forward."""
+    if _PENDING_COUNTERS:
+        torch._foreach_add_(_PENDING_COUNTERS, 1)
+        _PENDING_COUNTERS.clear()
+
+
 class _BNState:
     """Batch-norm running buffers of one layer (updated in place by the stats kernel)."""
 
@@ -52,7 +113,7 @@ class _BNState:
         m = self.mod
         if training:
             ssum, mean, invstd = ops.bn_stats(x, m.running_mean, m.running_var, m.momentum, m.eps)
-            m.num_batches_tracked += 1
+            _PENDING_COUNTERS.append(m.num_batches_tracked)
         else:
             ssum = None
             mean, invstd = ops.bn_eval_stats(m.running_mean, m.running_var, m.eps)
@@ -67,7 +128,7 @@ class _BNState:
         g, b = affine if affine is not None else (None, None)
         if update:
             out = ops.bn_stats_tiles(tile_stats, n, hw, m.running_mean, m.running_var, m.momentum, m.eps, g, b)
-            m.num_batches_tracked += 1
+            _PENDING_COUNTERS.append(m.num_batches_tracked)
             return out
         return ops.bn_stats_tiles(tile_stats, n, hw, None, None, m.momentum, m.eps, g, b)
 
@@ -88,6 +149,8 @@ class StemFn(torch.autograd.Function):
         out = ops.affine(a, scale, shift)
         ctx.training = training
         ctx.cin_real = w.shape[1]
+        ctx.ptrs = (w.data_ptr(), gamma.data_ptr(), beta.data_ptr())
+        ctx.wshape = tuple(w.shape)
         ctx.save_for_backward(x8, a, gamma, mean, invstd)
         return out
 
@@ -96,9 +159,14 @@ class StemFn(torch.autograd.Function):
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
         x8, a, gamma, mean, invstd = ctx.saved_tensors
-        da, dgamma, dbeta = ops.bn_bwd(_c(dout), a, gamma, mean, invstd, relu_mask=True)
-        dw = ops.conv3x3_wgrad(x8, da, ctx.cin_real)
+        pw, pg, pb = ctx.ptrs
+        vg, vb, vw = SINK.view(pg), SINK.view(pb), SINK.view(pw, ctx.wshape)
+        da, dgamma, dbeta = ops.bn_bwd(_c(dout), a, gamma, mean, invstd, relu_mask=True, out_dgamma=vg, out_dbeta=vb)
+        dw = ops.conv3x3_wgrad(x8, da, ctx.cin_real, out=vw)
         db = ops.colsum(da.view(-1, da.shape[-1]))
+        if vw is not None:
+            SINK.done(pw, pg, pb)
+            return None, None, db, None, None, None, None
         return None, dw, db, dgamma, dbeta, None, None
 
 
@@ -173,6 +241,10 @@ class SEBlockFn(torch.autograd.Function):
         ctx.fused_affine = aff is not None
         ctx.a_unfused = None if aff is not None else a      # (A/B switch only; keeps `a` alive for BN1's backward)
         ctx.has_bits = ebits is not None
+        # storage addresses of the parameters whose gradients can be written straight into the flat buffer (GradSink)
+        ctx.ptrs = (w1.data_ptr(), g1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                    (fb2.data_ptr(), fw2.data_ptr(), fb1.data_ptr(), fw1.data_ptr(), b2.data_ptr(), g2.data_ptr()))
+        ctx.wshapes = (tuple(w1.shape), tuple(w2.shape))
         tensors = [p, src, scale1, cc, e, g1, mean1, invstd1, g2, b2, mean2, invstd2, ssum2, pooled, hid, s, fw1, fw2,
                    wpk1d, wpk2d, shift1]
         if ebits is not None:
@@ -199,23 +271,35 @@ class SEBlockFn(torch.autograd.Function):
         ebits = None
         if ctx.has_bits:
             ebits, nb = t[21], 22
+        pw1, pg1, pb1, pw2, pse = ctx.ptrs
+        vse = SINK.span(pse)                  # [fc.2.bias | fc.2.weight | fc.0.bias | fc.0.weight | bn2.bias | bn2.weight] or None
+        vw1, vw2 = SINK.view(pw1, ctx.wshapes[0]), SINK.view(pw2, ctx.wshapes[1])
+        vg1, vb1 = SINK.view(pg1), SINK.view(pb1)
+        sunk = vse is not None and vw1 is not None and vw2 is not None and vg1 is not None and vb1 is not None
+        if not sunk:
+            vse = vw1 = vw2 = vg1 = vb1 = None
         dc, dr, dg2, db2, dfw1, dfb1, dfw2, dfb2 = ops.se_tail_bwd(de, e, cc, g2, b2, mean2, invstd2, ssum2, pooled,
                                                                    hid, s, fw1, fw2,
                                                                    want_dr=ctx.has_down or not FUSE_DR, tile_stats=tiles,
-                                                                   mask=ebits)
+                                                                   mask=ebits, packed_out=vse)
         if ctx.fused_affine:
             a = src
-            dw2 = ops.conv3x3_wgrad(a, dc, c, in_affine=(scale1, shift1))
+            dw2 = ops.conv3x3_wgrad(a, dc, c, in_affine=(scale1, shift1), out=vw2)
         else:
-            dw2 = ops.conv3x3_wgrad(src, dc, c)
+            dw2 = ops.conv3x3_wgrad(src, dc, c, out=vw2)
             a = ctx.a_unfused
         if FUSE_BNBWD:
             dbb, st = ops.conv3x3(dc, wpk2d, c, want_stats=True, stat_bn=(a, mean1, invstd1))
-            da, dg1, db1 = ops.bn_bwd(dbb, a, g1, mean1, invstd1, relu_mask=True, tile_stats=st)
+            da, dg1, db1 = ops.bn_bwd(dbb, a, g1, mean1, invstd1, relu_mask=True, tile_stats=st, out_dgamma=vg1,
+                                      out_dbeta=vb1)
         else:
             dbb = ops.conv3x3(dc, wpk2d, c)
-            da, dg1, db1 = ops.bn_bwd(dbb, a, g1, mean1, invstd1, relu_mask=True)
-        dw1 = ops.conv3x3_wgrad(p, da, cin)
+            da, dg1, db1 = ops.bn_bwd(dbb, a, g1, mean1, invstd1, relu_mask=True, out_dgamma=vg1, out_dbeta=vb1)
+        dw1 = ops.conv3x3_wgrad(p, da, cin, out=vw1)
+        if sunk:
+            SINK.done(*pse)
+            SINK.done(pw2, pg1, pb1, pw1)
+            dw1 = dg1 = db1 = dw2 = dg2 = db2 = dfw1 = dfb1 = dfw2 = dfb2 = None
         dwd = dgd = dbd = None
         if ctx.has_down:
             q, wd, gd, meand, invstdd = t[nb:nb + 5]

@@ -185,4 +185,5 @@ class SEResnet34(nn.Module):
         y = Fn.BiGRULayerFn.apply(y, *self.lstm.layer_params(0), save)
         y = self._dropout(y)
         y = Fn.BiGRULayerFn.apply(y, *self.lstm.layer_params(1), save)
+        Fn.flush_bn_counters()
         return Fn.LNTanhFn.apply(y, self.norm.weight, self.norm.bias, self.norm.eps)

@@ -252,4 +252,5 @@ class ResnetConformer(nn.Module):
         y = y.view(b, t, c)
         y = Fn.LinearFn.apply(y, self.bottleneck.weight, None)
         y = self.conformer(y, self._rng)
+        Fn.flush_bn_counters()
         return self.t_pooling(y)

@@ -98,7 +98,7 @@ def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, 
     return (y, stats) if want_stats else y
 
 
-def conv3x3_wgrad(x, dy, cin_real, in_affine=None, algo=None):
+def conv3x3_wgrad(x, dy, cin_real, in_affine=None, algo=None, out=None):
     """x [N][H][W][Cin], dy [N][H][W][Cout] -> dw [Cout][cin_real][3][3] (x optionally seen through an affine).
 
     Winograd form (default) when both channel counts are multiples of 32, else the direct implicit GEMM."""
@@ -106,7 +106,7 @@ def conv3x3_wgrad(x, dy, cin_real, in_affine=None, algo=None):
     n, h, w, cin = x.shape
     cout = dy.shape[3]
     sc, sh = in_affine if in_affine is not None else (None, None)
-    dw = _new(x, cout, cin_real, 3, 3)
+    dw = out if out is not None else _new(x, cout, cin_real, 3, 3)      # out: e.g. the parameter's slice of the flat gradient buffer
     algo = algo or os.environ.get("ADYOLO_WGRAD_ALGO") or conv_algo()
     if algo == "winograd" and cin % 32 == 0 and cout % 32 == 0:
         nslab = _lib.load().adyolo_wino_wgrad_slabs(n, h, w, cin, cout)
@@ -254,13 +254,14 @@ def affine(x, scale, shift):
     return y
 
 
-def bn_bwd(dy, x, gamma, mean, invstd, relu_mask=False, tile_stats=None):
+def bn_bwd(dy, x, gamma, mean, invstd, relu_mask=False, tile_stats=None, out_dgamma=None, out_dbeta=None):
     """-> dx, dgamma, dbeta.  relu_mask: additionally multiply dx by (x > 0) (x is a ReLU output).
     tile_stats: per-patch (sum dy, sum dy*xhat) written by the convolution that produced dy (skips the reduce pass)."""
     _chk(dy, x, gamma, mean, invstd)
     c = x.shape[-1]
     rows = x.numel() // c
-    sdy, sdyx = _new(x, c), _new(x, c)
+    sdy = out_dbeta if out_dbeta is not None else _new(x, c)          # = dbeta
+    sdyx = out_dgamma if out_dgamma is not None else _new(x, c)       # = dgamma
     if tile_stats is not None:
         _c("adyolo_bn_bwd_tiles", _p(tile_stats), _p(sdy), _p(sdyx), _p(_new(tile_stats, 2, 256, c)), tile_stats.shape[1], c,
            _stream())
@@ -301,7 +302,7 @@ def se_tail_fwd(c_t, r_t, scale, shift, s, want_mask=False):
 
 
 def se_tail_bwd(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1, w2, want_dr=True, tile_stats=None,
-                mask=None):
+                mask=None, packed_out=None):
     """Backward of  e = relu(bn2(c) * s + r)  incl. the SE FCs.
     -> dc, dr, dgamma, dbeta, dw1, db1, dw2, db2
     tile_stats: per-patch sums [2][tiles][C] of de * (e > 0) and de * (e > 0) * xhat(c) from the convolution epilogue
@@ -319,15 +320,16 @@ def se_tail_bwd(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1,
         _c("adyolo_se_tail_bwd_reduce", _p(de), _p(e), _p(mask), _p(c_t), _p(mean), _p(invstd), _p(sg), _p(sgx), _p(partial),
            n, hw, ch, _stream())
     pw = 2 * ch * cr + cr + 3 * ch
-    part, packed, cws = _new(c_t, n, pw), _new(c_t, pw), _new(c_t, 1024, pw)
+    part, cws = _new(c_t, n, pw), _new(c_t, 1024, pw)
+    packed = packed_out if packed_out is not None else _new(c_t, pw)    # packed_out: the six gradients' slice of the flat buffer
     dpool = _new(c_t, n, ch)
     _c("adyolo_se_fc_bwd", _p(sg), _p(sgx), _p(ssum), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(pooled), _p(hid),
        _p(s), _p(w1), _p(w2), _p(dpool), _p(part), _p(packed), _p(cws), n, hw, ch, cr, _stream())
     o = 0
-    dw1 = packed[o:o + cr * ch].view(cr, ch); o += cr * ch
-    db1 = packed[o:o + cr]; o += cr
-    dw2 = packed[o:o + ch * cr].view(ch, cr); o += ch * cr
     db2 = packed[o:o + ch]; o += ch
+    dw2 = packed[o:o + ch * cr].view(ch, cr); o += ch * cr
+    db1 = packed[o:o + cr]; o += cr
+    dw1 = packed[o:o + cr * ch].view(cr, ch); o += cr * ch
     sdd = packed[o:o + ch]; o += ch
     sddx = packed[o:o + ch]
     dgamma, dbeta = sddx, sdd

@@ -7,6 +7,7 @@ format (train.py:149,236 save/restore it) while running one HIP launch over the 
 """
 import torch
 
+from . import functional as Fn
 from . import ops
 from .dist import BucketedAllReduce, FlatParameters
 
@@ -69,7 +70,11 @@ class TrainStep:
         output = self.model(feat, channels_last8=True)
         self.optimizer.zero_grad()
         loss = self.criterion(output, target)
-        loss.backward()
+        Fn.SINK.begin(self.flat, self.reducer)       # weight / BatchNorm / SE gradients go straight into the flat buffer
+        try:
+            loss.backward()
+        finally:
+            Fn.SINK.end()
         scale = self.reducer.finish()
         self.optimizer.step(grad_scale=scale)
         return loss.detach()

@@ -179,7 +179,7 @@ int adyolo_bn_bwd_apply(const float *dy, const float *x, const float *gamma, con
  *                     s = sigmoid(W2 hid + b2) [N][C]
  *   adyolo_se_tail_fwd: e = relu((c*scale+shift)*s[n][c] + r)
  *   adyolo_se_tail_bwd_reduce: g = de*(e>0);  sg[n][c] = sum_hw g;  sgx[n][c] = sum_hw g*xhat
- *   adyolo_se_fc_bwd: from sg, sgx: dpool[n][c] and, packed as [dW1 Cr*C | db1 Cr | dW2 C*Cr | db2 C | sdd C | sddx C]
+ *   adyolo_se_fc_bwd: from sg, sgx: dpool[n][c] and, packed as [db2 C | dW2 C*Cr | db1 Cr | dW1 Cr*C | sdd C | sddx C]
  *                     (P words, one workgroup per sample + a deterministic column sum over the batch), the FC
  *                     gradients and the batch sums bn2's backward needs: sdd[c] = sum dd (= dbeta2),
  *                     sddx[c] = sum dd*xhat (= dgamma2)

@@ -459,3 +459,38 @@ def test_bucketed_allreduce_hooks_on_the_real_model(ops):
     assert hooked["dist"] and hooked["active"] and not plain["active"]
     assert hooked["buckets"] == 4 and all(f == [4, 0] for f in hooked["fired"]), hooked["fired"]
     assert hooked["losses"] == plain["losses"] and hooked["digest"] == plain["digest"]
+
+
+def test_grad_sink_equals_autograd_accumulation(ops):
+    """TrainStep lets the convolution / BatchNorm / SE gradient kernels write straight into the flat gradient buffer
+    (functional.GradSink) instead of returning tensors that autograd adds into it: both routes must give the same bits, and
+    every parameter must have received its gradient exactly once."""
+    import bench
+    from adyolo_amd import functional as Fn
+    from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
+    from adyolo_amd.dist import FlatParameters
+    from adyolo_amd.datasets import synthetic_targets
+    torch.manual_seed(100)
+    prm = bench.params("cuda:0")
+    model = WrapperModel((1, 7, 160, 64), (), prm).to("cuda:0")
+    model.train()
+    model.encoder.lstm.dropout = 0.0
+    flat = FlatParameters(model)
+    crit = WrapperCriterion(prm)
+    x = torch.randn(3, 7, 160, 64, generator=torch.Generator().manual_seed(4)).to("cuda:0")
+    target = synthetic_targets(3, 40, 12, seed=4)
+    grads = []
+    for use_sink in (False, True):
+        flat.zero_grad()
+        loss = crit(model(x), target)
+        if use_sink:
+            Fn.SINK.begin(flat)
+        try:
+            loss.backward()
+        finally:
+            Fn.SINK.end()
+        torch.cuda.synchronize()
+        grads.append(flat.flat_grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    for p, (off, n) in zip(flat.params, flat.offsets):
+        assert float(grads[1][off:off + n].abs().sum()) > 0 or p.numel() == 0
