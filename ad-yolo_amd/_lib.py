@@ -112,6 +112,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch ships its own libamdhip64; it must be the HIP runtime already mapped when this library (linked against the
+    # same SONAME) is loaded, otherwise the process ends up with two runtimes and this one sees no device
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise AdyoloHipError(
             "libadyolo_hip.so is not built (%s). Run `python -c \"import __graft_entry__ as g; g.build()\"` "
