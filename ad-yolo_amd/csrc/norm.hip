@@ -275,15 +275,19 @@ __global__ __launch_bounds__(256) void se_fc_fwd_kernel(
 
 __global__ __launch_bounds__(256) void se_tail_fwd_kernel(
     const float *__restrict__ c, const float *__restrict__ r, const float *__restrict__ scale,
-    const float *__restrict__ shift, const float *__restrict__ s, float *__restrict__ e,
-    unsigned long long *__restrict__ mask, long hw4, int c4n) {
+    const float *__restrict__ shift, const float *__restrict__ s, const float *__restrict__ r_scale,
+    const float *__restrict__ r_shift, float *__restrict__ e, unsigned long long *__restrict__ mask, long hw4, int c4n) {
     // grid (blocks, N): hw4 = HW * C/4 float4 per sample; mask (optional, needs hw4 % 64 == 0): bits of (e > 0)
     const int n = blockIdx.y;
     const size_t base = (size_t)n * hw4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw4; i += (long)gridDim.x * blockDim.x) {
         const int cx = (int)(i % c4n);
         const float4 cv = reinterpret_cast<const float4 *>(c)[base + i];
-        const float4 rv = reinterpret_cast<const float4 *>(r)[base + i];
+        float4 rv = reinterpret_cast<const float4 *>(r)[base + i];
+        if (r_scale) {           // the shortcut's own BatchNorm affine (downsample branch) applied on the fly
+            const float4 rs = reinterpret_cast<const float4 *>(r_scale)[cx], rt = reinterpret_cast<const float4 *>(r_shift)[cx];
+            rv = make_float4(fmaf(rv.x, rs.x, rt.x), fmaf(rv.y, rs.y, rt.y), fmaf(rv.z, rs.z, rt.z), fmaf(rv.w, rs.w, rt.w));
+        }
         const float4 sc = reinterpret_cast<const float4 *>(scale)[cx];
         const float4 sh = reinterpret_cast<const float4 *>(shift)[cx];
         const float4 sv = reinterpret_cast<const float4 *>(s)[(size_t)n * c4n + cx];
@@ -594,15 +598,16 @@ extern "C" long adyolo_relu_mask_words(int N, int HW, int C) {
 }
 
 extern "C" int adyolo_se_tail_fwd(const float *c, const float *r, const float *scale, const float *shift,
-                                  const float *s, float *e, uint64_t *mask, int N, int HW, int C, void *stream) {
-    ADYOLO_REQUIRE(c && r && scale && shift && s && e && N > 0 && HW > 0 && C % 4 == 0, ADYOLO_EINVAL,
-                   "se_tail_fwd: bad arguments");
+                                  const float *s, const float *r_scale, const float *r_shift, float *e, uint64_t *mask,
+                                  int N, int HW, int C, void *stream) {
+    ADYOLO_REQUIRE(c && r && scale && shift && s && e && N > 0 && HW > 0 && C % 4 == 0 && (!r_scale == !r_shift),
+                   ADYOLO_EINVAL, "se_tail_fwd: bad arguments");
     const long hw4 = (long)HW * (C / 4);
     ADYOLO_REQUIRE(!mask || hw4 % 64 == 0, ADYOLO_ENOSUP, "se_tail_fwd: mask bits need HW*C/4 %% 64 == 0 (HW=%d C=%d)", HW, C);
     int gx = ew_grid(hw4);
     if ((long)gx * N > 16384) gx = (int)(16384 / N > 0 ? 16384 / N : 1);
-    hipLaunchKernelGGL(se_tail_fwd_kernel, dim3(gx, N), dim3(256), 0, as_stream(stream), c, r, scale, shift, s, e,
-                       reinterpret_cast<unsigned long long *>(mask), hw4, C / 4);
+    hipLaunchKernelGGL(se_tail_fwd_kernel, dim3(gx, N), dim3(256), 0, as_stream(stream), c, r, scale, shift, s, r_scale,
+                       r_shift, e, reinterpret_cast<unsigned long long *>(mask), hw4, C / 4);
     return check_launch("se_tail_fwd");
 }
 

@@ -28,6 +28,9 @@ FUSE_SEBWD = os.environ.get("ADYOLO_FUSE_SEBWD", "0") != "0"
 # The block's final ReLU mask (e > 0) is written as bits by se_tail_fwd (1/32 of the bytes of e) and the two backward passes
 # of the SE tail read the bits instead of e: 7 -> 5.06 tensor passes for se_tail_bwd.
 FUSE_MASKBITS = os.environ.get("ADYOLO_FUSE_MASKBITS", "1") != "0"
+# The stem's BatchNorm output is never written: the stem hands relu(conv(x)) and (scale, shift) to the first block, which
+# applies the affine while conv1 / its weight-gradient stage the tensor and while the SE tail reads the identity shortcut.
+FUSE_STEM_AFFINE = os.environ.get("ADYOLO_FUSE_STEM_AFFINE", "1") != "0"
 
 
 class BlockLink:
@@ -137,7 +140,10 @@ class StemFn(torch.autograd.Function):
     """conv3x3(7->32, bias) -> ReLU -> BatchNorm   (reference resnet.py:183-185; ReLU before BN)."""
 
     @staticmethod
-    def forward(ctx, x8, w, b, gamma, beta, bn, training):
+    def forward(ctx, x8, w, b, gamma, beta, bn, training, holder=None):
+        """holder (a BlockLink-like object) given: the BatchNorm affine is NOT applied here -- the output is relu(conv(x)) and
+        holder.affine = (scale, shift) for the consumer (SEBlockFn's ``p_affine``); the incoming gradient is then the
+        gradient w.r.t. the affine's output, exactly what the consumer returns for its input."""
         wpk, _ = ops.pack_w3x3(w, 8, want_dgrad=False)
         if training and FUSE_STATS:
             a, st = ops.conv3x3(x8, wpk, w.shape[0], bias=b, relu=True, want_stats=True)
@@ -146,7 +152,11 @@ class StemFn(torch.autograd.Function):
             a = ops.conv3x3(x8, wpk, w.shape[0], bias=b, relu=True)
             _, mean, invstd = _BNState(bn).stats(a, False)
             scale, shift = ops.bn_scale_shift(gamma, beta, mean, invstd)
-        out = ops.affine(a, scale, shift)
+        if holder is not None:
+            holder.affine = (scale, shift)
+            out = a
+        else:
+            out = ops.affine(a, scale, shift)
         ctx.training = training
         ctx.cin_real = w.shape[1]
         ctx.ptrs = (w.data_ptr(), gamma.data_ptr(), beta.data_ptr())
@@ -166,8 +176,8 @@ class StemFn(torch.autograd.Function):
         db = ops.colsum(da.view(-1, da.shape[-1]))
         if vw is not None:
             SINK.done(pw, pg, pb)
-            return None, None, db, None, None, None, None
-        return None, dw, db, dgamma, dbeta, None, None
+            return None, None, db, None, None, None, None, None
+        return None, dw, db, dgamma, dbeta, None, None, None
 
 
 class SEBlockFn(torch.autograd.Function):
@@ -181,16 +191,19 @@ class SEBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, training, pool, bns, w1, g1, b1, w2, g2, b2, fw1, fb1, fw2, fb2, wd=None, gd=None, bd=None):
-        bn1, bn2, bnd, link_in, link_out = bns
+        bn1, bn2, bnd, link_in, link_out = bns[:5]
+        p_aff = bns[5] if len(bns) > 5 else None      # (scale, shift): the input is seen through this per-channel affine
+        if p_aff is not None and (pool or wd is not None):
+            raise NotImplementedError("p_affine is only supported for identity-shortcut blocks without pooling")
         p = ops.avgpool2(x) if pool else x
         n, h, w_, cin = p.shape
         c = w1.shape[0]
         wpk1, wpk1d = ops.pack_w3x3(w1, cin)
         if training and FUSE_STATS:
-            a, st1 = ops.conv3x3(p, wpk1, c, relu=True, want_stats=True)
+            a, st1 = ops.conv3x3(p, wpk1, c, relu=True, want_stats=True, in_affine=p_aff)
             _, mean1, invstd1, scale1, shift1 = _BNState(bn1).stats_tiles(st1, a, affine=(g1, b1))
         else:
-            a = ops.conv3x3(p, wpk1, c, relu=True)
+            a = ops.conv3x3(p, wpk1, c, relu=True, in_affine=p_aff)
             _, mean1, invstd1 = _BNState(bn1).stats(a, training)
             scale1, shift1 = ops.bn_scale_shift(g1, b1, mean1, invstd1)
         wpk2, wpk2d = ops.pack_w3x3(w2, c)
@@ -224,13 +237,13 @@ class SEBlockFn(torch.autograd.Function):
             q = ops.gemm(p, wd, n * h * w_, c, cin, cin, cin).view(n, h, w_, c)
             _, meand, invstdd = _BNState(bnd).stats(q, training)
             scaled, shiftd = ops.bn_scale_shift(gd, bd, meand, invstdd)
-            r = ops.affine(q, scaled, shiftd)
+            r, raff = q, (scaled, shiftd)            # the downsample BatchNorm is applied while the tail reads q
         else:
-            r = p
+            r, raff = p, p_aff
         if training and FUSE_MASKBITS:
-            e, ebits = ops.se_tail_fwd(cc, r, scale2, shift2, s, want_mask=True)
+            e, ebits = ops.se_tail_fwd(cc, r, scale2, shift2, s, want_mask=True, r_affine=raff)
         else:
-            e, ebits = ops.se_tail_fwd(cc, r, scale2, shift2, s), None
+            e, ebits = ops.se_tail_fwd(cc, r, scale2, shift2, s, r_affine=raff), None
         ctx.link_in = link_in if (FUSE_SEBWD and FUSE_DR and training and link_in is not None and not pool
                                   and wd is None and link_in.cc is not None) else None
         ctx.link_out = link_out if (FUSE_SEBWD and training) else None
@@ -241,6 +254,7 @@ class SEBlockFn(torch.autograd.Function):
         ctx.fused_affine = aff is not None
         ctx.a_unfused = None if aff is not None else a      # (A/B switch only; keeps `a` alive for BN1's backward)
         ctx.has_bits = ebits is not None
+        ctx.p_aff = p_aff
         # storage addresses of the parameters whose gradients can be written straight into the flat buffer (GradSink)
         ctx.ptrs = (w1.data_ptr(), g1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
                     (fb2.data_ptr(), fw2.data_ptr(), fb1.data_ptr(), fw1.data_ptr(), b2.data_ptr(), g2.data_ptr()))
@@ -295,7 +309,7 @@ class SEBlockFn(torch.autograd.Function):
         else:
             dbb = ops.conv3x3(dc, wpk2d, c)
             da, dg1, db1 = ops.bn_bwd(dbb, a, g1, mean1, invstd1, relu_mask=True, out_dgamma=vg1, out_dbeta=vb1)
-        dw1 = ops.conv3x3_wgrad(p, da, cin, out=vw1)
+        dw1 = ops.conv3x3_wgrad(p, da, cin, in_affine=ctx.p_aff, out=vw1)
         if sunk:
             SINK.done(*pse)
             SINK.done(pw2, pg1, pb1, pw1)

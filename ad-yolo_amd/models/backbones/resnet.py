@@ -82,11 +82,13 @@ class SEBasicBlock(nn.Module):
         else:
             self.downsample = None
 
-    def forward(self, x, link_in=None, link_out=None):
-        """link_in / link_out: ``functional.BlockLink`` shared with the block below / above (see FUSE_SEBWD)."""
+    def forward(self, x, link_in=None, link_out=None, in_affine=None):
+        """link_in / link_out: ``functional.BlockLink`` shared with the block below / above (see FUSE_SEBWD);
+        in_affine = (scale, shift): x is seen through this per-channel affine (the stem's un-materialised BatchNorm)."""
         fc0, fc2 = self.se.fc["0"], self.se.fc["2"]
         args = [x, self.training, self.pool,
-                (self.bn1, self.bn2, self.downsample["1"] if self.downsample is not None else None, link_in, link_out),
+                (self.bn1, self.bn2, self.downsample["1"] if self.downsample is not None else None, link_in, link_out,
+                 in_affine),
                 self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight, self.bn2.weight, self.bn2.bias,
                 fc0.weight, fc0.bias, fc2.weight, fc2.bias]
         if self.downsample is not None:
@@ -172,13 +174,17 @@ class SEResnet34(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("SEResnet34 (adyolo_amd) runs on MI355X only; move the model/input to a HIP device")
         x8 = x if channels_last8 else ops.nchw_to_nhwc8(x.contiguous().float())
+        first = self.layer1[0]
+        holder = Fn.BlockLink() if (Fn.FUSE_STEM_AFFINE and not first.pool and first.downsample is None) else None
         y = Fn.StemFn.apply(x8, self.conv1.weight, self.conv1.bias, self.bn1.weight, self.bn1.bias, self.bn1,
-                            self.training)
+                            self.training, holder)
+        stem_affine = holder.affine if holder is not None else None     # the stem's BatchNorm is applied by its consumer
         link = None                              # BlockLink between consecutive blocks (functional.FUSE_SEBWD)
         for li in range(1, 5):
             for blk in getattr(self, "layer%d" % li):
                 nxt = Fn.BlockLink()
-                y = blk(y, link_in=link, link_out=nxt)
+                y = blk(y, link_in=link, link_out=nxt, in_affine=stem_affine)
+                stem_affine = None
                 link = nxt
         y = Fn.SAPFn.apply(y, self.attention.W.weight, self.attention.W.bias)
         save = self.training and torch.is_grad_enabled()

@@ -285,8 +285,8 @@ def se_fc_fwd(ssum, scale, shift, w1, b1, w2, b2, hw):
     return pooled, hid, s
 
 
-def se_tail_fwd(c_t, r_t, scale, shift, s, want_mask=False):
-    """e = relu((c*scale+shift)*s + r).  want_mask: also return the ReLU mask (e > 0) as bits (int64 words, 1/32 of the
+def se_tail_fwd(c_t, r_t, scale, shift, s, want_mask=False, r_affine=None):
+    """e = relu((c*scale+shift)*s + r), r seen through r_affine = (scale, shift) per channel when given.  want_mask: also return the ReLU mask (e > 0) as bits (int64 words, 1/32 of the
     bytes of e) for ``se_tail_bwd(..., mask=)``; None when the shape does not support it (HW*C/4 % 64 != 0)."""
     _chk(c_t, r_t, scale, shift, s)
     n, ch = c_t.shape[0], c_t.shape[-1]
@@ -297,7 +297,9 @@ def se_tail_fwd(c_t, r_t, scale, shift, s, want_mask=False):
         words = _lib.load().adyolo_relu_mask_words(n, hw, ch)
         if words > 0:
             mask = torch.empty(words, dtype=torch.int64, device=c_t.device)
-    _c("adyolo_se_tail_fwd", _p(c_t), _p(r_t), _p(scale), _p(shift), _p(s), _p(e), _p(mask), n, hw, ch, _stream())
+    rs, rt = r_affine if r_affine is not None else (None, None)
+    _c("adyolo_se_tail_fwd", _p(c_t), _p(r_t), _p(scale), _p(shift), _p(s), _p(rs), _p(rt), _p(e), _p(mask), n, hw, ch,
+       _stream())
     return (e, mask) if want_mask else e
 
 

@@ -194,8 +194,11 @@ int adyolo_se_fc_fwd(const float *ssum, const float *scale, const float *shift, 
  * not supported: HW*C/4 must be a multiple of 64).  The backward passes then read the bits (1/32 of the bytes) instead
  * of e; with mask given, e may be NULL there. */
 long adyolo_relu_mask_words(int N, int HW, int C);
+/* r_scale / r_shift (both or neither): e = relu((c*scale+shift)*s + (r*r_scale + r_shift)) -- the downsample branch's
+ * BatchNorm (resnet.py:160-163) applied while the shortcut is read, so bn(conv1x1(x)) is never written */
 int adyolo_se_tail_fwd(const float *c, const float *r, const float *scale, const float *shift,
-                       const float *s, float *e, uint64_t *mask /*or NULL*/, int N, int HW, int C, void *stream);
+                       const float *s, const float *r_scale /*or NULL*/, const float *r_shift /*or NULL*/, float *e,
+                       uint64_t *mask /*or NULL*/, int N, int HW, int C, void *stream);
 int adyolo_se_tail_bwd_reduce(const float *de, const float *e, const uint64_t *mask /*or NULL*/, const float *c,
                               const float *mean, const float *invstd, float *sg, float *sgx, float *partial, int N,
                               int HW, int C, void *stream);
