@@ -24,10 +24,10 @@ SIGNATURES = {
     "adyolo_nchw_to_nhwc8": (I, [P, P, I, I, I, I, P]),
     "adyolo_pack_w3x3": (I, [P, P, P, I, I, I, P]),
     "adyolo_conv3x3_tiles": (I, [I] * 3),
-    "adyolo_conv3x3_fwd": (I, [P] * 13 + [I] * 6 + [P]),
+    "adyolo_conv3x3_fwd": (I, [P] * 13 + [I] * 7 + [P]),
     "adyolo_wino_pack_w": (I, [P, P, P, I, I, I, P]),
     "adyolo_wino_tiles": (I, [I] * 3),
-    "adyolo_wino_fwd": (I, [P] * 13 + [I] * 6 + [P]),
+    "adyolo_wino_fwd": (I, [P] * 13 + [I] * 7 + [P]),
     "adyolo_wino_wgrad_slabs": (I, [I] * 5),
     "adyolo_wino_wgrad": (I, [P] * 7 + [I] * 6 + [P]),
     "adyolo_conv3x3_wgrad_slabs": (I, [I] * 5),

@@ -51,6 +51,23 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ReLU mask of a tensor as bits: the float4 with global index i (4 consecutive channels) owns bit (i & 63) of the four
+// 64-bit words mask[(i >> 6) * 4 + k], k = component -- one wave-wide ballot per component when a wave covers 64
+// consecutive, 64-aligned float4s.  Reading the mask moves 1/32 of the bytes of reading the tensor itself.
+__device__ __forceinline__ void mask_bits4(const unsigned long long *__restrict__ mask, size_t i, bool &x, bool &y,
+                                           bool &z, bool &w) {
+    const ulonglong2 lo = *reinterpret_cast<const ulonglong2 *>(mask + (i >> 6) * 4);
+    const ulonglong2 hi = *reinterpret_cast<const ulonglong2 *>(mask + (i >> 6) * 4 + 2);
+    const int b = (int)(i & 63);
+    x = (lo.x >> b) & 1ull; y = (lo.y >> b) & 1ull; z = (hi.x >> b) & 1ull; w = (hi.y >> b) & 1ull;
+}
+
+// one element (flat index o of the tensor) of the same bit mask
+__device__ __forceinline__ bool mask_bit1(const unsigned long long *__restrict__ mask, size_t o) {
+    const size_t i = o >> 2;
+    return (mask[(i >> 6) * 4 + (o & 3)] >> (i & 63)) & 1ull;
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // Sum `nparts` partial rows of a [nparts][ld] fp32 array for 32 consecutive columns starting at c0, in double.

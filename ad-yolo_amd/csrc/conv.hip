@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(
     const float *__restrict__ addend, const float *__restrict__ addend_mask, const float *__restrict__ in_scale,
     const float *__restrict__ in_shift, float *__restrict__ y, float *__restrict__ stats,
     const float *__restrict__ stat_aux, const float *__restrict__ stat_mean, const float *__restrict__ stat_invstd,
-    const float *__restrict__ stat_mask, int H, int W, int Cin, int Cout, int tilesW, int tilesH, int relu) {
+    const float *__restrict__ stat_mask, int H, int W, int Cin, int Cout, int tilesW, int tilesH, int relu,
+    int mask_bits) {
     using Cfg = ConvCfg<KC, BN, TW>;
     constexpr int TH = Cfg::TH, HW_ = Cfg::HW_, NPIX = Cfg::NPIX, AS = Cfg::AS, NT = Cfg::NT, Q = Cfg::Q;
     constexpr int WPT = Cfg::WPT;
@@ -185,11 +186,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(
                     if (bias) v += bias[co];
                     if (addend) {
                         const float ad = addend[o];
-                        v += addend_mask ? (addend_mask[o] > 0.f ? ad : 0.f) : ad;
+                        const bool keep = !addend_mask ? true
+                                          : ((mask_bits & 1) ? mask_bit1(reinterpret_cast<const unsigned long long *>(addend_mask), o)
+                                                             : addend_mask[o] > 0.f);
+                        v += keep ? ad : 0.f;
                     }
                     if (relu) v = fmaxf(v, 0.f);
                     y[o] = v;
-                    if (stat_mask && !(stat_mask[o] > 0.f)) v = 0.f;      // statistics of v * (mask > 0)
+                    if (stat_mask) {                                      // statistics of v * (mask > 0)
+                        const bool keep = (mask_bits & 2) ? mask_bit1(reinterpret_cast<const unsigned long long *>(stat_mask), o)
+                                                          : stat_mask[o] > 0.f;
+                        if (!keep) v = 0.f;
+                    }
                     ssum[nt] += v;
                     // second statistic: v^2 (BatchNorm forward of the consumer) or v * xhat(aux) (BatchNorm backward:
                     // sum dy * xhat, with aux = the BatchNorm input living at the same positions as this output)
@@ -394,7 +402,7 @@ template <int KC, int BN, int TW>
 static int launch_fwd(const float *x, const float *wpk, const float *bias, const float *addend,
                       const float *addend_mask, const float *in_scale, const float *in_shift, float *y, float *stats,
                       const float *stat_aux, const float *stat_mean, const float *stat_invstd, const float *stat_mask,
-                      int N, int H, int W, int Cin, int Cout, int relu, hipStream_t st) {
+                      int N, int H, int W, int Cin, int Cout, int relu, int mask_bits, hipStream_t st) {
     // (a variant that walks several patches per workgroup and prefetches the next halo patch into registers under
     //  the current patch's MFMAs was measured 6-9 % SLOWER at every stage on MI355X -- 252 VGPRs, no gain over the
     //  overlap two resident workgroups per CU already give -- and was removed; see DESIGN.md "Tried and rejected")
@@ -403,7 +411,7 @@ static int launch_fwd(const float *x, const float *wpk, const float *bias, const
     dim3 grid((unsigned)(N * tilesH * tilesW), (unsigned)(Cout / BN));
     hipLaunchKernelGGL((conv3x3_fwd_kernel<KC, BN, TW>), grid, dim3(256), 0, st, x, wpk, bias, addend, addend_mask,
                        in_scale, in_shift, y, stats, stat_aux, stat_mean, stat_invstd, stat_mask, H, W, Cin, Cout, tilesW,
-                       tilesH, relu);
+                       tilesH, relu, mask_bits);
     return check_launch("conv3x3_fwd");
 }
 
@@ -442,8 +450,10 @@ extern "C" int adyolo_conv3x3_fwd(const float *x, const float *wpk, const float 
                                   const float *addend_mask, const float *in_scale, const float *in_shift, float *y,
                                   float *stats, const float *stat_aux, const float *stat_mean,
                                   const float *stat_invstd, const float *stat_mask, int N, int H, int W, int Cin,
-                                  int Cout, int relu, void *stream) {
+                                  int Cout, int relu, int mask_bits, void *stream) {
     ADYOLO_REQUIRE(x && wpk && y && N > 0 && H > 0 && W > 0, ADYOLO_EINVAL, "conv3x3_fwd: bad arguments");
+    ADYOLO_REQUIRE(!(mask_bits & ~3) && (!mask_bits || ((long)H * W * (Cout / 4)) % 64 == 0), ADYOLO_ENOSUP,
+                   "conv3x3_fwd: mask bits need H*W*Cout/4 %% 64 == 0");
     ADYOLO_REQUIRE((Cin == 8 || Cin % 32 == 0) && Cout % 32 == 0, ADYOLO_ENOSUP,
                    "conv3x3_fwd: Cin=%d must be 8 or a multiple of 32, Cout=%d a multiple of 32", Cin, Cout);
     ADYOLO_REQUIRE((in_scale == nullptr) == (in_shift == nullptr) && (!addend_mask || addend), ADYOLO_EINVAL,
@@ -455,7 +465,7 @@ extern "C" int adyolo_conv3x3_fwd(const float *x, const float *wpk, const float 
     const bool wide = W >= 32;
 #define ADYOLO_FWD(KC_, BN_, TW_) \
     launch_fwd<KC_, BN_, TW_>(x, wpk, bias, addend, addend_mask, in_scale, in_shift, y, stats, stat_aux, stat_mean, \
-                              stat_invstd, stat_mask, N, H, W, Cin, Cout, relu, st)
+                              stat_invstd, stat_mask, N, H, W, Cin, Cout, relu, mask_bits, st)
     if (Cin == 8) return wide ? ADYOLO_FWD(8, 32, 32) : ADYOLO_FWD(8, 32, 16);
     if (Cout % 64 == 0) return wide ? ADYOLO_FWD(32, 64, 32) : ADYOLO_FWD(32, 64, 16);
     return wide ? ADYOLO_FWD(32, 32, 32) : ADYOLO_FWD(32, 32, 16);

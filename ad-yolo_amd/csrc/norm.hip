@@ -67,17 +67,6 @@ struct BnBwdF {          // (dy, dy * xhat)
                         a.w * (xv.w - m.w) * is.w);
     }
 };
-// ReLU mask of a tensor as bits: the float4 with global index i (4 consecutive channels) owns bit (i & 63) of the four
-// 64-bit words mask[(i >> 6) * 4 + k], k = component -- one wave-wide ballot per component when a wave covers 64
-// consecutive, 64-aligned float4s.  Reading the mask moves 1/32 of the bytes of reading the tensor itself.
-__device__ __forceinline__ void mask_bits4(const unsigned long long *__restrict__ mask, size_t i, bool &x, bool &y,
-                                           bool &z, bool &w) {
-    const ulonglong2 lo = *reinterpret_cast<const ulonglong2 *>(mask + (i >> 6) * 4);
-    const ulonglong2 hi = *reinterpret_cast<const ulonglong2 *>(mask + (i >> 6) * 4 + 2);
-    const int b = (int)(i & 63);
-    x = (lo.x >> b) & 1ull; y = (lo.y >> b) & 1ull; z = (hi.x >> b) & 1ull; w = (hi.y >> b) & 1ull;
-}
-
 struct SeBwdF {          // g = de * (e > 0): (g, g * xhat(c)); the mask comes from `mask` bits when given, else from e
     const float *de, *e, *c, *mean, *invstd; const unsigned long long *mask; int HW, C;
     __device__ void operator()(int n, int r, int cx, float4 &a, float4 &b) const {

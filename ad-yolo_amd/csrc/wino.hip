@@ -50,7 +50,9 @@ __global__ __launch_bounds__(256, (WinoCfg<NT, ONE>::WG_PER_CU)) void wino_fwd_k
     const float *__restrict__ in_shift, float *__restrict__ y, float *__restrict__ stats,
     const float *__restrict__ stat_aux, const float *__restrict__ stat_mean, const float *__restrict__ stat_invstd,
     const float *__restrict__ stat_mask, int H, int W, int Cin, int Cout, int tilesW, int tilesH, int nsp, int ncb,
-    int xcd_div, int relu) {
+    int xcd_div, int relu, int mask_bits) {
+    // mask_bits: bit 0 -- addend_mask points to ReLU-mask BITS (common.hpp mask_bits4) instead of a float tensor;
+    //            bit 1 -- the same for stat_mask (1/32 of the epilogue's read traffic for that operand)
     using Cfg = WinoCfg<NT, ONE>;
     constexpr int CB = Cfg::CB, CBP = Cfg::CBP;
     constexpr int AFFC = ONE ? WKC : WMAXC;               // channels in the affine table
@@ -315,9 +317,14 @@ __global__ __launch_bounds__(256, (WinoCfg<NT, ONE>::WG_PER_CU)) void wino_fwd_k
                     if (addend) {
                         float4 ad = *reinterpret_cast<const float4 *>(addend + o);
                         if (addend_mask) {
-                            const float4 mk = *reinterpret_cast<const float4 *>(addend_mask + o);
-                            ad = make_float4(mk.x > 0.f ? ad.x : 0.f, mk.y > 0.f ? ad.y : 0.f, mk.z > 0.f ? ad.z : 0.f,
-                                             mk.w > 0.f ? ad.w : 0.f);
+                            bool kx, ky, kz, kw;
+                            if (mask_bits & 1) {
+                                mask_bits4(reinterpret_cast<const unsigned long long *>(addend_mask), o >> 2, kx, ky, kz, kw);
+                            } else {
+                                const float4 mk = *reinterpret_cast<const float4 *>(addend_mask + o);
+                                kx = mk.x > 0.f; ky = mk.y > 0.f; kz = mk.z > 0.f; kw = mk.w > 0.f;
+                            }
+                            ad = make_float4(kx ? ad.x : 0.f, ky ? ad.y : 0.f, kz ? ad.z : 0.f, kw ? ad.w : 0.f);
                         }
                         v = f4_add(v, ad);
                     }
@@ -325,9 +332,14 @@ __global__ __launch_bounds__(256, (WinoCfg<NT, ONE>::WG_PER_CU)) void wino_fwd_k
                     *reinterpret_cast<float4 *>(y + o) = v;      // (non-temporal loads/stores here: measured 1 % slower)
                     if (stats) {
                         if (stat_mask) {        // statistics of v * (mask > 0): the SE / BN2 backward sums of the block below
-                            const float4 mk = *reinterpret_cast<const float4 *>(stat_mask + o);
-                            v = make_float4(mk.x > 0.f ? v.x : 0.f, mk.y > 0.f ? v.y : 0.f, mk.z > 0.f ? v.z : 0.f,
-                                            mk.w > 0.f ? v.w : 0.f);
+                            bool kx, ky, kz, kw;
+                            if (mask_bits & 2) {
+                                mask_bits4(reinterpret_cast<const unsigned long long *>(stat_mask), o >> 2, kx, ky, kz, kw);
+                            } else {
+                                const float4 mk = *reinterpret_cast<const float4 *>(stat_mask + o);
+                                kx = mk.x > 0.f; ky = mk.y > 0.f; kz = mk.z > 0.f; kw = mk.w > 0.f;
+                            }
+                            v = make_float4(kx ? v.x : 0.f, ky ? v.y : 0.f, kz ? v.z : 0.f, kw ? v.w : 0.f);
                         }
                         ssum = f4_add(ssum, v);
                         if (stat_aux) {
@@ -440,8 +452,11 @@ extern "C" int adyolo_wino_pack_w(const float *w, float *u_fwd, float *u_dgrad, 
 extern "C" int adyolo_wino_fwd(const float *x, const float *u, const float *bias, const float *addend,
                                const float *addend_mask, const float *in_scale, const float *in_shift, float *y,
                                float *stats, const float *stat_aux, const float *stat_mean, const float *stat_invstd,
-                               const float *stat_mask, int N, int H, int W, int Cin, int Cout, int relu, void *stream) {
+                               const float *stat_mask, int N, int H, int W, int Cin, int Cout, int relu, int mask_bits,
+                               void *stream) {
     ADYOLO_REQUIRE(x && u && y && N > 0 && H > 0 && W > 0, ADYOLO_EINVAL, "wino_fwd: bad arguments");
+    ADYOLO_REQUIRE(!(mask_bits & ~3) && (!mask_bits || ((long)H * W * (Cout / 4)) % 64 == 0), ADYOLO_ENOSUP,
+                   "wino_fwd: mask bits need H*W*Cout/4 %% 64 == 0");
     ADYOLO_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0 && Cin > 0 && Cout > 0 && Cin <= WMAXC, ADYOLO_ENOSUP,
                    "wino_fwd: Cin=%d (<= 512) and Cout=%d must be multiples of 32", Cin, Cout);
     ADYOLO_REQUIRE((size_t)H * W * Cin * 4 < ((size_t)1 << 31), ADYOLO_ENOSUP, "wino_fwd: one sample must stay below 2 GiB");
@@ -463,7 +478,7 @@ extern "C" int adyolo_wino_fwd(const float *x, const float *u, const float *bias
 #define ADYOLO_WINO_FWD(NT_, ONE_)                                                                                  \
     hipLaunchKernelGGL((wino_fwd_kernel<NT_, ONE_>), dim3((unsigned)blocks), dim3(256), 0, st, x, u, bias, addend,       \
                        addend_mask, in_scale, in_shift, y, stats, stat_aux, stat_mean, stat_invstd, stat_mask, H, W,   \
-                       Cin, Cout, tilesW, tilesH, nsp, ncb, xcd_div, relu)
+                       Cin, Cout, tilesW, tilesH, nsp, ncb, xcd_div, relu, mask_bits)
     if (Cin == WKC) {
         if (nt == 2) ADYOLO_WINO_FWD(2, true); else ADYOLO_WINO_FWD(1, true);
     } else {

@@ -23,8 +23,10 @@ FUSE_BNBWD = os.environ.get("ADYOLO_FUSE_BNBWD", "1") != "0"
 # launch that produces dA = conv1_dgrad(da_B) + de_B * (e_B > 0) also sums dA * (e_A > 0) and dA * (e_A > 0) * xhat(c_A) per
 # patch (stat_mask = e_A = B's input, stat_aux = c_A), so A's backward skips its three-tensor reduction pass.  Active for 12
 # of the 16 blocks, bit-compatible with the unfused path in the golden tests, but the two extra tensors the epilogue
-# reads cost what the removed pass saved (168.5 vs 168.3 ms per step): off by default, kept as an A/B switch.
-FUSE_SEBWD = os.environ.get("ADYOLO_FUSE_SEBWD", "0") != "0"
+# reads cost what the removed pass saved (168.5 vs 168.3 ms per step) in round 1.  Round 2: with the ReLU masks read as
+# BITS (stat_mask and addend_mask of the epilogue move 1/32 of the bytes) the fusion wins 0.3-0.5 ms per step
+# (160.45 / 160.72 -> 160.18 ms in one session) and is on; ADYOLO_FUSE_SEBWD=0 switches it off.
+FUSE_SEBWD = os.environ.get("ADYOLO_FUSE_SEBWD", "1") != "0"
 # The block's final ReLU mask (e > 0) is written as bits by se_tail_fwd (1/32 of the bytes of e) and the two backward passes
 # of the SE tail read the bits instead of e: 7 -> 5.06 tensor passes for se_tail_bwd.
 FUSE_MASKBITS = os.environ.get("ADYOLO_FUSE_MASKBITS", "1") != "0"
@@ -38,7 +40,7 @@ class BlockLink:
     A.forward publishes (c_A, mean2_A, invstd2_A); B.backward leaves the per-patch sums for A.backward."""
 
     def __init__(self):
-        self.cc = self.mean2 = self.invstd2 = self.tiles = None
+        self.cc = self.mean2 = self.invstd2 = self.tiles = self.ebits = None
 
 
 def _c(t):
@@ -249,6 +251,7 @@ class SEBlockFn(torch.autograd.Function):
         ctx.link_out = link_out if (FUSE_SEBWD and training) else None
         if ctx.link_out is not None:
             link_out.cc, link_out.mean2, link_out.invstd2, link_out.tiles = cc, mean2, invstd2, None
+            link_out.ebits = ebits
         ctx.training, ctx.pool, ctx.has_down = training, pool, wd is not None
         ctx.in_hw = (x.shape[1], x.shape[2])
         ctx.fused_affine = aff is not None
@@ -325,12 +328,14 @@ class SEBlockFn(torch.autograd.Function):
             dp = ops.conv3x3(da, wpk1d, cin, addend=dp_res)
         else:
             # identity shortcut: its gradient de * (e > 0) is formed inside the dgrad epilogue
+            emask = ebits if ebits is not None else e          # this block's ReLU mask: bits when the forward stored them
             if ctx.link_in is not None:
                 lk = ctx.link_in
-                dp, lk.tiles = ops.conv3x3(da, wpk1d, cin, addend=de, addend_mask=e, want_stats=True,
-                                           stat_bn=(lk.cc, lk.mean2, lk.invstd2), stat_mask=p)
+                dp, lk.tiles = ops.conv3x3(da, wpk1d, cin, addend=de, addend_mask=emask, want_stats=True,
+                                           stat_bn=(lk.cc, lk.mean2, lk.invstd2),
+                                           stat_mask=lk.ebits if lk.ebits is not None else p)
             elif FUSE_DR:
-                dp = ops.conv3x3(da, wpk1d, cin, addend=de, addend_mask=e)
+                dp = ops.conv3x3(da, wpk1d, cin, addend=de, addend_mask=emask)
             else:
                 dp = ops.conv3x3(da, wpk1d, cin, addend=dr)
         dx = ops.avgpool2_bwd(dp, ctx.in_hw[0], ctx.in_hw[1]) if ctx.pool else dp

@@ -82,8 +82,14 @@ def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, 
     addend_mask: addend is multiplied by (mask > 0); want_stats: also return the per-patch channel sums
     [2][tiles][cout] of the output for ``bn_stats_tiles``; stat_bn=(aux, mean, invstd): the second per-patch sum
     becomes sum(y * xhat(aux)) (the output is a gradient, aux the BatchNorm input) for ``bn_bwd(..., tile_stats=)``;
-    stat_mask: both sums are taken of y * (stat_mask > 0) (for ``se_tail_bwd(..., tile_stats=)`` of the block below)."""
-    _chk(x, wpk, bias, addend, addend_mask, stat_mask)
+    stat_mask: both sums are taken of y * (stat_mask > 0) (for ``se_tail_bwd(..., tile_stats=)`` of the block below).
+    addend_mask / stat_mask may also be the int64 ReLU-mask BITS ``se_tail_fwd(..., want_mask=True)`` returned."""
+    mbits = 0
+    if addend_mask is not None and addend_mask.dtype == torch.int64:
+        mbits |= 1
+    if stat_mask is not None and stat_mask.dtype == torch.int64:
+        mbits |= 2
+    _chk(x, wpk, bias, addend, None if mbits & 1 else addend_mask, None if mbits & 2 else stat_mask)
     n, h, w, cin = x.shape
     wino = wpk.dim() == 4
     y = _new(x, n, h, w, cout)
@@ -94,7 +100,8 @@ def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, 
     sc, sh = in_affine if in_affine is not None else (None, None)
     sa, sm, si = stat_bn if stat_bn is not None else (None, None, None)
     _c("adyolo_wino_fwd" if wino else "adyolo_conv3x3_fwd", _p(x), _p(wpk), _p(bias), _p(addend), _p(addend_mask),
-       _p(sc), _p(sh), _p(y), _p(stats), _p(sa), _p(sm), _p(si), _p(stat_mask), n, h, w, cin, cout, int(relu), _stream())
+       _p(sc), _p(sh), _p(y), _p(stats), _p(sa), _p(sm), _p(si), _p(stat_mask), n, h, w, cin, cout, int(relu), mbits,
+       _stream())
     return (y, stats) if want_stats else y
 
 

@@ -70,6 +70,8 @@ int adyolo_nchw_to_nhwc8(const float *x, float *y, int B, int C, int H, int W, v
  *   y = relu?( conv(x', w) + bias + addend' )   with the optional fusions
  *     x' = x*in_scale[c] + in_shift[c] on in-image pixels (BatchNorm affine of the producer; zero padding stays 0)
  *     addend' = addend * (addend_mask > 0)  (residual gradient  de * (e > 0)  formed on the fly)
+ *     mask_bits: bit 0 -- addend_mask points to ReLU-mask BITS (the uint64 words adyolo_se_tail_fwd writes, see K3b)
+ *       instead of a float tensor; bit 1 -- the same for stat_mask.  Bits move 1/32 of the bytes.
  *     stats [2][tiles][Cout]: per 256-pixel patch, per channel sum of y and either sum of y^2 (stat_aux == NULL: the
  *       BatchNorm statistics / SE squeeze of the consumer, finished by adyolo_bn_stats_tiles) or sum of
  *       y * (stat_aux - stat_mean[c]) * stat_invstd[c] (y is a gradient, stat_aux the BatchNorm input at the same
@@ -86,7 +88,7 @@ int adyolo_conv3x3_tiles(int N, int H, int W);   /* number of 256-pixel patches 
 int adyolo_conv3x3_fwd(const float *x, const float *wpk, const float *bias, const float *addend,
                        const float *addend_mask, const float *in_scale, const float *in_shift, float *y,
                        float *stats, const float *stat_aux, const float *stat_mean, const float *stat_invstd,
-                       const float *stat_mask, int N, int H, int W, int Cin, int Cout, int relu, void *stream);
+                       const float *stat_mask, int N, int H, int W, int Cin, int Cout, int relu, int mask_bits, void *stream);
 /*   stat_mask (optional, needs stats): the two per-patch sums are taken of y * (stat_mask > 0) instead of y -- with
  *   stat_aux = c and stat_mask = e of the block BELOW, the data-gradient launch that produces de also produces the
  *   per-sample sums of the SE / BatchNorm-2 backward (finished by adyolo_se_tail_bwd_tiles), y itself is unaffected. */
@@ -101,7 +103,7 @@ int adyolo_wino_tiles(int N, int H, int W);
 int adyolo_wino_fwd(const float *x, const float *u, const float *bias, const float *addend,
                     const float *addend_mask, const float *in_scale, const float *in_shift, float *y, float *stats,
                     const float *stat_aux, const float *stat_mean, const float *stat_invstd, const float *stat_mask,
-                    int N, int H, int W, int Cin, int Cout, int relu, void *stream);
+                    int N, int H, int W, int Cin, int Cout, int relu, int mask_bits, void *stream);
 /* Winograd weight-gradient: dw = G^T [ sum_tiles (B^T d B)(.)(A e A^T) ] G.  slabs: [n_slabs][16][Cin][Cout] float32 with
  * n_slabs = adyolo_wino_wgrad_slabs(...); du: [16][Cin][Cout] scratch; dw: reference layout [Cout][Cin_real][3][3]. */
 int adyolo_wino_wgrad_slabs(int N, int H, int W, int Cin, int Cout);
