@@ -42,7 +42,7 @@ SIGNATURES = {
     "adyolo_affine_nhwc": (I, [P] * 4 + [L, I, P]),
     "adyolo_bn_bwd_reduce": (I, [P] * 7 + [L, I, P]),
     "adyolo_bn_bwd_tiles": (I, [P, P, P, P, I, I, P]),
-    "adyolo_bn_bwd_apply": (I, [P] * 10 + [L, I, I, P]),
+    "adyolo_bn_bwd_apply": (I, [P] * 12 + [L, I, I, P]),
     "adyolo_se_fc_fwd": (I, [P] * 10 + [I, I, I, I, P]),
     "adyolo_relu_mask_words": (L, [I, I, I]),
     "adyolo_se_tail_fwd": (I, [P] * 9 + [I, I, I, P]),

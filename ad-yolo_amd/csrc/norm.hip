@@ -196,7 +196,13 @@ __global__ __launch_bounds__(256) void affine_kernel(const float *__restrict__ x
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ gamma,
     const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ sdy,
-    const float *__restrict__ sdyx, float *__restrict__ dx, long n4, int c4n, float invR, int relu_mask) {
+    const float *__restrict__ sdyx, float *__restrict__ dx, float *__restrict__ sum_partial, long n4, int c4n, float invR,
+    int relu_mask) {
+    // sum_partial (optional, [gridDim.x][C]): per-workgroup channel sums of dx -- e.g. the bias gradient of the convolution
+    // that feeds this BatchNorm (the stem's: a separate column sum would re-read the 1.26 GB tensor).  A thread's channel
+    // quad is fixed (the grid stride is a multiple of C/4), so it accumulates in registers.
+    __shared__ float4 sred[256];
+    float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int cx = (int)(i % c4n);
         const float4 d = reinterpret_cast<const float4 *>(dy)[i];
@@ -218,7 +224,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
             if (!(xv.w > 0.f)) o.w = 0.f;
         }
         reinterpret_cast<float4 *>(dx)[i] = o;
+        sacc.x += o.x; sacc.y += o.y; sacc.z += o.z; sacc.w += o.w;
     }
+    if (sum_partial) {          // fixed order: threads with the same channel quad are tid, tid + c4n, ...
+        sred[threadIdx.x] = sacc;
+        __syncthreads();
+        if ((int)threadIdx.x < c4n) {
+            float4 t = sred[threadIdx.x];
+            for (int k = threadIdx.x + c4n; k < 256; k += c4n) {
+                const float4 u = sred[k];
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            reinterpret_cast<float4 *>(sum_partial + (size_t)blockIdx.x * c4n * 4)[threadIdx.x] = t;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void partial_colsum_kernel(const float *__restrict__ partial, float *__restrict__ out,
+                                                             int nblk, int C) {
+    __shared__ double red[256];
+    const double sm = block_colsum32(partial, nblk, (size_t)C, blockIdx.x * 32, C, red);
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    if ((threadIdx.x >> 5) == 0 && c < C) out[c] = (float)sm;
 }
 __global__ void accum2_kernel(const float *a, const float *b, float *da, float *db, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -554,15 +580,24 @@ extern "C" int adyolo_bn_bwd_tiles(const float *tile_stats, float *sdy, float *s
 
 extern "C" int adyolo_bn_bwd_apply(const float *dy, const float *x, const float *gamma, const float *mean,
                                    const float *invstd, const float *sdy, const float *sdyx, float *dx, float *dgamma,
-                                   float *dbeta, long rows, int C, int relu_mask, void *stream) {
+                                   float *dbeta, float *dx_colsum, float *colsum_partial, long rows, int C,
+                                   int relu_mask, void *stream) {
     ADYOLO_REQUIRE(dy && x && gamma && mean && invstd && sdy && sdyx && dx && rows > 0 && C % 4 == 0, ADYOLO_EINVAL,
                    "bn_bwd_apply: bad arguments");
     hipStream_t st = as_stream(stream);
     const long n4 = rows * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, dy, x, gamma, mean, invstd, sdy, sdyx,
-                       dx, n4, C / 4, (float)(1.0 / (double)rows), relu_mask);
+    ADYOLO_REQUIRE(!dx_colsum || (colsum_partial && 256 % (C / 4) == 0), ADYOLO_EINVAL,
+                   "bn_bwd_apply: dx_colsum needs a [8192][C] partial workspace and C/4 dividing 256");
+    const int grid = ew_grid(n4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, dy, x, gamma, mean, invstd, sdy, sdyx, dx,
+                       dx_colsum ? colsum_partial : (float *)nullptr, n4, C / 4, (float)(1.0 / (double)rows), relu_mask);
     int rc = check_launch("bn_bwd_apply");
     if (rc) return rc;
+    if (dx_colsum) {
+        hipLaunchKernelGGL(partial_colsum_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, colsum_partial, dx_colsum, grid, C);
+        rc = check_launch("bn_bwd_apply_colsum");
+        if (rc) return rc;
+    }
     if (dgamma || dbeta) {
         hipLaunchKernelGGL(accum2_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, sdyx, sdy, dgamma, dbeta, C);
         rc = check_launch("bn_bwd_accum");

@@ -41,6 +41,7 @@ class BlockLink:
 
     def __init__(self):
         self.cc = self.mean2 = self.invstd2 = self.tiles = self.ebits = None
+        self.affine = self.stem_bn = None        # (stem hand-over: see StemFn / FUSE_STEM_AFFINE)
 
 
 def _c(t):
@@ -154,8 +155,12 @@ class StemFn(torch.autograd.Function):
             a = ops.conv3x3(x8, wpk, w.shape[0], bias=b, relu=True)
             _, mean, invstd = _BNState(bn).stats(a, False)
             scale, shift = ops.bn_scale_shift(gamma, beta, mean, invstd)
+        ctx.holder = None
         if holder is not None:
             holder.affine = (scale, shift)
+            if training and FUSE_BNBWD:            # the consumer's dgrad epilogue can sum this BatchNorm's backward statistics
+                holder.stem_bn = (a, mean, invstd)
+                ctx.holder = holder
             out = a
         else:
             out = ops.affine(a, scale, shift)
@@ -173,9 +178,12 @@ class StemFn(torch.autograd.Function):
         x8, a, gamma, mean, invstd = ctx.saved_tensors
         pw, pg, pb = ctx.ptrs
         vg, vb, vw = SINK.view(pg), SINK.view(pb), SINK.view(pw, ctx.wshape)
-        da, dgamma, dbeta = ops.bn_bwd(_c(dout), a, gamma, mean, invstd, relu_mask=True, out_dgamma=vg, out_dbeta=vb)
+        tiles = None
+        if ctx.holder is not None and ctx.holder.tiles is not None:      # left by the first block's dgrad epilogue
+            tiles, ctx.holder.tiles = ctx.holder.tiles, None
+        da, dgamma, dbeta, db = ops.bn_bwd(_c(dout), a, gamma, mean, invstd, relu_mask=True, tile_stats=tiles,
+                                           out_dgamma=vg, out_dbeta=vb, want_dx_colsum=True)   # db = sum of da: the conv bias gradient
         dw = ops.conv3x3_wgrad(x8, da, ctx.cin_real, out=vw)
-        db = ops.colsum(da.view(-1, da.shape[-1]))
         if vw is not None:
             SINK.done(pw, pg, pb)
             return None, None, db, None, None, None, None, None
@@ -195,6 +203,7 @@ class SEBlockFn(torch.autograd.Function):
     def forward(ctx, x, training, pool, bns, w1, g1, b1, w2, g2, b2, fw1, fb1, fw2, fb2, wd=None, gd=None, bd=None):
         bn1, bn2, bnd, link_in, link_out = bns[:5]
         p_aff = bns[5] if len(bns) > 5 else None      # (scale, shift): the input is seen through this per-channel affine
+        ctx.stem_holder = bns[6] if len(bns) > 6 else None    # BlockLink of the stem: its BatchNorm backward sums come from our dgrad
         if p_aff is not None and (pool or wd is not None):
             raise NotImplementedError("p_affine is only supported for identity-shortcut blocks without pooling")
         p = ops.avgpool2(x) if pool else x
@@ -334,6 +343,11 @@ class SEBlockFn(torch.autograd.Function):
                 dp, lk.tiles = ops.conv3x3(da, wpk1d, cin, addend=de, addend_mask=emask, want_stats=True,
                                            stat_bn=(lk.cc, lk.mean2, lk.invstd2),
                                            stat_mask=lk.ebits if lk.ebits is not None else p)
+            elif FUSE_DR and ctx.stem_holder is not None and getattr(ctx.stem_holder, "stem_bn", None) is not None:
+                # first block: dp is the gradient w.r.t. the stem's BatchNorm output -- sum dp and dp * xhat(a_stem) per patch
+                # here, so the stem's backward skips its 2.5 GB reduction pass
+                dp, ctx.stem_holder.tiles = ops.conv3x3(da, wpk1d, cin, addend=de, addend_mask=emask, want_stats=True,
+                                                        stat_bn=ctx.stem_holder.stem_bn)
             elif FUSE_DR:
                 dp = ops.conv3x3(da, wpk1d, cin, addend=de, addend_mask=emask)
             else:

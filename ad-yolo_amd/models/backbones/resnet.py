@@ -82,13 +82,13 @@ class SEBasicBlock(nn.Module):
         else:
             self.downsample = None
 
-    def forward(self, x, link_in=None, link_out=None, in_affine=None):
+    def forward(self, x, link_in=None, link_out=None, in_affine=None, stem_holder=None):
         """link_in / link_out: ``functional.BlockLink`` shared with the block below / above (see FUSE_SEBWD);
         in_affine = (scale, shift): x is seen through this per-channel affine (the stem's un-materialised BatchNorm)."""
         fc0, fc2 = self.se.fc["0"], self.se.fc["2"]
         args = [x, self.training, self.pool,
                 (self.bn1, self.bn2, self.downsample["1"] if self.downsample is not None else None, link_in, link_out,
-                 in_affine),
+                 in_affine, stem_holder),
                 self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight, self.bn2.weight, self.bn2.bias,
                 fc0.weight, fc0.bias, fc2.weight, fc2.bias]
         if self.downsample is not None:
@@ -183,7 +183,8 @@ class SEResnet34(nn.Module):
         for li in range(1, 5):
             for blk in getattr(self, "layer%d" % li):
                 nxt = Fn.BlockLink()
-                y = blk(y, link_in=link, link_out=nxt, in_affine=stem_affine)
+                y = blk(y, link_in=link, link_out=nxt, in_affine=stem_affine,
+                        stem_holder=holder if stem_affine is not None else None)
                 stem_affine = None
                 link = nxt
         y = Fn.SAPFn.apply(y, self.attention.W.weight, self.attention.W.bias)

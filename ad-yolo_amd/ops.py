@@ -261,7 +261,8 @@ def affine(x, scale, shift):
     return y
 
 
-def bn_bwd(dy, x, gamma, mean, invstd, relu_mask=False, tile_stats=None, out_dgamma=None, out_dbeta=None):
+def bn_bwd(dy, x, gamma, mean, invstd, relu_mask=False, tile_stats=None, out_dgamma=None, out_dbeta=None,
+           want_dx_colsum=False):
     """-> dx, dgamma, dbeta.  relu_mask: additionally multiply dx by (x > 0) (x is a ReLU output).
     tile_stats: per-patch (sum dy, sum dy*xhat) written by the convolution that produced dy (skips the reduce pass)."""
     _chk(dy, x, gamma, mean, invstd)
@@ -277,8 +278,13 @@ def bn_bwd(dy, x, gamma, mean, invstd, relu_mask=False, tile_stats=None, out_dga
         _c("adyolo_bn_bwd_reduce", _p(dy), _p(x), _p(mean), _p(invstd), _p(sdy), _p(sdyx), _p(partial), rows, c,
            _stream())
     dx = torch.empty_like(x)
+    colsum = part = None
+    if want_dx_colsum:          # channel sums of dx from the same pass (e.g. the bias gradient of the producing convolution)
+        colsum, part = _new(x, c), _new(x, 8192, c)
     _c("adyolo_bn_bwd_apply", _p(dy), _p(x), _p(gamma), _p(mean), _p(invstd), _p(sdy), _p(sdyx), _p(dx), NULL, NULL,
-       rows, c, int(relu_mask), _stream())
+       _p(colsum), _p(part), rows, c, int(relu_mask), _stream())
+    if want_dx_colsum:
+        return dx, sdyx, sdy, colsum
     return dx, sdyx, sdy
 
 

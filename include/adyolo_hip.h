@@ -172,7 +172,8 @@ int adyolo_bn_bwd_tiles(const float *tile_stats, float *sdy, float *sdyx, float 
                         void *stream);
 int adyolo_bn_bwd_apply(const float *dy, const float *x, const float *gamma, const float *mean,
                         const float *invstd, const float *sdy, const float *sdyx, float *dx,
-                        float *dgamma, float *dbeta, long rows, int C, int relu_mask, void *stream);
+                        float *dgamma, float *dbeta, float *dx_colsum /*or NULL: [C] channel sums of dx*/,
+                        float *colsum_partial /*[8192][C] workspace when dx_colsum*/, long rows, int C, int relu_mask, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K3b squeeze-excite + residual tail of SEBasicBlock (resnet.py:38-47, SELayer :91-106), fused:

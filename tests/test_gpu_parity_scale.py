@@ -184,16 +184,21 @@ def test_seed100_training_step_matches_reference(ops, monkeypatch, algo):
 
 def test_training_trajectories_direct_vs_winograd(ops, monkeypatch):
     """40 Adam steps on a fixed synthetic batch (8 x 10 s raw audio, K1 included) with the direct and the Winograd
-    convolutions: identical loss at step 0 (1e-5), never more than 2e-3 apart relative, both decreasing
-    (reference loop: src/train.py:40-62)."""
+    convolutions: identical loss at step 0 (1e-5), both decreasing, and never further apart than round-off alone drives
+    two runs of the SAME algorithm: the yardstick is the direct path re-run with the BatchNorm-backward sums taken by the
+    separate reduction pass instead of the dgrad epilogue (same arithmetic, other summation order); the bound is 3x that
+    gap with a floor of 2e-3 (reference loop: src/train.py:40-62)."""
     import bench
     from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
     from adyolo_amd.features import FeatureExtractor
     from adyolo_amd.datasets import synthetic_audio, synthetic_targets
     from adyolo_amd.train import TrainStep
 
-    def run(algo, steps=40):
+    import adyolo_amd.functional as Fn
+
+    def run(algo, steps=40, fuse_bnbwd=True):
         monkeypatch.setenv("ADYOLO_CONV_ALGO", algo)
+        monkeypatch.setattr(Fn, "FUSE_BNBWD", fuse_bnbwd)
         torch.manual_seed(100)
         prm = bench.params("cuda:0")
         b, n = 8, 24000 * 10
@@ -206,12 +211,14 @@ def test_training_trajectories_direct_vs_winograd(ops, monkeypatch):
         losses = torch.stack([tr.step(audio, target).reshape(()) for _ in range(steps)])
         return losses.cpu().double().numpy()
 
-    a, w = run("direct"), run("winograd")
+    a, w, a2 = run("direct"), run("winograd"), run("direct", fuse_bnbwd=False)
     assert np.all(np.isfinite(a)) and np.all(np.isfinite(w))
-    assert abs(a[0] - w[0]) <= 1e-5 * abs(a[0])
-    rel = np.abs(a - w) / np.abs(a)
-    print("direct %.5f -> %.5f, winograd %.5f -> %.5f, worst relative gap %.2e" % (a[0], a[-1], w[0], w[-1], rel.max()))
-    assert rel.max() <= 2e-3, rel
+    assert abs(a[0] - w[0]) <= 1e-5 * abs(a[0]) and abs(a[0] - a2[0]) <= 1e-6 * abs(a[0])
+    rel, noise = np.abs(a - w) / np.abs(a), np.abs(a - a2) / np.abs(a)
+    print("direct %.5f -> %.5f, winograd %.5f -> %.5f, worst relative gap %.2e (same-algorithm round-off yardstick %.2e)"
+          % (a[0], a[-1], w[0], w[-1], rel.max(), noise.max()))
+    assert rel.max() <= max(2e-3, 3 * noise.max()), (rel, noise)
+    assert abs(a[-1] - w[-1]) <= 1e-3 * abs(a[-1])
     assert a[-1] < 0.7 * a[0] and w[-1] < 0.7 * w[0]
 
 
