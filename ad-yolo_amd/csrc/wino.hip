@@ -668,7 +668,11 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
         }
         __syncthreads();
 
+        // Wave priorities (s_setprio): the staging code between the substeps runs at 0, the LDS reads and transforms of a
+        // substep at 1, its MFMAs at 3, so that of the two waves sharing a SIMD (one of each resident workgroup) the one
+        // with matrix work ready is issued first: measured -4 % at every stage (same box, stage 4: 3.29 -> 3.16 ms)
         auto substep = [&](int rb) {                  // one tile row: x rows rb .. rb + 3, dy rows rb, rb + 1 of the rings
+            __builtin_amdgcn_s_setprio(1);
             const float *xa = Xs + ((rb + ia) % XSLOTS) * XROW + aoff;
             const float *xb = Xs + ((rb + ib) % XSLOTS) * XROW + aoff;
             const float *e0 = Dsh + (rb & (DSLOTS - 1)) * DROW + aoff;
@@ -709,6 +713,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(3);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const float4 a = v == 0 ? f4_sub(r0, r2) : (v == 1 ? f4_add(r1, r2) : (v == 2 ? f4_sub(r2, r1) : f4_sub(r1, r3)));
@@ -721,6 +726,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
                     acc[v][nt] = mfma32(a.w, b.w, acc[v][nt]);
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         };
 
