@@ -70,6 +70,7 @@ SIGNATURES = {
     "adyolo_act_bwd": (I, [P, P, P, L, I, I, P]),
     "adyolo_seddoa_loss": (I, [P] * 5 + [L, I, I, I, F, F, P]),
     "adyolo_adpit_loss": (I, [P] * 5 + [L, I, P]),
+    "adyolo_conv_gemm": (I, [P, P, P, P] + [I] * 13 + [P]),
     "adyolo_im2col": (I, [P, P] + [I] * 10 + [P]),
     "adyolo_col2im": (I, [P, P] + [I] * 10 + [P]),
     "adyolo_pack_wk": (I, [P, P, I, I, I, I, I, P]),

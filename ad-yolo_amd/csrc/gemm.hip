@@ -17,11 +17,22 @@ struct GemmBatch {
     float alpha;
 };
 
-template <bool TA, bool TB>
+// Implicit convolution operand (no im2col buffer): one GEMM operand is gathered from a channels-last tensor
+// src [n][Hs][Ws][Cs] while it is staged.  The GEMM index that runs over pixels ((n, y, x) of an [n][Hm][Wm] grid) is m
+// for G == 1 (k-major A: forward and data-gradient) and k for G == 2 (transposed B: weight-gradient); the other index of
+// that operand is (kh, kw, c) = ((kh * KW + kw) * Cs + c).  dgrad == 0: source pixel (y*SH - PH + kh, x*SW - PW + kw);
+// dgrad == 1 (transposed convolution): ((y + PH - kh) / SH, (x + PW - kw) / SW) where both divisions are exact.
+struct ConvGather {
+    int Hs, Ws, Cs, Hm, Wm, KH, KW, SH, SW, PH, PW, dgrad, kreal;
+};
+
+template <bool TA, bool TB, int G = 0>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                       const float *__restrict__ bias, float *__restrict__ C,
                                                       int M, int N, int K, int lda, int ldb, int ldc, int klen,
-                                                      size_t slab_stride, int slab_ld, int accumulate, GemmBatch bt) {
+                                                      size_t slab_stride, int slab_ld, int accumulate, GemmBatch bt,
+                                                      ConvGather cg) {
+    static_assert(G == 0 || (G == 1 && !TA) || (G == 2 && TB), "gathered operand: k-major A or transposed B");
     constexpr int A_LD = TA ? (GBM + 4) : (GBK + 4);
     constexpr int B_LD = TB ? (GBN + 4) : (GBK + 4);
     __shared__ __attribute__((aligned(16))) float As[TA ? GBK * (GBM + 4) : GBM * (GBK + 4)];
@@ -46,10 +57,60 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
+    // gathered A (G == 1): the pixel of each of this thread's four rows is fixed over the K loop
+    int gy[4] = {0, 0, 0, 0}, gx[4] = {0, 0, 0, 0}, gb[4] = {-1, -1, -1, -1};
+    if (G == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + ((tid + i * 256) >> 3);
+            if (m < M) {
+                const int x_ = m % cg.Wm, t_ = m / cg.Wm;
+                const int y_ = t_ % cg.Hm, n_ = t_ / cg.Hm;
+                gy[i] = cg.dgrad ? y_ + cg.PH : y_ * cg.SH - cg.PH;
+                gx[i] = cg.dgrad ? x_ + cg.PW : x_ * cg.SW - cg.PW;
+                gb[i] = n_ * cg.Hs * cg.Ws;
+            }
+        }
+    }
+    // gathered B (G == 2): the (kh, kw, c) of this thread's columns is fixed over the K loop
+    int bkh = 0, bkw = 0, bc = -1;
+    if (G == 2) {
+        const int nn = n0 + (tid & 15) * 4;
+        if (nn < cg.kreal) {
+            const int tap = nn / cg.Cs;
+            bc = nn - tap * cg.Cs;
+            bkh = tap / cg.KW;
+            bkw = tap - bkh * cg.KW;
+        }
+    }
+
     // software pipeline: the next K tile is fetched into registers while the current one feeds the matrix cores
     float4 ra[4], rb[2];
     auto fetch = [&](int k0) {
-        if (!TA) {
+        if (G == 1) {
+            const int k = k0 + (tid & 7) * 4;
+            const int tap = k / cg.Cs, c = k - tap * cg.Cs;
+            const int kh = tap / cg.KW, kw = tap - kh * cg.KW;
+            const bool kok = k < kend && k < cg.kreal;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int sy, sx;
+                bool ok = kok && gb[i] >= 0;
+                if (cg.dgrad) {
+                    const int ty = gy[i] - kh, tx = gx[i] - kw;
+                    sy = ty / cg.SH;
+                    sx = tx / cg.SW;
+                    ok = ok && ty >= 0 && tx >= 0 && sy * cg.SH == ty && sx * cg.SW == tx;
+                } else {
+                    sy = gy[i] + kh;
+                    sx = gx[i] + kw;
+                    ok = ok && sy >= 0 && sx >= 0;
+                }
+                ok = ok && sy < cg.Hs && sx < cg.Ws;
+                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) ra[i] = *reinterpret_cast<const float4 *>(A + ((size_t)(gb[i] + sy * cg.Ws + sx) * cg.Cs + c));
+            }
+        } else if (!TA) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int idx = tid + i * 256;
@@ -68,7 +129,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ 
                 if (k < kend && m < M) ra[i] = *reinterpret_cast<const float4 *>(A + (size_t)k * lda + m);
             }
         }
-        if (!TB) {
+        if (G == 2) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int k = k0 + ((tid + i * 256) >> 4);
+                const int x_ = k % cg.Wm, t_ = k / cg.Wm;
+                const int y_ = t_ % cg.Hm, n_ = t_ / cg.Hm;
+                const int sy = y_ * cg.SH - cg.PH + bkh, sx = x_ * cg.SW - cg.PW + bkw;
+                rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < kend && bc >= 0 && sy >= 0 && sy < cg.Hs && sx >= 0 && sx < cg.Ws)
+                    rb[i] = *reinterpret_cast<const float4 *>(B + ((size_t)((n_ * cg.Hs + sy) * cg.Ws + sx) * cg.Cs + bc));
+            }
+        } else if (!TB) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int idx = tid + i * 256;
@@ -246,9 +318,10 @@ extern "C" int adyolo_gemm(const float *A, const float *B, const float *bias, fl
     const size_t slab_stride = splits > 1 ? (size_t)M * N : 0;
     float *out = splits > 1 ? slabs : C;
     GemmBatch bt{0, 0, 0, 0, 0, 0, 0, 1.0f};
+    ConvGather cg{};
 #define LAUNCH(TA_, TB_)                                                                                       \
     hipLaunchKernelGGL((gemm_kernel<TA_, TB_>), grid, dim3(256), 0, st, A, B, bias, out, M, N, K, lda, ldb, ldc, \
-                       klen, slab_stride, N, accumulate, bt)
+                       klen, slab_stride, N, accumulate, bt, cg)
     if (transA && transB) LAUNCH(true, true);
     else if (transA) LAUNCH(true, false);
     else if (transB) LAUNCH(false, true);
@@ -278,15 +351,70 @@ extern "C" int adyolo_gemm_batched(const float *A, const float *B, float *C, int
     GemmBatch bt{inner, oA, iA, oB, iB, oC, iC, alpha};
     const float *bias = nullptr;
     const size_t slab_stride = 0;
+    ConvGather cg{};
 #define LAUNCHB(TA_, TB_)                                                                                     \
     hipLaunchKernelGGL((gemm_kernel<TA_, TB_>), grid, dim3(256), 0, st, A, B, bias, C, M, N, K, lda, ldb, ldc, \
-                       klen, slab_stride, N, accumulate, bt)
+                       klen, slab_stride, N, accumulate, bt, cg)
     if (transA && transB) LAUNCHB(true, true);
     else if (transA) LAUNCHB(true, false);
     else if (transB) LAUNCHB(false, true);
     else LAUNCHB(false, false);
 #undef LAUNCHB
     return check_launch("gemm_batched");
+}
+
+// General strided convolution on channels-last tensors as an implicit GEMM (no column buffer).
+//   mode 0 (forward):        out y  [N*Ho*Wo][Cout] = gather(x)  . wk^T      src = x [N][H][W][Cin],    other = wk  [Cout][Kp]
+//   mode 1 (data-gradient):  out dx [N*H*W][Cin]    = gather(dy) . wkT^T     src = dy [N][Ho][Wo][Cout], other = wkT [Cin][Kq]
+//   mode 2 (weight-gradient):out dwk[Cout][Kp]      = dy^T . gather(x)       src = x,                    other = dy
+// with Kp = roundup4(KH*KW*Cin), k = (kh*KW + kw)*Cin + ci and Kq = roundup4(KH*KW*Cout), k = (kh*KW + kw)*Cout + co.
+extern "C" int adyolo_conv_gemm(const float *src, const float *other, float *out, float *slabs, int mode, int N, int H,
+                                int W, int Cin, int Cout, int KH, int KW, int SH, int SW, int PH, int PW, int splits,
+                                void *stream) {
+    ADYOLO_REQUIRE(src && other && out && N > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && SH > 0 && SW > 0 && PH >= 0 &&
+                       PW >= 0 && mode >= 0 && mode <= 2,
+                   ADYOLO_EINVAL, "conv_gemm: bad arguments");
+    ADYOLO_REQUIRE(Cin > 0 && Cout > 0 && Cin % 4 == 0 && Cout % 4 == 0, ADYOLO_ENOSUP,
+                   "conv_gemm: Cin=%d and Cout=%d must be multiples of 4", Cin, Cout);
+    const int Ho = (H + 2 * PH - KH) / SH + 1, Wo = (W + 2 * PW - KW) / SW + 1;
+    ADYOLO_REQUIRE(Ho > 0 && Wo > 0, ADYOLO_EINVAL, "conv_gemm: empty output");
+    ADYOLO_REQUIRE((size_t)N * H * W * Cin < ((size_t)1 << 31) && (size_t)N * Ho * Wo * Cout < ((size_t)1 << 31), ADYOLO_ENOSUP,
+                   "conv_gemm: tensors must stay below 2^31 elements");
+    hipStream_t st = as_stream(stream);
+    const int Kp = cdiv(KH * KW * Cin, 4) * 4, Kq = cdiv(KH * KW * Cout, 4) * 4;
+    GemmBatch bt{0, 0, 0, 0, 0, 0, 0, 1.0f};
+    const float *bias = nullptr;
+    int M, Nn, K;
+    ConvGather cg;
+    if (mode == 0) {
+        M = N * Ho * Wo, Nn = Cout, K = Kp;
+        cg = ConvGather{H, W, Cin, Ho, Wo, KH, KW, SH, SW, PH, PW, 0, KH * KW * Cin};
+    } else if (mode == 1) {
+        M = N * H * W, Nn = Cin, K = Kq;
+        cg = ConvGather{Ho, Wo, Cout, H, W, KH, KW, SH, SW, PH, PW, 1, KH * KW * Cout};
+    } else {
+        M = Cout, Nn = Kp, K = N * Ho * Wo;
+        cg = ConvGather{H, W, Cin, Ho, Wo, KH, KW, SH, SW, PH, PW, 0, KH * KW * Cin};
+    }
+    if (mode != 2 || splits < 1) splits = mode == 2 ? (splits < 1 ? 1 : splits) : 1;
+    ADYOLO_REQUIRE(splits == 1 || slabs, ADYOLO_EINVAL, "conv_gemm: splits > 1 needs a slab workspace");
+    const int klen = cdiv(cdiv(K, splits), GBK) * GBK;
+    splits = cdiv(K, klen);
+    dim3 grid((unsigned)cdiv(Nn, GBN), (unsigned)cdiv(M, GBM), (unsigned)splits);
+    const size_t slab_stride = splits > 1 ? (size_t)M * Nn : 0;
+    float *dst = splits > 1 ? slabs : out;
+    if (mode == 2)
+        hipLaunchKernelGGL((gemm_kernel<true, true, 2>), grid, dim3(256), 0, st, other, src, bias, dst, M, Nn, K, Cout, 0,
+                           Nn, klen, slab_stride, Nn, 0, bt, cg);
+    else
+        hipLaunchKernelGGL((gemm_kernel<false, false, 1>), grid, dim3(256), 0, st, src, other, bias, dst, M, Nn, K, 0,
+                           mode == 0 ? Kp : Kq, Nn, klen, slab_stride, Nn, 0, bt, cg);
+    int rc = check_launch("conv_gemm");
+    if (rc || splits == 1) return rc;
+    const size_t total = (size_t)M * Nn;
+    hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3(cdiv((long)total, 256)), dim3(256), 0, st, slabs, bias, out, M, Nn,
+                       Nn, splits, 0);
+    return check_launch("conv_gemm_reduce");
 }
 
 extern "C" int adyolo_colsum(const float *A, float *out, float *partial, int R, int C, int lda, int accumulate,

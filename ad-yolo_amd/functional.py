@@ -531,39 +531,28 @@ class _FusedLossFn(torch.autograd.Function):
 
 # ============================================================================================== conformer nodes
 class ConvFn(torch.autograd.Function):
-    """General strided convolution (channels-last) = im2col + fp32-MFMA GEMM.  x [N][H][W][Cin], w [Cout][Cin][KH][KW]
-    (reference resnet_conformer.py:347 7x7 s(1,2); torchvision BasicBlock 3x3 / 1x1 s(1,2) at :353-393).
-    The column matrix is recomputed in backward instead of being kept alive."""
+    """General strided convolution (channels-last) as an implicit GEMM on the fp32 MFMA: the column matrix is never built,
+    the GEMM gathers its operand from the activation tensor while staging it (``adyolo_conv_gemm``).
+    x [N][H][W][Cin], w [Cout][Cin][KH][KW]  (reference resnet_conformer.py:347 7x7 s(1,2); torchvision BasicBlock
+    3x3 / 1x1 s(1,2) at :353-393)."""
 
     @staticmethod
     def forward(ctx, x, w, stride, padding):
-        kh, kw = w.shape[2], w.shape[3]
-        col, ho, wo = ops.im2col(x, kh, kw, stride[0], stride[1], padding[0], padding[1])
-        wk = ops.pack_wk(w)
-        kp = wk.shape[1]
-        y = ops.gemm(col, wk, col.shape[0], w.shape[0], kp, kp, kp)
-        ctx.geom = (kh, kw, stride, padding)
+        n, h, ww, cin = x.shape
+        cout, _, kh, kw = w.shape
+        ctx.geom = (n, h, ww, cin, cout, kh, kw, stride[0], stride[1], padding[0], padding[1])
         ctx.save_for_backward(x, w)
-        return y.view(x.shape[0], ho, wo, w.shape[0])
+        return ops.conv_gemm(0, x, ops.pack_wk(w), *ctx.geom)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        kh, kw, stride, padding = ctx.geom
-        n, h, ww, cin = x.shape
-        cout = w.shape[0]
-        dy2 = _c(dy).view(-1, cout)
-        rows = dy2.shape[0]
-        col, _, _ = ops.im2col(x, kh, kw, stride[0], stride[1], padding[0], padding[1])
-        kp = col.shape[1]
-        dwk = ops.gemm(dy2, col, cout, kp, rows, cout, kp, trans_a=True, trans_b=True,
-                       splits=ops.wgrad_splits(cout, kp, rows))
-        dw = ops.unpack_wk(dwk, cout, cin, kh, kw)
+        n, h, ww, cin, cout, kh, kw = ctx.geom[:7]
+        dy = _c(dy)
+        dw = ops.unpack_wk(ops.conv_gemm(2, x, dy, *ctx.geom), cout, cin, kh, kw)
         dx = None
         if ctx.needs_input_grad[0]:
-            wk = ops.pack_wk(w)
-            dcol = ops.gemm(dy2, wk, rows, kp, cout, cout, kp, trans_b=True)
-            dx = ops.col2im(dcol, n, h, ww, cin, kh, kw, stride[0], stride[1], padding[0], padding[1])
+            dx = ops.conv_gemm(1, dy, ops.pack_wk(w.transpose(0, 1).contiguous()), *ctx.geom)
         return dx, dw, None, None
 
 

@@ -543,6 +543,29 @@ def col2im(dcol, n, h, w, c, kh, kw, sh, sw, ph, pw):
     return dx
 
 
+def conv_gemm(mode, src, other, n, h, w, cin, cout, kh, kw, sh, sw, ph, pw):
+    """General strided convolution as an implicit GEMM (no column buffer), channels-last.
+    mode 0: src x [N][H][W][Cin], other wk = pack_wk(w) -> y [N][Ho][Wo][Cout]
+    mode 1: src dy [N][Ho][Wo][Cout], other wkT = pack_wk(w.transpose(0, 1)) -> dx [N][H][W][Cin]
+    mode 2: src x, other dy -> dwk [Cout][Kp] (split-K over the output pixels, summed in a fixed order)."""
+    _chk(src, other)
+    ho, wo = conv_out_hw(h, w, kh, kw, sh, sw, ph, pw)
+    splits, slabs = 1, None
+    if mode == 0:
+        out = _new(src, n, ho, wo, cout)
+    elif mode == 1:
+        out = _new(src, n, h, w, cin)
+    else:
+        kp = _kp(kh, kw, cin)
+        out = _new(src, cout, kp)
+        splits = wgrad_splits(cout, kp, n * ho * wo)
+        if splits > 1:
+            slabs = _new(src, splits, cout, kp)
+    _c("adyolo_conv_gemm", _p(src), _p(other), _p(out), _p(slabs), mode, n, h, w, cin, cout, kh, kw, sh, sw, ph, pw, splits,
+       _stream())
+    return out
+
+
 def pack_wk(w):
     """w [Cout][Cin][KH][KW] -> [Cout][Kp] with k = (kh*KW+kw)*Cin + ci."""
     _chk(w)

@@ -310,6 +310,16 @@ int adyolo_pcm16_to_f32(const int16_t *pcm, float *out, long n, void *stream);
 int adyolo_mask_ranges(float *feat, const int32_t *ranges, int B, int T, int F, int C, void *stream);
 int adyolo_colstats(const float *a, float *partial, double *out, long rows, int cols, void *stream);
 
+/* General strided convolution (channels-last) as an implicit GEMM on the fp32 MFMA, no column buffer (replaces nn.Conv2d
+ * 7x7 s(1,2) at reference resnet_conformer.py:347 and torchvision BasicBlock's 3x3 / 1x1 s(1,2) at :353-393; forward,
+ * data-gradient and weight-gradient).  Cin, Cout multiples of 4.  Kp = roundup4(KH*KW*Cin), Kq = roundup4(KH*KW*Cout).
+ *   mode 0: src = x [N][H][W][Cin],     other = wk  [Cout][Kp] (k = (kh*KW+kw)*Cin + ci),  out = y  [N][Ho][Wo][Cout]
+ *   mode 1: src = dy [N][Ho][Wo][Cout], other = wkT [Cin][Kq]  (k = (kh*KW+kw)*Cout + co), out = dx [N][H][W][Cin]
+ *   mode 2: src = x,                    other = dy,                                         out = dwk [Cout][Kp]
+ * splits (mode 2 only): split-K over the N*Ho*Wo output pixels, slabs = [splits][Cout][Kp] workspace (deterministic sum). */
+int adyolo_conv_gemm(const float *src, const float *other, float *out, float *slabs, int mode, int N, int H, int W,
+                     int Cin, int Cout, int KH, int KW, int SH, int SW, int PH, int PW, int splits, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K9  ResNet-Conformer encoder pieces (src/models/backbones/resnet_conformer.py), channels-last fp32
  *   im2col / col2im / pack_wk : general strided convolution = im2col + adyolo_gemm; rows of `col` / `wk` are

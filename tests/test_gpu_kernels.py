@@ -579,13 +579,18 @@ def test_wrapper_model_matches_reference_golden(ops, monkeypatch, algo):
 
 
 def test_conformer_pieces_match_torch(ops):
-    """im2col convolution (7x7 s(1,2), 3x3 s(1,2), 1x1 s(1,2)), max-pool, attention core, conv module pieces."""
+    """implicit-GEMM convolution (7x7 s(1,2), 3x3 s(1,2), 1x1 s(1,2), the narrow stride-1 maps of the deep stages, a
+    stride-(2,2) case with odd sizes for the transposed gather), max-pool, attention core, conv module pieces."""
     from adyolo_amd import functional as Fn
     g = torch.Generator().manual_seed(61)
     for (cin, cout, k, stride, pad, h, w) in [(8, 64, 7, (1, 2), (3, 3), 12, 64), (64, 128, 3, (1, 2), (1, 1), 10, 16),
-                                              (128, 256, 1, (1, 2), (0, 0), 9, 8), (256, 512, 3, (1, 2), (1, 1), 6, 2)]:
+                                              (128, 256, 1, (1, 2), (0, 0), 9, 8), (256, 512, 3, (1, 2), (1, 1), 6, 2),
+                                              (256, 256, 3, (1, 1), (1, 1), 37, 2), (512, 512, (3, 1), (1, 1), (1, 0), 70, 1),
+                                              (128, 128, 3, (1, 1), (1, 1), 33, 4), (12, 20, 3, (2, 2), (1, 1), 9, 7),
+                                              (16, 36, (5, 3), (2, 1), (2, 0), 11, 5)]:
+        kh_, kw_ = (k, k) if isinstance(k, int) else k
         x = torch.randn(2, cin, h, w, generator=g)
-        wt = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+        wt = torch.randn(cout, cin, kh_, kw_, generator=g) / np.sqrt(cin * kh_ * kw_)
         xo, wo = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
         yo = F.conv2d(xo, wo, None, stride=stride, padding=pad)
         probe = torch.randn_like(yo)
@@ -593,9 +598,9 @@ def test_conformer_pieces_match_torch(ops):
         xg, wg = dev(nhwc(x)).requires_grad_(True), dev(wt).requires_grad_(True)
         yg = Fn.ConvFn.apply(xg, wg, stride, pad)
         (yg * dev(nhwc(probe))).sum().backward()
-        assert_close(nchw(yg), yo, 3e-5, "strided conv fwd k=%d" % k)
-        assert_close(nchw(xg.grad), xo.grad, 3e-5, "strided conv dx k=%d" % k)
-        assert_close(wg.grad, wo.grad, 3e-5, "strided conv dw k=%d" % k)
+        assert_close(nchw(yg), yo, 3e-5, "strided conv fwd k=%s" % (k,))
+        assert_close(nchw(xg.grad), xo.grad, 3e-5, "strided conv dx k=%s" % (k,))
+        assert_close(wg.grad, wo.grad, 3e-5, "strided conv dw k=%s" % (k,))
     # max-pool 3x3 s(1,2) p1
     x = torch.randn(2, 64, 9, 32, generator=g)
     xo = x.clone().requires_grad_(True)

@@ -8,7 +8,12 @@ SHAPES = [("head fwd", 38400, 2400, 256, False, False, 1), ("gru proj", 38400, 7
           ("head dX", 38400, 256, 2400, False, True, 1), ("head dW", 2400, 256, 38400, True, True, 9),
           ("down1x1 s2", 2457600, 64, 32, False, False, 1), ("down1x1 s4", 614400, 256, 128, False, False, 1),
           ("down dW s4", 256, 128, 614400, True, True, 64), ("ffn conformer", 6400, 2048, 512, False, False, 1),
-          ("ffn dW", 2048, 512, 6400, True, True, 1), ("attn proj", 6400, 512, 512, False, False, 1)]
+          ("ffn dW", 2048, 512, 6400, True, True, 1), ("attn proj", 6400, 512, 512, False, False, 1),
+          # ResNet-Conformer (config 4, B = 32 x 20 s: 25600 rows, d_model 256, FFN 1024)
+          ("c4 ffn1", 25600, 1024, 256, False, False, 1), ("c4 ffn2", 25600, 256, 1024, False, False, 1),
+          ("c4 ffn1 dX", 25600, 256, 1024, False, True, 1), ("c4 ffn2 dX", 25600, 1024, 256, False, True, 1),
+          ("c4 ffn1 dW", 1024, 256, 25600, True, True, 16), ("c4 ffn2 dW", 256, 1024, 25600, True, True, 16),
+          ("c4 proj", 25600, 256, 256, False, False, 1), ("c4 proj dW", 256, 256, 25600, True, True, 50)]
 for name, m, n, k, ta, tb, splits in SHAPES:
     a = torch.randn((k, m) if ta else (m, k), device="cuda:0")
     b = torch.randn((k, n) if tb else (n, k), device="cuda:0")
