@@ -8,8 +8,8 @@ Same constructor ``(in_feat_shape, out_shape, params)``, ``enc_out_dim`` attribu
 and the same 549 ``state_dict`` keys.  Quirks kept: ReLU *before* BatchNorm after the 7x7 stem (:423-425), layer3 has 5
 blocks (:373-384), ``PoolingModule.max_pool`` is an average pool (:289) so pooling is 2 x avg, attention ``mask`` path dead.
 
-This is the correctness-first version of the row: strided convolutions run as im2col + the fp32-MFMA GEMM, stride-1 3x3
-convolutions on the implicit-GEMM / Winograd kernels; attention is the flash-style fp32-MFMA kernel of csrc/attention.hip
+Strided convolutions (and the stride-1 ones on maps narrower than 8 bins) run on the implicit-GEMM convolution
+(``adyolo_conv_gemm``: no column buffer), the other stride-1 3x3 convolutions on the Winograd kernels; attention is the flash-style fp32-MFMA kernel of csrc/attention.hip
 (scores never written to HBM).
 """
 import math
@@ -31,13 +31,23 @@ def _dropout(x, p, training, rng):
 
 def _conv3x3_s1(x, w):
     """Stride-1 3x3 convolution.  Winograd kernels on wide maps; the deep stages of this ResNet have strided the
-    frequency axis down to 2 and 1 bins, where an 8 x 16-pixel Winograd patch would be 87-94 % padding, so those run as
-    im2col + GEMM.  For W == 1 only the centre kernel column ever meets data (the other two see zero padding), so the
-    convolution IS the 3 x 1 one on w[:, :, :, 1:2]; the outer taps get exactly zero gradient, as in the reference."""
-    wd = x.shape[2]
+    frequency axis down to 4, 2 and 1 bins, where an 8 x 16-pixel Winograd patch would be 75-94 % padding, so those run on
+    the implicit-GEMM convolution, without the taps that only ever meet the zero padding:
+    W == 1: only the centre kernel column meets data, the convolution IS the 3 x 1 one on w[:, :, :, 1:2];
+    W == 2: every (input bin, output bin) pair is within one tap, so the two bins fold into the channel axis
+            (free views [N][H][1][2 C]) and the convolution IS a 3 x 1 one with the 2 Cout x 2 Cin block filter
+            w2[wo*Cout + co][wi*Cin + ci][kh] = w[co][ci][kh][wi - wo + 1]  -- 2/3 of the multiplies of the padded form.
+    The filter rearrangements are differentiable torch views / copies of the (tiny) weight, so the untouched taps get
+    exactly zero gradient, as in the reference."""
+    n, h, wd, cin = x.shape
     if wd == 1:
         return Fn.ConvFn.apply(x, w[:, :, :, 1:2].contiguous(), (1, 1), (1, 0))
     if wd == 2:
+        cout = w.shape[0]
+        w2 = torch.stack((w[..., 1:3], w[..., 0:2]), 0)                     # [wo][co][ci][kh][wi]
+        w2 = w2.permute(0, 1, 4, 2, 3).reshape(2 * cout, 2 * cin, 3, 1)
+        return Fn.ConvFn.apply(x.view(n, h, 1, 2 * cin), w2, (1, 1), (1, 0)).view(n, h, 2, cout)
+    if wd <= 4:
         return Fn.ConvFn.apply(x, w, (1, 1), (1, 1))
     return Fn.Conv3x3S1Fn.apply(x, w)
 

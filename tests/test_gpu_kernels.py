@@ -601,6 +601,24 @@ def test_conformer_pieces_match_torch(ops):
         assert_close(nchw(yg), yo, 3e-5, "strided conv fwd k=%s" % (k,))
         assert_close(nchw(xg.grad), xo.grad, 3e-5, "strided conv dx k=%s" % (k,))
         assert_close(wg.grad, wo.grad, 3e-5, "strided conv dw k=%s" % (k,))
+    # the stride-1 3x3 router of the deep, narrow stages (W = 4: implicit GEMM, W = 2: bins folded into channels,
+    # W = 1: centre column only) against conv2d, including the exactly-zero gradient of the taps that only see padding
+    from adyolo_amd.models.backbones.resnet_conformer import _conv3x3_s1
+    for (c, h, w) in [(128, 21, 4), (64, 19, 2), (96, 17, 1), (64, 16, 16)]:
+        x = torch.randn(2, c, h, w, generator=g)
+        wt = torch.randn(c, c, 3, 3, generator=g) / np.sqrt(9 * c)
+        xo, wo = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+        yo = F.conv2d(xo, wo, None, padding=1)
+        probe = torch.randn_like(yo)
+        (yo * probe).sum().backward()
+        xg, wg = dev(nhwc(x)).requires_grad_(True), dev(wt).requires_grad_(True)
+        yg = _conv3x3_s1(xg, wg)
+        (yg * dev(nhwc(probe))).sum().backward()
+        assert_close(nchw(yg), yo, 3e-5, "narrow conv fwd W=%d" % w)
+        assert_close(nchw(xg.grad), xo.grad, 3e-5, "narrow conv dx W=%d" % w)
+        assert_close(wg.grad, wo.grad, 3e-5, "narrow conv dw W=%d" % w)
+        if w == 1:
+            assert float(wg.grad[..., 0].abs().max()) == 0.0 and float(wg.grad[..., 2].abs().max()) == 0.0
     # max-pool 3x3 s(1,2) p1
     x = torch.randn(2, 64, 9, 32, generator=g)
     xo = x.clone().requires_grad_(True)
