@@ -193,6 +193,13 @@ __global__ __launch_bounds__(256) void affine_kernel(const float *__restrict__ x
     }
 }
 
+// Streaming kernels of this file (bn_bwd_apply, se_tail_fwd, se_tail_bwd_apply) share one loop shape: a thread owns the
+// float4 index tid + 256 j, so when C/4 divides 256 (INV) its channel quad never changes -- the per-channel operands are
+// loaded once into registers (no 64-bit modulo, no L1 traffic per element) and EW_U independent float4 loads per tensor
+// are in flight before the first use.
+constexpr int EW_U = 4;
+
+template <bool INV>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ gamma,
     const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ sdy,
@@ -203,15 +210,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     // quad is fixed (the grid stride is a multiple of C/4), so it accumulates in registers.
     __shared__ float4 sred[256];
     float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        const int cx = (int)(i % c4n);
-        const float4 d = reinterpret_cast<const float4 *>(dy)[i];
-        const float4 xv = reinterpret_cast<const float4 *>(x)[i];
-        const float4 g = reinterpret_cast<const float4 *>(gamma)[cx];
-        const float4 m = reinterpret_cast<const float4 *>(mean)[cx];
-        const float4 is = reinterpret_cast<const float4 *>(invstd)[cx];
-        const float4 a = reinterpret_cast<const float4 *>(sdy)[cx];
-        const float4 b = reinterpret_cast<const float4 *>(sdyx)[cx];
+    float4 g, m, is, a, b;
+    auto load_params = [&](int cx) {
+        g = reinterpret_cast<const float4 *>(gamma)[cx];
+        m = reinterpret_cast<const float4 *>(mean)[cx];
+        is = reinterpret_cast<const float4 *>(invstd)[cx];
+        a = reinterpret_cast<const float4 *>(sdy)[cx];
+        b = reinterpret_cast<const float4 *>(sdyx)[cx];
+    };
+    auto one = [&](float4 d, float4 xv) {
         float4 o;
         o.x = g.x * is.x * (d.x - a.x * invR - (xv.x - m.x) * is.x * b.x * invR);
         o.y = g.y * is.y * (d.y - a.y * invR - (xv.y - m.y) * is.y * b.y * invR);
@@ -223,8 +230,35 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
             if (!(xv.z > 0.f)) o.z = 0.f;
             if (!(xv.w > 0.f)) o.w = 0.f;
         }
-        reinterpret_cast<float4 *>(dx)[i] = o;
         sacc.x += o.x; sacc.y += o.y; sacc.z += o.z; sacc.w += o.w;
+        return o;
+    };
+    const float4 *dy4 = reinterpret_cast<const float4 *>(dy), *x4 = reinterpret_cast<const float4 *>(x);
+    float4 *dx4 = reinterpret_cast<float4 *>(dx);
+    if (INV) {
+        load_params((int)threadIdx.x % c4n);
+        const long step = (long)gridDim.x * 256 * EW_U;
+        for (long i0 = (long)blockIdx.x * 256 * EW_U + threadIdx.x; i0 < n4; i0 += step) {
+            float4 d[EW_U], xv[EW_U];
+#pragma unroll
+            for (int u = 0; u < EW_U; ++u) {
+                const long i = i0 + u * 256;
+                if (i < n4) {
+                    d[u] = dy4[i];
+                    xv[u] = x4[i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < EW_U; ++u) {
+                const long i = i0 + u * 256;
+                if (i < n4) dx4[i] = one(d[u], xv[u]);
+            }
+        }
+    } else {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+            load_params((int)(i % c4n));
+            dx4[i] = one(dy4[i], x4[i]);
+        }
     }
     if (sum_partial) {          // fixed order: threads with the same channel quad are tid, tid + c4n, ...
         sred[threadIdx.x] = sacc;
@@ -288,6 +322,7 @@ __global__ __launch_bounds__(256) void se_fc_fwd_kernel(
     }
 }
 
+template <bool INV>
 __global__ __launch_bounds__(256) void se_tail_fwd_kernel(
     const float *__restrict__ c, const float *__restrict__ r, const float *__restrict__ scale,
     const float *__restrict__ shift, const float *__restrict__ s, const float *__restrict__ r_scale,
@@ -295,28 +330,56 @@ __global__ __launch_bounds__(256) void se_tail_fwd_kernel(
     // grid (blocks, N): hw4 = HW * C/4 float4 per sample; mask (optional, needs hw4 % 64 == 0): bits of (e > 0)
     const int n = blockIdx.y;
     const size_t base = (size_t)n * hw4;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw4; i += (long)gridDim.x * blockDim.x) {
-        const int cx = (int)(i % c4n);
-        const float4 cv = reinterpret_cast<const float4 *>(c)[base + i];
-        float4 rv = reinterpret_cast<const float4 *>(r)[base + i];
+    const float4 *c4 = reinterpret_cast<const float4 *>(c) + base, *r4 = reinterpret_cast<const float4 *>(r) + base;
+    float4 *e4 = reinterpret_cast<float4 *>(e) + base;
+    float4 sc, sh, sv, rs = make_float4(1.f, 1.f, 1.f, 1.f), rt = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_params = [&](int cx) {
+        sc = reinterpret_cast<const float4 *>(scale)[cx];
+        sh = reinterpret_cast<const float4 *>(shift)[cx];
+        sv = reinterpret_cast<const float4 *>(s)[(size_t)n * c4n + cx];
         if (r_scale) {           // the shortcut's own BatchNorm affine (downsample branch) applied on the fly
-            const float4 rs = reinterpret_cast<const float4 *>(r_scale)[cx], rt = reinterpret_cast<const float4 *>(r_shift)[cx];
-            rv = make_float4(fmaf(rv.x, rs.x, rt.x), fmaf(rv.y, rs.y, rt.y), fmaf(rv.z, rs.z, rt.z), fmaf(rv.w, rs.w, rt.w));
+            rs = reinterpret_cast<const float4 *>(r_scale)[cx];
+            rt = reinterpret_cast<const float4 *>(r_shift)[cx];
         }
-        const float4 sc = reinterpret_cast<const float4 *>(scale)[cx];
-        const float4 sh = reinterpret_cast<const float4 *>(shift)[cx];
-        const float4 sv = reinterpret_cast<const float4 *>(s)[(size_t)n * c4n + cx];
+    };
+    auto one = [&](long i, float4 cv, float4 rv) {
+        if (r_scale) rv = make_float4(fmaf(rv.x, rs.x, rt.x), fmaf(rv.y, rs.y, rt.y), fmaf(rv.z, rs.z, rt.z), fmaf(rv.w, rs.w, rt.w));
         float4 o;
         o.x = fmaxf((cv.x * sc.x + sh.x) * sv.x + rv.x, 0.f);
         o.y = fmaxf((cv.y * sc.y + sh.y) * sv.y + rv.y, 0.f);
         o.z = fmaxf((cv.z * sc.z + sh.z) * sv.z + rv.z, 0.f);
         o.w = fmaxf((cv.w * sc.w + sh.w) * sv.w + rv.w, 0.f);
-        reinterpret_cast<float4 *>(e)[base + i] = o;
+        e4[i] = o;
         if (mask) {      // the whole wave is here: i runs over 64-aligned groups of 64 and hw4 % 64 == 0
             const unsigned long long bx = __ballot(o.x > 0.f), by = __ballot(o.y > 0.f);
             const unsigned long long bz = __ballot(o.z > 0.f), bw = __ballot(o.w > 0.f);
             const int lane = threadIdx.x & 63;
             if (lane < 4) mask[((base + i) >> 6) * 4 + lane] = lane == 0 ? bx : (lane == 1 ? by : (lane == 2 ? bz : bw));
+        }
+    };
+    if (INV) {
+        load_params((int)threadIdx.x % c4n);
+        const long step = (long)gridDim.x * 256 * EW_U;
+        for (long i0 = (long)blockIdx.x * 256 * EW_U + threadIdx.x; i0 < hw4; i0 += step) {
+            float4 cv[EW_U], rv[EW_U];
+#pragma unroll
+            for (int u = 0; u < EW_U; ++u) {
+                const long i = i0 + u * 256;
+                if (i < hw4) {
+                    cv[u] = c4[i];
+                    rv[u] = r4[i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < EW_U; ++u) {
+                const long i = i0 + u * 256;
+                if (i < hw4) one(i, cv[u], rv[u]);
+            }
+        }
+    } else {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw4; i += (long)gridDim.x * blockDim.x) {
+            load_params((int)(i % c4n));
+            one(i, c4[i], r4[i]);
         }
     }
 }
@@ -383,6 +446,7 @@ __global__ __launch_bounds__(256) void se_fc_bwd_sample_kernel(
     }
 }
 
+template <bool INV>
 __global__ __launch_bounds__(256) void se_tail_bwd_apply_kernel(
     const float *__restrict__ de, const float *__restrict__ e, const float *__restrict__ c,
     const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ invstd,
@@ -391,24 +455,20 @@ __global__ __launch_bounds__(256) void se_tail_bwd_apply_kernel(
     const unsigned long long *__restrict__ mask, long hw4, int c4n, float invHW, float invR) {
     const int n = blockIdx.y;
     const size_t base = (size_t)n * hw4;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw4; i += (long)gridDim.x * blockDim.x) {
-        const int cx = (int)(i % c4n);
-        const float4 d = reinterpret_cast<const float4 *>(de)[base + i];
-        bool px, py, pz, pw;
-        if (mask) {
-            mask_bits4(mask, base + i, px, py, pz, pw);
-        } else {
-            const float4 ev = reinterpret_cast<const float4 *>(e)[base + i];
-            px = ev.x > 0.f; py = ev.y > 0.f; pz = ev.z > 0.f; pw = ev.w > 0.f;
-        }
-        const float4 cv = reinterpret_cast<const float4 *>(c)[base + i];
-        const float4 ga = reinterpret_cast<const float4 *>(gamma)[cx];
-        const float4 m = reinterpret_cast<const float4 *>(mean)[cx];
-        const float4 is = reinterpret_cast<const float4 *>(invstd)[cx];
-        const float4 sv = reinterpret_cast<const float4 *>(s)[(size_t)n * c4n + cx];
-        const float4 dp = reinterpret_cast<const float4 *>(dpool)[(size_t)n * c4n + cx];
-        const float4 a = reinterpret_cast<const float4 *>(sdd)[cx];
-        const float4 b = reinterpret_cast<const float4 *>(sddx)[cx];
+    const float4 *de4 = reinterpret_cast<const float4 *>(de) + base, *c4 = reinterpret_cast<const float4 *>(c) + base;
+    const float4 *e4 = e ? reinterpret_cast<const float4 *>(e) + base : nullptr;
+    float4 *dc4 = reinterpret_cast<float4 *>(dc) + base, *dr4 = dr ? reinterpret_cast<float4 *>(dr) + base : nullptr;
+    float4 ga, m, is, sv, dp, a, b;
+    auto load_params = [&](int cx) {
+        ga = reinterpret_cast<const float4 *>(gamma)[cx];
+        m = reinterpret_cast<const float4 *>(mean)[cx];
+        is = reinterpret_cast<const float4 *>(invstd)[cx];
+        sv = reinterpret_cast<const float4 *>(s)[(size_t)n * c4n + cx];
+        dp = reinterpret_cast<const float4 *>(dpool)[(size_t)n * c4n + cx];
+        a = reinterpret_cast<const float4 *>(sdd)[cx];
+        b = reinterpret_cast<const float4 *>(sddx)[cx];
+    };
+    auto one = [&](long i, float4 d, float4 cv, bool px, bool py, bool pz, bool pw) {
         float4 g, o;
         g.x = px ? d.x : 0.f;
         g.y = py ? d.y : 0.f;
@@ -418,8 +478,47 @@ __global__ __launch_bounds__(256) void se_tail_bwd_apply_kernel(
         o.y = ga.y * is.y * (g.y * sv.y + dp.y * invHW - a.y * invR - (cv.y - m.y) * is.y * b.y * invR);
         o.z = ga.z * is.z * (g.z * sv.z + dp.z * invHW - a.z * invR - (cv.z - m.z) * is.z * b.z * invR);
         o.w = ga.w * is.w * (g.w * sv.w + dp.w * invHW - a.w * invR - (cv.w - m.w) * is.w * b.w * invR);
-        reinterpret_cast<float4 *>(dc)[base + i] = o;
-        if (dr) reinterpret_cast<float4 *>(dr)[base + i] = g;
+        dc4[i] = o;
+        if (dr4) dr4[i] = g;
+    };
+    if (INV) {
+        load_params((int)threadIdx.x % c4n);
+        const long step = (long)gridDim.x * 256 * EW_U;
+        for (long i0 = (long)blockIdx.x * 256 * EW_U + threadIdx.x; i0 < hw4; i0 += step) {
+            float4 d[EW_U], cv[EW_U];
+            bool px[EW_U], py[EW_U], pz[EW_U], pw[EW_U];
+#pragma unroll
+            for (int u = 0; u < EW_U; ++u) {
+                const long i = i0 + u * 256;
+                if (i < hw4) {
+                    d[u] = de4[i];
+                    cv[u] = c4[i];
+                    if (mask) {
+                        mask_bits4(mask, base + i, px[u], py[u], pz[u], pw[u]);
+                    } else {
+                        const float4 ev = e4[i];
+                        px[u] = ev.x > 0.f; py[u] = ev.y > 0.f; pz[u] = ev.z > 0.f; pw[u] = ev.w > 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < EW_U; ++u) {
+                const long i = i0 + u * 256;
+                if (i < hw4) one(i, d[u], cv[u], px[u], py[u], pz[u], pw[u]);
+            }
+        }
+    } else {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw4; i += (long)gridDim.x * blockDim.x) {
+            load_params((int)(i % c4n));
+            bool px, py, pz, pw;
+            if (mask) {
+                mask_bits4(mask, base + i, px, py, pz, pw);
+            } else {
+                const float4 ev = e4[i];
+                px = ev.x > 0.f; py = ev.y > 0.f; pz = ev.z > 0.f; pw = ev.w > 0.f;
+            }
+            one(i, de4[i], c4[i], px, py, pz, pw);
+        }
     }
 }
 
@@ -588,9 +687,14 @@ extern "C" int adyolo_bn_bwd_apply(const float *dy, const float *x, const float 
     const long n4 = rows * (C / 4);
     ADYOLO_REQUIRE(!dx_colsum || (colsum_partial && 256 % (C / 4) == 0), ADYOLO_EINVAL,
                    "bn_bwd_apply: dx_colsum needs a [8192][C] partial workspace and C/4 dividing 256");
-    const int grid = ew_grid(n4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, dy, x, gamma, mean, invstd, sdy, sdyx, dx,
-                       dx_colsum ? colsum_partial : (float *)nullptr, n4, C / 4, (float)(1.0 / (double)rows), relu_mask);
+    const bool inv = 256 % (C / 4) == 0;
+    const int grid = ew_grid(inv ? cdiv(n4, (long)EW_U) : n4);
+    if (inv)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid), dim3(256), 0, st, dy, x, gamma, mean, invstd, sdy, sdyx, dx,
+                           dx_colsum ? colsum_partial : (float *)nullptr, n4, C / 4, (float)(1.0 / (double)rows), relu_mask);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0, st, dy, x, gamma, mean, invstd, sdy, sdyx, dx,
+                           dx_colsum ? colsum_partial : (float *)nullptr, n4, C / 4, (float)(1.0 / (double)rows), relu_mask);
     int rc = check_launch("bn_bwd_apply");
     if (rc) return rc;
     if (dx_colsum) {
@@ -628,10 +732,15 @@ extern "C" int adyolo_se_tail_fwd(const float *c, const float *r, const float *s
                    ADYOLO_EINVAL, "se_tail_fwd: bad arguments");
     const long hw4 = (long)HW * (C / 4);
     ADYOLO_REQUIRE(!mask || hw4 % 64 == 0, ADYOLO_ENOSUP, "se_tail_fwd: mask bits need HW*C/4 %% 64 == 0 (HW=%d C=%d)", HW, C);
-    int gx = ew_grid(hw4);
+    const bool inv = 256 % (C / 4) == 0;
+    int gx = ew_grid(inv ? cdiv(hw4, (long)EW_U) : hw4);
     if ((long)gx * N > 16384) gx = (int)(16384 / N > 0 ? 16384 / N : 1);
-    hipLaunchKernelGGL(se_tail_fwd_kernel, dim3(gx, N), dim3(256), 0, as_stream(stream), c, r, scale, shift, s, r_scale,
-                       r_shift, e, reinterpret_cast<unsigned long long *>(mask), hw4, C / 4);
+    if (inv)
+        hipLaunchKernelGGL(se_tail_fwd_kernel<true>, dim3(gx, N), dim3(256), 0, as_stream(stream), c, r, scale, shift, s,
+                           r_scale, r_shift, e, reinterpret_cast<unsigned long long *>(mask), hw4, C / 4);
+    else
+        hipLaunchKernelGGL(se_tail_fwd_kernel<false>, dim3(gx, N), dim3(256), 0, as_stream(stream), c, r, scale, shift, s,
+                           r_scale, r_shift, e, reinterpret_cast<unsigned long long *>(mask), hw4, C / 4);
     return check_launch("se_tail_fwd");
 }
 
@@ -687,12 +796,17 @@ extern "C" int adyolo_se_tail_bwd_apply(const float *de, const float *e, const u
                        HW > 0 && C % 4 == 0,
                    ADYOLO_EINVAL, "se_tail_bwd_apply: bad arguments");
     const long hw4 = (long)HW * (C / 4);
-    int gx = ew_grid(hw4);
+    const bool inv = 256 % (C / 4) == 0;
+    int gx = ew_grid(inv ? cdiv(hw4, (long)EW_U) : hw4);
     if ((long)gx * N > 16384) gx = (int)(16384 / N > 0 ? 16384 / N : 1);
-    hipLaunchKernelGGL(se_tail_bwd_apply_kernel, dim3(gx, N), dim3(256), 0, as_stream(stream), de, e, c, gamma, mean,
-                       invstd, s, dpool, sdd, sddx, dc, dr, reinterpret_cast<const unsigned long long *>(mask), hw4,
-                       C / 4, 1.0f / (float)HW,
-                       (float)(1.0 / ((double)N * (double)HW)));
+    if (inv)
+        hipLaunchKernelGGL(se_tail_bwd_apply_kernel<true>, dim3(gx, N), dim3(256), 0, as_stream(stream), de, e, c, gamma,
+                           mean, invstd, s, dpool, sdd, sddx, dc, dr, reinterpret_cast<const unsigned long long *>(mask),
+                           hw4, C / 4, 1.0f / (float)HW, (float)(1.0 / ((double)N * (double)HW)));
+    else
+        hipLaunchKernelGGL(se_tail_bwd_apply_kernel<false>, dim3(gx, N), dim3(256), 0, as_stream(stream), de, e, c, gamma,
+                           mean, invstd, s, dpool, sdd, sddx, dc, dr, reinterpret_cast<const unsigned long long *>(mask),
+                           hw4, C / 4, 1.0f / (float)HW, (float)(1.0 / ((double)N * (double)HW)));
     return check_launch("se_tail_bwd_apply");
 }
 

@@ -256,7 +256,7 @@ class SEBlockFn(torch.autograd.Function):
         else:
             e, ebits = ops.se_tail_fwd(cc, r, scale2, shift2, s, r_affine=raff), None
         ctx.link_in = link_in if (FUSE_SEBWD and FUSE_DR and training and link_in is not None and not pool
-                                  and wd is None and link_in.cc is not None) else None
+                                  and link_in.cc is not None) else None
         ctx.link_out = link_out if (FUSE_SEBWD and training) else None
         if ctx.link_out is not None:
             link_out.cc, link_out.mean2, link_out.invstd2, link_out.tiles = cc, mean2, invstd2, None
@@ -334,7 +334,13 @@ class SEBlockFn(torch.autograd.Function):
             dwd = ops.gemm(dq, p, c, cin, rows, c, cin, trans_a=True, trans_b=True,
                            splits=ops.wgrad_splits(c, cin, rows)).view(c, cin, 1, 1)
             dp_res = ops.gemm(dq, wd, rows, cin, c, c, cin, trans_b=True).view(n, h, w_, cin)
-            dp = ops.conv3x3(da, wpk1d, cin, addend=dp_res)
+            if ctx.link_in is not None:       # un-pooled stage boundary (stage 4): dp is the gradient of the block above
+                lk = ctx.link_in
+                dp, lk.tiles = ops.conv3x3(da, wpk1d, cin, addend=dp_res, want_stats=True,
+                                           stat_bn=(lk.cc, lk.mean2, lk.invstd2),
+                                           stat_mask=lk.ebits if lk.ebits is not None else p)
+            else:
+                dp = ops.conv3x3(da, wpk1d, cin, addend=dp_res)
         else:
             # identity shortcut: its gradient de * (e > 0) is formed inside the dgrad epilogue
             emask = ebits if ebits is not None else e          # this block's ReLU mask: bits when the forward stored them
