@@ -370,6 +370,82 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(
     }
 }
 
+// Weight gradient of the 8-channel stem convolution (Cin = 8 padded from 7, Cout = 32; reference resnet.py:142).  As a GEMM
+// it is D[co][n = tap*8 + ci] = sum over pixels dy[pix][co] * x[pix + tap][ci]: M = 32 output channels is exactly one MFMA
+// tile, N = 72 is three (the last a quarter full) and the contraction runs over pixels, so both operands ARE in MFMA layout
+// in memory: lane (co, pixel parity) reads dy[pixel][co] (128 contiguous bytes per pixel across the 32 lanes) and lane
+// (n, pixel parity) reads x[pixel + tap][ci] (32 contiguous bytes per tap) straight from global memory -- no LDS staging,
+// no transposition.  A wave walks image rows, SW_U pixel pairs (4 x SW_U dword loads) in flight ahead of 3 x SW_U MFMAs; the
+// generic kernel above pads Cin to 32 (4x the matrix work) and took 1.69 ms at B = 64 x 60 s for a 1.57 GB read.
+constexpr int SW_U = 8;
+__global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                            float *__restrict__ slabs, int H, int W, int rows_total) {
+    __shared__ float red[4 * 32 * 72];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    int ky[3], kx[3], ci[3];
+    bool tv[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int n = t * 32 + li, tap = n >> 3;
+        tv[t] = tap < 9;
+        ky[t] = tap / 3 - 1;
+        kx[t] = tap % 3 - 1;
+        ci[t] = n & 7;
+    }
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // rows are dealt to the workgroups in contiguous runs (neighbouring rows share their x taps in L2), one row per wave
+    const int per = (rows_total + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * per, r1 = min(rows_total, r0 + per);
+    for (int row = r0 + wave; row < r1; row += 4) {
+        const int y = row % H;
+        const float *dyrow = dy + (size_t)row * W * 32 + li;
+        const float *xrow[3];
+        bool rowok[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int yy = y + ky[t];
+            rowok[t] = tv[t] && yy >= 0 && yy < H;
+            xrow[t] = x + ((size_t)(row + (rowok[t] ? ky[t] : 0)) * W) * 8 + ci[t];
+        }
+        for (int xp = 0; xp < W; xp += 2 * SW_U) {
+            float a[SW_U], b[3][SW_U];
+#pragma unroll
+            for (int u = 0; u < SW_U; ++u) {
+                const int px = xp + 2 * u + lh;
+                const bool pok = px < W;
+                a[u] = pok ? dyrow[(size_t)px * 32] : 0.f;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int xx = px + kx[t];
+                    const bool ok = pok && rowok[t] && xx >= 0 && xx < W;
+                    b[t][u] = ok ? xrow[t][(size_t)xx * 8] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < SW_U; ++u)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[t] = mfma32(a[u], b[t][u], acc[t]);
+        }
+    }
+    // the four waves' partial sums are added in wave order; one slab [32][9][8] per workgroup
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = t * 32 + li;
+            if (n < 72) red[(wave * 32 + mfma_row(r, lane)) * 72 + n] = acc[t][r];
+        }
+    __syncthreads();
+    for (int i = tid; i < 32 * 72; i += 256)
+        slabs[(size_t)blockIdx.x * (32 * 72) + i] = ((red[i] + red[32 * 72 + i]) + red[2 * 32 * 72 + i]) + red[3 * 32 * 72 + i];
+}
+
 // slabs [nslab][Cout][9][CinP] -> dw [Cout][Cin_real][3][3]: 32 outputs x 8 slab-groups per workgroup (coalesced 128-byte
 // rows, partial sums in double), deterministic
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float *__restrict__ slabs,
@@ -486,6 +562,15 @@ extern "C" int adyolo_conv3x3_wgrad(const float *x, const float *dy, const float
     hipStream_t st = as_stream(stream);
     int TW;
     const int nsplit = wgrad_splits(N, H, W, Cin, Cout, &TW);
+    if (Cin == 8 && Cout == 32 && !in_scale && (long)N * H < (1L << 31)) {       // the stem: operands straight from memory
+        const int nblk = nsplit < 512 ? nsplit : 512;       // (the slab workspace holds nsplit x 32 x 9 x 32 floats)
+        hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk), dim3(256), 0, st, x, dy, slabs, H, W, N * H);
+        int rcs = check_launch("stem_wgrad");
+        if (rcs) return rcs;
+        hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(cdiv(32 * 72, 32)), dim3(256), 0, st, slabs, dw, nblk, 32, 8,
+                           Cin_real);
+        return check_launch("stem_wgrad_reduce");
+    }
     const int TH = 256 / TW;
     const int tilesW = cdiv(W, TW), tilesH = cdiv(H, TH);
     const int ntiles = N * tilesW * tilesH;

@@ -88,6 +88,7 @@ def test_conv3x3_forward(ops, n, h, w, cin, cout, relu, bias, addend, algo):
     (3, 40, 64, 32, 32), (2, 150, 24, 32, 64), (1, 67, 37, 64, 32),
     (6, 132, 16, 256, 256),      # Winograd wgrad: 18 work items on 16 slabs -> several items per workgroup, ragged segment
     (2, 21, 19, 96, 32),         # odd H and W (general masking path), 3 input-channel blocks
+    (3, 11, 37, 7, 32), (1, 5, 64, 7, 32), (5, 3, 6, 7, 32),    # stem weight-gradient kernel: odd W, fewer rows than waves
 ])
 @pytest.mark.parametrize("algo", ["direct", "winograd"])
 def test_conv3x3_dgrad_wgrad(ops, n, h, w, cin, cout, algo):

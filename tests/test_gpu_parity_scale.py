@@ -324,6 +324,23 @@ def test_stem_conv_at_bench_shape_slices(ops):
     tot = st[0].double().sum(0).cpu()
     ref = y.double().sum(dim=(0, 1, 2)).cpu()
     assert float((tot - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+    # weight gradient at full size (stem kernel: rows dealt to 512 workgroups): with dy non-zero only in three row bands
+    # (first rows, last rows, a band across a sample boundary) it must equal the float64 weight gradient of those bands
+    dy = torch.zeros(n, h, w, 32, device="cuda:0")
+    bands = ((0, 0, 40), (n - 1, h - 40, h), (17, h - 3, h), (18, 0, 5))
+    ref_dw = torch.zeros(32, 7, 3, 3, dtype=torch.float64)
+    for clip, r0, r1 in bands:
+        dy[clip, r0:r1] = torch.randn(r1 - r0, w, 32, generator=gen, device="cuda:0")
+        lo, hi = max(r0 - 1, 0), min(r1 + 1, h)
+        xin = x[clip, lo:hi, :, :7].cpu().permute(2, 0, 1)[None].double()
+        wd_ = wt.cpu().double().requires_grad_(True)
+        out = F.conv2d(xin, wd_, None, padding=1)
+        gsl = torch.zeros_like(out)
+        gsl[0, :, r0 - lo:r1 - lo] = dy[clip, r0:r1].cpu().double().permute(2, 0, 1)
+        out.backward(gsl)
+        ref_dw += wd_.grad
+    dw = ops.conv3x3_wgrad(x, dy, 7)
+    assert _rel(dw.cpu(), ref_dw) <= 2e-5
 
 
 # ------------------------------------------------------------------------------ benchmark shape: loss
