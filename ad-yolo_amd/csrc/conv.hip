@@ -370,6 +370,85 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(
     }
 }
 
+// Forward of the 8-channel stem convolution (Cin = 8 padded from 7, Cout = 32, bias + ReLU + per-patch BatchNorm sums;
+// reference resnet.py:142,183-184).  One (tap, 8 channels) slice of a pixel is exactly the 8 k-values four MFMAs consume,
+// so the A operand is ONE float4 per lane and tap read straight from memory (lanes (pixel, half) cover 32 consecutive
+// pixels x 32 bytes = 1 KB contiguous), the 9 x 8 x 32 filter lives in 36 registers, and nothing goes through LDS but the
+// per-patch sums.  Same patch grid (8 x 32 pixels per workgroup, two image rows per wave) and statistics layout as
+// conv3x3_fwd_kernel<8, 32, 32>, which staged a halo patch in LDS for a 72-deep contraction: 0.78 ms at B = 64 x 60 s for
+// a 1.57 GB read + write.
+__global__ __launch_bounds__(256, 4) void stem_fwd_kernel(const float *__restrict__ x, const float *__restrict__ wpk,
+                                                          const float *__restrict__ bias, float *__restrict__ y,
+                                                          float *__restrict__ stats, int H, int W, int tilesW, int tilesH,
+                                                          int relu) {
+    __shared__ float red[4 * 32 * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    int bid = blockIdx.x;
+    const int tw = bid % tilesW;
+    bid /= tilesW;
+    const int th = bid % tilesH;
+    const int n = bid / tilesH;
+    const int ty0 = th * 8, tx0 = tw * 32;
+    float4 bw[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) bw[tap] = *reinterpret_cast<const float4 *>(wpk + (li * 9 + tap) * 8 + lh * 4);
+    const float bv = bias ? bias[li] : 0.f;
+    const float *xn = x + (size_t)n * H * W * 8 + lh * 4;
+    float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int gy = ty0 + wave * 2 + mt;
+        float4 a[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = gy + tap / 3 - 1, xx = tx0 + li + tap % 3 - 1;
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const int cy = min(max(yy, 0), H - 1), cx = min(max(xx, 0), W - 1);
+            const float4 v = *reinterpret_cast<const float4 *>(xn + ((size_t)cy * W + cx) * 8);
+            a[tap] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            acc = mfma32(a[tap].x, bw[tap].x, acc);
+            acc = mfma32(a[tap].y, bw[tap].y, acc);
+            acc = mfma32(a[tap].z, bw[tap].z, acc);
+            acc = mfma32(a[tap].w, bw[tap].w, acc);
+        }
+        if (gy < H) {
+            float *yrow = y + (((size_t)n * H + gy) * W) * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gx = tx0 + mfma_row(r, lane);
+                if (gx < W) {
+                    float v = acc[r] + bv;
+                    if (relu) v = fmaxf(v, 0.f);
+                    yrow[(size_t)gx * 32] = v;
+                    ssum += v;
+                    ssq += v * v;
+                }
+            }
+        }
+    }
+    if (stats) {        // layout [2][tiles][32], tile = blockIdx.x (as conv3x3_fwd_kernel)
+        const float a0 = ssum + __shfl_xor(ssum, 32, 64), a1 = ssq + __shfl_xor(ssq, 32, 64);
+        if (lh == 0) {
+            red[(wave * 32 + li) * 2 + 0] = a0;
+            red[(wave * 32 + li) * 2 + 1] = a1;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int c = tid >> 1, which = tid & 1;
+            const float v = red[(0 * 32 + c) * 2 + which] + red[(1 * 32 + c) * 2 + which] + red[(2 * 32 + c) * 2 + which] +
+                            red[(3 * 32 + c) * 2 + which];
+            stats[which * ((size_t)gridDim.x * 32) + (size_t)blockIdx.x * 32 + c] = v;
+        }
+    }
+}
+
 // Weight gradient of the 8-channel stem convolution (Cin = 8 padded from 7, Cout = 32; reference resnet.py:142).  As a GEMM
 // it is D[co][n = tap*8 + ci] = sum over pixels dy[pix][co] * x[pix + tap][ci]: M = 32 output channels is exactly one MFMA
 // tile, N = 72 is three (the last a quarter full) and the contraction runs over pixels, so both operands ARE in MFMA layout
@@ -542,6 +621,12 @@ extern "C" int adyolo_conv3x3_fwd(const float *x, const float *wpk, const float 
 #define ADYOLO_FWD(KC_, BN_, TW_) \
     launch_fwd<KC_, BN_, TW_>(x, wpk, bias, addend, addend_mask, in_scale, in_shift, y, stats, stat_aux, stat_mean, \
                               stat_invstd, stat_mask, N, H, W, Cin, Cout, relu, mask_bits, st)
+    if (Cin == 8 && Cout == 32 && wide && !addend && !in_scale && !stat_aux && !stat_mask) {      // the stem
+        const int tilesW = cdiv(W, 32), tilesH = cdiv(H, 8);
+        hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)(N * tilesH * tilesW)), dim3(256), 0, st, x, wpk, bias, y, stats, H,
+                           W, tilesW, tilesH, relu);
+        return check_launch("stem_fwd");
+    }
     if (Cin == 8) return wide ? ADYOLO_FWD(8, 32, 32) : ADYOLO_FWD(8, 32, 16);
     if (Cout % 64 == 0) return wide ? ADYOLO_FWD(32, 64, 32) : ADYOLO_FWD(32, 64, 16);
     return wide ? ADYOLO_FWD(32, 32, 32) : ADYOLO_FWD(32, 32, 16);

@@ -47,6 +47,8 @@ def assert_close(got, ref, tol, what):
 @pytest.mark.parametrize("n,h,w,cin,cout,relu,bias,addend", [
     (2, 20, 64, 7, 32, True, True, False),       # stem shape family (Cin 7 padded to 8), W=64 -> TW=32
     (1, 9, 16, 7, 32, False, True, False),       # ragged H, TW=16 path
+    (3, 13, 45, 7, 32, True, True, False),       # stem kernel: ragged rows and columns (2 column patches, the 2nd 13 wide)
+    (2, 11, 32, 7, 32, False, False, False),     # stem kernel without bias / ReLU
     (2, 16, 64, 32, 32, False, False, True),     # layer1
     (2, 13, 32, 32, 64, True, False, False),     # layer2.0 conv1, ragged H
     (1, 24, 32, 64, 64, False, False, True),
