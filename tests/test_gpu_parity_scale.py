@@ -254,6 +254,51 @@ def test_eval_forward_at_reference_test_shape(ops):
     assert e_y <= 1e-3 and e_l <= 1e-3 * max(1.0, float(l_ref.abs().max()))
 
 
+def test_conformer_eval_forward_at_training_shape(ops):
+    """ResNet-Conformer (config 4) at its training length, B = 1, T = 800 (20 s): the implicit-GEMM convolutions (7x7 s(1,2)
+    stem, strided first blocks, the W = 4 / 2 / 1 stride-1 maps with the folded W = 2 form), the Winograd ones (W = 8) and
+    the flash-style attention at T = 800 against the float32 CPU oracle (oracle/conformer.py, itself pinned by the
+    reference golden at T = 32) with random default-init weights: encoder output 1e-3."""
+    from adyolo_amd.wrapper import WrapperModel
+    from oracle import conformer as ocf
+    prm = _params()
+    prm["args"]["encoder"] = "resnet-conformer"
+    torch.manual_seed(100)
+    model = WrapperModel((1, 7, 800, 64), (), prm).to("cuda:0")
+    gen = torch.Generator().manual_seed(4)
+    for k, v in model.state_dict().items():
+        if k.endswith("running_mean"):
+            v.copy_((torch.rand(v.shape, generator=gen) * 0.2 - 0.1).to(v.device))
+        elif k.endswith("running_var"):
+            v.copy_((torch.rand(v.shape, generator=gen) * 0.5 + 0.75).to(v.device))
+    model.eval()
+    x = torch.randn(1, 7, 800, 64, generator=gen)
+    with torch.no_grad():
+        y = model.encoder(x.to("cuda:0"))
+    torch.cuda.synchronize()
+    sd = {k[len("encoder."):]: v.detach().cpu() for k, v in model.state_dict().items() if k.startswith("encoder.")}
+    with torch.no_grad():
+        y_ref = ocf.encoder_forward(sd, x, training=False)
+    assert y.shape == (1, 200, 256)
+    err = float((y.cpu() - y_ref).abs().max())
+    print("conformer T=800 eval: encoder err %.2e (absmax %.2f)" % (err, float(y_ref.abs().max())))
+    assert err <= 1e-3 * max(1.0, float(y_ref.abs().max()))
+    # training mode (batch statistics through 36 BatchNorms + 8 conformer blocks), dropout switched off on both sides
+    enc = model.encoder
+    enc.train()
+    for m in enc.modules():
+        if hasattr(m, "p") and isinstance(getattr(m, "p"), float):
+            m.p = 0.0
+        if hasattr(m, "p2"):
+            m.p2 = 0.0
+    with torch.no_grad():
+        yt = enc(x.to("cuda:0"))
+        yt_ref = ocf.encoder_forward(sd, x, training=True)
+    err = float((yt.cpu() - yt_ref).abs().max())
+    print("conformer T=800 train-mode forward: encoder err %.2e" % err)
+    assert err <= 1e-3 * max(1.0, float(yt_ref.abs().max()))
+
+
 # ------------------------------------------------------------------------------ benchmark shape: convolution slice checks
 BENCH_STAGES = [  # (Cin, Cout, H, W) of the 3x3 convolutions of stages 1-4 at 64 clips x 60 s
     (32, 32, 2400, 64), (64, 64, 1200, 32), (128, 128, 600, 16), (256, 256, 600, 16), (32, 64, 1200, 32)]
