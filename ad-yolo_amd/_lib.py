@@ -63,6 +63,7 @@ SIGNATURES = {
     "adyolo_ln_tanh_fwd": (I, [P] * 4 + [L, I, F, P]),
     "adyolo_ln_tanh_bwd": (I, [P] * 8 + [L, I, F, P]),
     "adyolo_dropout_mask": (I, [P, L, F, U64, U64, P]),
+    "adyolo_dropout_apply": (I, [P, P, L, F, U64, U64, P]),
     "adyolo_loss_workspace_words": (L, [I, I, I, I]),
     "adyolo_loss_fwd_bwd": (I, [P] * 6 + [I] * 7 + [P, P, F, F, F, F, P]),
     "adyolo_yolo_decode": (I, [P, P, L, I, I, I, I, F, F, F, P]),

@@ -432,6 +432,23 @@ __global__ void dropout_mask_kernel(float *__restrict__ mask, long n, float p, f
     }
 }
 
+// y = x * mask with the SAME mask values dropout_mask_kernel writes for (seed, offset) -- generated on the fly, so neither
+// the forward nor the backward pass (dx = dy * mask: the same call on dy) moves a mask tensor
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, long n4,
+                                                            float p, float keep_scale, uint64_t seed, uint64_t offset) {
+    const uint64_t s0 = splitmix64(seed);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = x[i];
+        const uint64_t b = offset + (uint64_t)i * 4;
+        const float u0 = (float)(splitmix64(s0 ^ b) >> 40) * (1.0f / 16777216.0f);
+        const float u1 = (float)(splitmix64(s0 ^ (b + 1)) >> 40) * (1.0f / 16777216.0f);
+        const float u2 = (float)(splitmix64(s0 ^ (b + 2)) >> 40) * (1.0f / 16777216.0f);
+        const float u3 = (float)(splitmix64(s0 ^ (b + 3)) >> 40) * (1.0f / 16777216.0f);
+        y[i] = make_float4(v.x * (u0 >= p ? keep_scale : 0.f), v.y * (u1 >= p ? keep_scale : 0.f),
+                           v.z * (u2 >= p ? keep_scale : 0.f), v.w * (u3 >= p ? keep_scale : 0.f));
+    }
+}
+
 }  // namespace adyolo
 
 using namespace adyolo;
@@ -526,6 +543,16 @@ extern "C" int adyolo_ln_bwd(const float *dy, const float *x, const float *gamma
     if (rc) return rc;
     hipLaunchKernelGGL(ln_bwd_final_kernel, dim3(16), dim3(256), 0, st, partial, dgamma, dbeta, nblk);
     return check_launch("ln_bwd_final");
+}
+
+extern "C" int adyolo_dropout_apply(const float *x, float *y, long n, float p, uint64_t seed, uint64_t offset, void *stream) {
+    ADYOLO_REQUIRE(x && y && n > 0 && n % 4 == 0 && p >= 0.f && p < 1.f, ADYOLO_EINVAL,
+                   "dropout_apply: n must be a positive multiple of 4, 0 <= p < 1");
+    const long n4 = n / 4, g = (n4 + 255) / 256;
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y), n4, p, 1.0f / (1.0f - p), seed,
+                       offset);
+    return check_launch("dropout_apply");
 }
 
 extern "C" int adyolo_dropout_mask(float *mask, long n, float p, uint64_t seed, uint64_t offset, void *stream) {

@@ -475,6 +475,21 @@ class DropoutFn(torch.autograd.Function):
         return ops.mul(_c(dy), mask), None
 
 
+class DropoutHashFn(torch.autograd.Function):
+    """Dropout whose mask is regenerated from (seed, offset) of a ``DropoutStream`` in the forward and in the backward
+    kernel -- the same mask values ``DropoutFn`` would read from a tensor, without the tensor."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, offset):
+        ctx.key = (p, seed, offset)
+        return ops.dropout_apply(_c(x), p, seed, offset)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, offset = ctx.key
+        return ops.dropout_apply(_c(dy), p, seed, offset), None, None, None
+
+
 class ADYOLOLossFn(torch.autograd.Function):
     """AD-YOLO loss (reference loss.py:189-251); the gradient w.r.t. the logits is produced by the same
     launch that computes the loss and only rescaled by the incoming gradient in backward."""

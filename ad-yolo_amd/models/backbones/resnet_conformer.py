@@ -26,7 +26,9 @@ from .resnet import BatchNormParams, ConvParams, LayerNormParams, LinearParams
 def _dropout(x, p, training, rng):
     if not training or p <= 0.0:
         return x
-    return Fn.DropoutFn.apply(x, rng.mask(x, p))
+    if x.numel() % 4:
+        return Fn.DropoutFn.apply(x, rng.mask(x, p))
+    return Fn.DropoutHashFn.apply(x, p, *rng.draw(x.numel()))
 
 
 def _conv3x3_s1(x, w):

@@ -437,6 +437,14 @@ def dropout_mask(like, p, seed, offset):
     return mask
 
 
+def dropout_apply(x, p, seed, offset):
+    """x * mask, mask = dropout_mask(x, p, seed, offset) generated on the fly (no mask tensor)."""
+    _chk(x)
+    y = torch.empty_like(x)
+    _c("adyolo_dropout_apply", _p(x), _p(y), x.numel(), float(p), ctypes.c_uint64(seed), ctypes.c_uint64(offset), _stream())
+    return y
+
+
 # ---------------------------------------------------------------------------------------------- loss / optim
 def adyolo_loss(logit, target, nb_classes, grid=(8, 4), anchors=5, thr=(45.0, 25.0, 10.0),
                 gains=(5.0, 1.0, 5.0, 3.0), grid_size=(45.0, 45.0), g_overlap=0.5, need_grad=True, grad_scale=1.0,

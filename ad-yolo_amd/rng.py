@@ -32,6 +32,13 @@ class DropoutStream:
         self.offset += like.numel()
         return m
 
+    def draw(self, n):
+        """(seed, offset) for ``n`` values generated inside a kernel (``ops.dropout_apply``); advances the stream by n.
+        The values are the ones ``mask`` would have written."""
+        key = (self.seed, self.offset)
+        self.offset += int(n)
+        return key
+
     def seed32(self, n):
         """A 32-bit seed for a kernel that draws ``n`` values from its own stateless hash; advances the stream by n."""
         x = (self.seed ^ ((self.offset * 0x9E3779B97F4A7C15) & _MASK64)) & _MASK64

@@ -258,6 +258,10 @@ int adyolo_ln_tanh_bwd(const float *dy, const float *x, const float *y, const fl
                        float *dx, float *dgamma, float *dbeta, float *partial, long R, int C,
                        float eps, void *stream);
 int adyolo_dropout_mask(float *mask, long n, float p, uint64_t seed, uint64_t offset, void *stream);
+/* y[i] = x[i] * mask[i] with the mask values adyolo_dropout_mask writes for (seed, offset), generated on the fly (forward:
+ * x -> y; backward: the same call on the incoming gradient); n a multiple of 4.  Replaces nn.Dropout /
+ * nn.GRU(dropout=) (reference resnet.py:153, resnet_conformer.py:46-47,199-206). */
+int adyolo_dropout_apply(const float *x, float *y, long n, float p, uint64_t seed, uint64_t offset, void *stream);
 int adyolo_mul(const float *a, const float *b, float *y, long n, void *stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -351,6 +351,28 @@ def test_dropout_mask_statistics(ops):
     assert len(vals) == 2 and abs(vals[1] - 1 / 0.7) < 1e-6 and vals[0] == 0.0
 
 
+def test_dropout_apply_regenerates_the_mask(ops):
+    """The mask-free dropout (forward and backward) multiplies by exactly the values adyolo_dropout_mask writes for the same
+    (seed, offset): bit-equal to x * mask, including a non-zero stream offset and a grid-stride tail."""
+    from adyolo_amd import functional as Fn
+    from adyolo_amd.rng import DropoutStream
+    g = torch.Generator().manual_seed(9)
+    for n, off in ((1 << 20, 0), (12 * 257 * 4, 777), (3 * 1000 * 1000 + 4, (1 << 33) + 5)):
+        x = dev(torch.randn(n, generator=g))
+        m = ops.dropout_mask(x, 0.2, 0xABCDEF0123, off)
+        assert torch.equal(ops.dropout_apply(x, 0.2, 0xABCDEF0123, off), x * m)
+    torch.manual_seed(5)
+    s1, s2 = DropoutStream(0x11), DropoutStream(0x11)
+    x = dev(torch.randn(4, 50, 256, generator=g)).requires_grad_(True)
+    s1.draw(1000)
+    s2.mask(torch.empty(1000, device="cuda:0"), 0.2)                     # both streams advanced by the same count
+    y = Fn.DropoutHashFn.apply(x, 0.2, *s1.draw(x.numel()))
+    mask = s2.mask(x, 0.2)
+    assert s1.offset == s2.offset and torch.equal(y, x.detach() * mask)
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad, mask)
+
+
 # ------------------------------------------------------------------------------------------------ loss
 @pytest.mark.parametrize("tag,nb_classes", [("c12", 12), ("c13", 13), ("sat", 12)])
 def test_loss_matches_golden_and_oracle(ops, tag, nb_classes):
