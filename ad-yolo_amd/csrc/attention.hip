@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const float *__restric
         // S^T = K Q^T
         f32x16 st = {0};
         const float4 *krow = reinterpret_cast<const float4 *>(&kt[col * AKS + 32 * hi]);
+__builtin_amdgcn_s_setprio(2);      // matrix work first among the waves sharing this SIMD (-2 % per launch)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float4 a = krow[i];
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const float *__restric
             st = mfma32(a.z, qf[4 * i + 2], st);
             st = mfma32(a.w, qf[4 * i + 3], st);
         }
+__builtin_amdgcn_s_setprio(0);
         // online softmax (base 2): this lane's 16 keys of query `col`, the other half of the keys sits in lane ^ 32
         const int key0 = kb * 32;
         float mx = -INFINITY;
@@ -134,12 +136,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const float *__restric
                 st[j] = attn_keep(row_id, (unsigned)(key0 + acc_row(j, hi)), (unsigned)T, seed, drop_thr) ? st[j] * keep_scale : 0.f;
         }
         // O^T += V^T P^T: step j contracts key acc_row(j, 0) (lane half 0) and acc_row(j, 1) (lane half 1)
+__builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const float *vr = &vt[acc_row(j, hi) * AKS + col];
             o0 = mfma32(vr[0], st[j], o0);
             o1 = mfma32(vr[32], st[j], o1);
         }
+__builtin_amdgcn_s_setprio(0);
     }
     // epilogue: ctx[q][h*64 + dv] = O^T[dv][q] / l;  register r of o<dvb> holds dv = dvb*32 + acc_row(r, hi)
     if (q0 + col < T) {
@@ -234,6 +238,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(
         f32x16 s = {0}, dp = {0};
         const float4 *qrow = reinterpret_cast<const float4 *>(&qt[col * AKS + 32 * hi]);
         const float4 *drow = reinterpret_cast<const float4 *>(&dt[col * AKS + 32 * hi]);
+__builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float4 a = qrow[i], d4 = drow[i];
@@ -246,6 +251,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(
             dp = mfma32(d4.z, vf[4 * i + 2], dp);
             dp = mfma32(d4.w, vf[4 * i + 3], dp);
         }
+__builtin_amdgcn_s_setprio(0);
         // register j: query qb*32 + acc_row(j, hi), key k0 + col
         const int q00 = qb * 32;
 #pragma unroll
@@ -261,6 +267,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(
             dp[j] = ds;         // dS   -> dK
         }
         // dV^T += dO^T P_d ; dK^T += Q^T dS : step j contracts query acc_row(j, 0) / acc_row(j, 1)
+__builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int qi = acc_row(j, hi);
@@ -271,6 +278,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(
             dk0 = mfma32(qr[0], dp[j], dk0);
             dk1 = mfma32(qr[32], dp[j], dk1);
         }
+__builtin_amdgcn_s_setprio(0);
     }
     if (k0 + col < T) {
         float *dkd = dk + base + (size_t)(k0 + col) * E, *dvd = dv + base + (size_t)(k0 + col) * E;
@@ -335,6 +343,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
         f32x16 st = {0}, dpt = {0};
         const float4 *krow = reinterpret_cast<const float4 *>(&kt[col * AKS + 32 * hi]);
         const float4 *vrow = reinterpret_cast<const float4 *>(&vt[col * AKS + 32 * hi]);
+__builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float4 a = krow[i], c = vrow[i];
@@ -347,6 +356,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
             dpt = mfma32(c.z, df[4 * i + 2], dpt);
             dpt = mfma32(c.w, df[4 * i + 3], dpt);
         }
+__builtin_amdgcn_s_setprio(0);
         const int key0 = kb * 32;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -356,12 +366,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
             if (drop_thr) keep = attn_keep(row_id, (unsigned)min(key, T - 1), (unsigned)T, seed, drop_thr) ? keep_scale : 0.f;
             st[j] = p * (dpt[j] * keep - my_delta) * scale;            // dS^T
         }
+__builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const float *kr = &kt[acc_row(j, hi) * AKS + col];
             dq0 = mfma32(kr[0], st[j], dq0);
             dq1 = mfma32(kr[32], st[j], dq1);
         }
+__builtin_amdgcn_s_setprio(0);
     }
     if (q0 + col < T) {
         float *dst = dq + base + (size_t)(q0 + col) * E;
