@@ -44,7 +44,7 @@ def _worker(rank, world, port, xs, ys, out):
         with torch.no_grad():
             flat.flat.add_(flat.flat_grad, alpha=-0.1 * scale)
     if rank == 0:
-        out.put(flat.flat.clone())
+        out.put(flat.flat.detach().numpy().copy())      # plain bytes: a tensor would travel as a handle into this process
     dist.barrier()
     dist.destroy_process_group()
 
@@ -66,11 +66,11 @@ def test_bucketed_allreduce_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, xs, ys, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    got = torch.from_numpy(q.get(timeout=120))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    torch.testing.assert_close(got, flat_ref.flat, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(got, flat_ref.flat.detach(), rtol=1e-5, atol=1e-6)
 
 
 def test_flat_parameters_keep_module_semantics():
@@ -106,8 +106,10 @@ def _worker_startup(rank, world, port, out):
     stream = DropoutStream(0x5EED)
     model[1].running_mean.fill_(float(rank + 1))
     flat.average_buffers()
-    out.put((rank, flat.flat.clone(), flat.flat_grad.clone() * scale, red.fired_from_hooks, red.fired_from_finish,
-             stream.seed, model[1].running_mean.clone()))
+    # (numpy copies, not tensors: a tensor in a multiprocessing queue is a handle the parent must fetch from this process
+    #  while it is still alive)
+    out.put((rank, flat.flat.detach().numpy().copy(), (flat.flat_grad.detach() * scale).numpy().copy(), red.fired_from_hooks,
+             red.fired_from_finish, stream.seed, model[1].running_mean.detach().numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -124,11 +126,11 @@ def test_startup_broadcast_leftover_buckets_and_rank_seeds():
         p.join(timeout=120)
         assert p.exitcode == 0
     (_, p0, g0, h0, f0, s0, rm0), (_, p1, g1, h1, f1, s1, rm1) = got
-    assert torch.equal(p0, p1), "ranks must start from rank 0's parameters"
-    assert torch.equal(g0, g1), "averaged gradients must be identical on every rank"
+    assert (p0 == p1).all(), "ranks must start from rank 0's parameters"
+    assert (g0 == g1).all(), "averaged gradients must be identical on every rank"
     assert h0 + f0 == 2 and f0 >= 1 and (h0, f0) == (h1, f1)
     assert s0 != s1, "dropout streams must differ between the data-parallel ranks"
-    assert torch.equal(rm0, rm1) and float(rm0[0]) == 1.5          # running statistics averaged over the ranks
+    assert (rm0 == rm1).all() and float(rm0[0]) == 1.5            # running statistics averaged over the ranks
 
 
 def test_fused_adam_state_dict_uses_module_parameter_order():
