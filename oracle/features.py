@@ -72,11 +72,17 @@ def mel_filterbank(sr=SR, n_fft=N_FFT, n_mels=N_MELS):
     return np.ascontiguousarray(w.astype(np.float32).T)
 
 
-def stft(audio, n_fft=N_FFT, hop=HOP):
+def stft_all_frames(audio, n_fft=N_FFT, hop=HOP):
+    """What ``librosa.core.stft`` hands back at datasets.py:255 (before the ``[:, :nb_feature_frames]`` cut at :257): all
+    1 + N // hop centred frames, (T + 1, n_bins, C)."""
+    return stft(audio, n_fft, hop, extra_frame=True)
+
+
+def stft(audio, n_fft=N_FFT, hop=HOP, extra_frame=False):
     """datasets.py:252-258.  audio (N, C) float64 -> (T, n_bins, C) complex128, T=int(N/hop)."""
     audio = np.asarray(audio, dtype=np.float64)
     n, c = audio.shape
-    t = int(n / float(hop))
+    t = int(n / float(hop)) + (1 if extra_frame else 0)
     win = hann_periodic(n_fft)
     out = np.empty((t, n_fft // 2 + 1, c), dtype=np.complex128)
     for ch in range(c):
@@ -113,6 +119,35 @@ def foa_intensity(spec, mel_wts):
 def unit_scaler():
     return {"MEL": {"mean": np.zeros((1, N_MELS, 4)), "std": np.ones((1, N_MELS, 4))},
             "IV": {"mean": np.zeros((1, N_MELS, 3)), "std": np.ones((1, N_MELS, 3))}}
+
+
+def synthetic_spectrum(seed, t):
+    """Seeded complex spectrum (T + 1, 601, 4) for the spectrum-injection fixture (tests/golden/features_ref.npz, made by
+    running the reference's own ``get_feature`` on it): Y / Z / X partly coherent with W so the intensity vector is not
+    noise; magnitudes span 100 dB and one frame is near-silent, so the 1e-8 of E and power_to_db's floor / clip matter."""
+    rng = np.random.default_rng(int(seed))
+    shape = (int(t) + 1, N_BINS)
+    mag = 10.0 ** rng.uniform(-4.0, 1.0, size=shape)
+    w = mag * np.exp(1j * rng.uniform(-np.pi, np.pi, size=shape))
+    spec = np.empty(shape + (4,), dtype=np.complex128)
+    spec[:, :, 0] = w
+    for c in range(1, 4):
+        coh = rng.uniform(-1.0, 1.0, size=shape)
+        noise = 0.3 * mag * (rng.normal(size=shape) + 1j * rng.normal(size=shape))
+        spec[:, :, c] = coh * w + noise
+    spec[3, :, :] *= 1e-7
+    return spec
+
+
+def features_from_spectrum(spec, scaler=None, mel_wts=None):
+    """datasets.py:287-290 on a given (T, 601, 4) spectrum -> z-scored (MEL (T,64,4), IV (T,64,3)) float64."""
+    if mel_wts is None:
+        mel_wts = mel_filterbank()
+    if scaler is None:
+        scaler = unit_scaler()
+    mel = (logmel(spec, mel_wts) - scaler["MEL"]["mean"]) / scaler["MEL"]["std"]
+    iv = (foa_intensity(spec, mel_wts) - scaler["IV"]["mean"]) / scaler["IV"]["std"]
+    return mel, iv
 
 
 def get_feature(audio, scaler=None, mel_wts=None):

@@ -577,6 +577,64 @@ def gen_scaler():
                             iv_mean=s["IV"]["mean"], iv_std=s["IV"]["std"])
 
 
+def gen_features_ref():
+    """a5 / a6 pinned to the reference's OWN NumPy code (datasets.py:260-292): the real ``FeatureLabelProcessor`` methods
+    ``get_logmel_spectrogram`` (the ``np.dot(mag, mel_wts)`` step and channel loop), ``get_melscale_foa_intensity_vectors`` and
+    ``get_feature`` (frame counts, z-score with the shipped DCASE2021 ``scaler_wts.pkl``) run here with only the three
+    librosa calls shimmed (``core.stft`` hands back an injected spectrum, ``power_to_db`` / ``filters.mel`` are the oracle's
+    restatements -- those three stay "parity unpinned").  Two cases:
+      spec_* : a seeded random complex spectrum (T + 1 = 13 frames, correlated channels, 100 dB of dynamic range) --
+               the fixture stores the generator seed and the reference's outputs, the test regenerates the spectrum;
+      audio_*: one second of seeded 4-channel noise + tones through the oracle's STFT (what ``core.stft`` returns), so the
+               whole audio -> (7, T, 64) float32 chain after the STFT is the reference's: K1 is compared against it on the GPU."""
+    import datasets as ref_datasets
+    lib = sys.modules["librosa"]
+    lib.power_to_db = ofeat.power_to_db
+    inject = {}
+
+    def stft_shim(y, n_fft, hop_length, win_length, window):      # get_stft_spectrogram calls it once per channel, in order
+        assert (n_fft, hop_length, win_length, window) == (1200, 600, 1200, "han")
+        inject["calls"] += 1
+        return inject["spec"][inject["calls"] - 1]
+    lib.core.stft = stft_shim
+    prm = make_params(12)
+    flp = ref_datasets.FeatureLabelProcessor(prm)
+    out = {}
+    # ---- case 1: injected random spectrum
+    seed, t = 20260301, 12
+    spec = ofeat.synthetic_spectrum(seed, t)                 # (T + 1, 601, 4) complex128
+    inject["spec"] = [np.ascontiguousarray(spec[:, :, c].T) for c in range(4)]    # librosa layout: (601, frames) per channel
+    inject["calls"] = 0
+    audio_len = t * 600
+    (mel_z, iv_z), nb_label = flp.get_feature(np.zeros((audio_len, 4)))
+    lin = spec[:t]
+    out.update(spec_seed=np.int64(seed), spec_t=np.int64(t), spec_nb_label_frames=np.int64(nb_label),
+               spec_mel_z=mel_z, spec_iv_z=iv_z, spec_iv_raw=flp.get_melscale_foa_intensity_vectors(lin),
+               spec_logmel_raw=flp.get_logmel_spectrogram(lin))
+    lib.power_to_db = lambda s: s                            # the np.dot(|X|^2, mel_wts) step alone
+    out["spec_melpow"] = flp.get_logmel_spectrogram(lin)
+    lib.power_to_db = ofeat.power_to_db
+    # ---- case 2: audio through the oracle's STFT, everything after it is the reference's code
+    rng = np.random.default_rng(20260302)
+    n = 24000
+    tt = np.arange(n) / 24000.0
+    pcm = rng.normal(0.0, 0.05, size=(n, 4))
+    pcm[:, 0] += 0.2 * np.sin(2 * np.pi * 440.0 * tt)
+    pcm[:, 1] += 0.1 * np.sin(2 * np.pi * 440.0 * tt + 0.3)
+    pcm[:, 3] -= 0.15 * np.sin(2 * np.pi * 3000.0 * tt)
+    pcm[n // 2:] *= 1e-3                                      # second half 60 dB down: the top_db clip is active
+    pcm16 = np.clip(np.round(pcm * 32768.0), -32768, 32767).astype(np.int16)
+    audio = pcm16 / 32768.0 + 1e-8                           # datasets.py:147
+    full = ofeat.stft_all_frames(audio)                      # (T + 1, 601, 4)
+    inject["spec"] = [np.ascontiguousarray(full[:, :, c].T) for c in range(4)]
+    inject["calls"] = 0
+    (mel_z, iv_z), nb_label = flp.get_feature(audio)
+    feat = np.concatenate([mel_z.transpose(2, 0, 1), iv_z.transpose(2, 0, 1)], 0).astype(np.float32)   # datasets.py:158-160
+    out.update(audio_pcm16=pcm16, audio_feat=feat, audio_nb_label_frames=np.int64(nb_label))
+    np.savez_compressed(os.path.join(HERE, "features_ref.npz"), **out)
+    print("features_ref.npz", {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -595,3 +653,4 @@ if __name__ == "__main__":
     gen_rotation()
     gen_conformer()
     gen_scaler()
+    gen_features_ref()

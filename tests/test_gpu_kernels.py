@@ -524,6 +524,22 @@ def test_features_match_oracle(ops):
         assert float(out_cl8[b, :, :, 7].abs().max()) == 0.0
 
 
+def test_features_match_reference_made_golden(ops):
+    """K1 against ``features_ref.npz``: the features the reference's own ``get_feature`` (datasets.py:281-292, real scaler)
+    produced for this int16 clip, with only librosa's three calls shimmed when the fixture was made -- a check of the GPU
+    path that does not go through oracle/features.py's restatement of the intensity vector / z-score at all."""
+    from adyolo_amd.features import FeatureExtractor, load_scaler_npz
+    g = np.load(os.path.join(G, "features_ref.npz"))
+    scaler = load_scaler_npz(os.path.join(G, "scaler_DCASE2021.npz"))
+    pcm = torch.from_numpy(g["audio_pcm16"]).to("cuda:0").contiguous()
+    audio = ops.pcm16_to_f32(pcm).view(1, -1, 4)
+    got = FeatureExtractor(scaler, "cuda:0")(audio, channels_last8=False)[0].cpu()
+    ref = torch.from_numpy(g["audio_feat"])
+    assert_close(got[:4], ref[:4], 1e-3, "log-mel vs the reference-made golden")
+    err_iv = float((got[4:] - ref[4:]).abs().max())
+    assert err_iv < 1e-3, "IV abs err %.3e" % err_iv                   # absolute: z-scored IV reaches |x| ~ 30
+
+
 def test_chunk_features_match_oracle_per_window(ops):
     """Offline chunking on the GPU (reference src/preprocess.py:13-84: windows of chunk_window_s at chunk_stride_s, each
     written as its own file and featurised on its own): ``chunk_offsets`` computes every window's features from the

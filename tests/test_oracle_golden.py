@@ -241,6 +241,33 @@ OTHER_EVENTS = {0: [[3, 0, 10.0, 5.0]], 1: [[3, 0, 10.0, 5.0], [7, 1, -170.0, 40
                 6: [[11, 0, -90.0, 0.0], [4, 1, 90.0, 0.0], [11, 2, 0.0, 45.0]], 9: [[6, 0, 20.0, 20.0]]}
 
 
+def test_feature_chain_after_the_stft_matches_the_real_reference():
+    """a5 / a6 (and the mel product of a4) against the reference's OWN NumPy code: ``features_ref.npz`` was made by the real
+    ``FeatureLabelProcessor.get_feature`` / ``get_melscale_foa_intensity_vectors`` / ``get_logmel_spectrogram``
+    (datasets.py:260-292) on an injected spectrum with the shipped DCASE2021 scaler (tests/golden/make_golden.py
+    ``gen_features_ref``); only librosa's stft / power_to_db / filters.mel were shims there."""
+    g = np.load(os.path.join(G, "features_ref.npz"))
+    z = np.load(os.path.join(G, "scaler_DCASE2021.npz"))
+    scaler = {"MEL": {"mean": z["mel_mean"], "std": z["mel_std"]}, "IV": {"mean": z["iv_mean"], "std": z["iv_std"]}}
+    t = int(g["spec_t"])
+    spec = ofeat.synthetic_spectrum(int(g["spec_seed"]), t)[:t]          # the cut of datasets.py:257
+    mel_wts = ofeat.mel_filterbank()
+    np.testing.assert_allclose(ofeat.foa_intensity(spec, mel_wts), g["spec_iv_raw"], rtol=1e-12, atol=1e-15)
+    melpow = np.stack([np.dot(np.abs(spec[:, :, c]) ** 2, mel_wts) for c in range(4)], -1)
+    np.testing.assert_allclose(melpow, g["spec_melpow"], rtol=1e-13, atol=0)
+    np.testing.assert_allclose(ofeat.logmel(spec, mel_wts), g["spec_logmel_raw"], rtol=1e-12, atol=1e-12)
+    mel_z, iv_z = ofeat.features_from_spectrum(spec, scaler, mel_wts)
+    np.testing.assert_allclose(mel_z, g["spec_mel_z"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(iv_z, g["spec_iv_z"], rtol=1e-11, atol=1e-12)
+    assert float(np.abs(g["spec_iv_z"]).max()) > 1.0                      # the z-score (std ~ 0.01) is really exercised
+    # audio case: int16 -> /32768 + 1e-8 -> [oracle STFT] -> reference code -> (7, T, 64) float32
+    audio = ofeat.int16_to_audio(g["audio_pcm16"])
+    feat, nb_label = ofeat.get_feature(audio, scaler, mel_wts)
+    assert nb_label == int(g["audio_nb_label_frames"]) == 10 and feat.dtype == np.float32
+    np.testing.assert_allclose(feat, g["audio_feat"], rtol=0, atol=1e-6)
+    assert int(g["spec_nb_label_frames"]) == t * 600 // 2400
+
+
 def test_other_label_encoders_match_reference():
     from oracle import other_losses as ool
     from adyolo_amd.datasets import ClasswiseLabelEncoder
