@@ -87,7 +87,22 @@ def load_optimizer_state_dict(optimizer, model, sd):
     optimizer.step_count = steps.pop() if steps else 0
 
 
+def _sync_for_save(optimizer):
+    """Data parallelism: BatchNorm running statistics are per-rank (each rank sees its own shard), so before a checkpoint
+    is written EVERY rank averages them over the ranks (``FlatParameters.average_buffers``, a collective: all ranks must
+    call ``save_checkpoint`` / ``save_best``); only rank 0 then writes the file.  -> True when this process writes."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        flat = getattr(optimizer, "flat", None)
+        if flat is not None:
+            flat.average_buffers()
+        return dist.get_rank() == 0
+    return True
+
+
 def save_checkpoint(path, model, optimizer, start_epoch_nb, conf_thresh, best_log, train_remaining_file, device):
+    if not _sync_for_save(optimizer):
+        return
     torch.save({"start_epoch_nb": start_epoch_nb,
                 "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
                 "optim_state_dict": optimizer_state_dict(optimizer, model),
@@ -96,6 +111,8 @@ def save_checkpoint(path, model, optimizer, start_epoch_nb, conf_thresh, best_lo
 
 
 def save_best(path, model, optimizer, epoch_nb, conf_thresh):
+    if not _sync_for_save(optimizer):
+        return
     torch.save({"epoch_nb": epoch_nb, "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
                 "optim_state_dict": optimizer_state_dict(optimizer, model), "confidence_thresh": float(conf_thresh)}, path)
 

@@ -89,7 +89,7 @@ class FeatureExtractor:
         self.sc_mean, self.sc_rstd = f32(mean), f32(1.0 / std)
         self.mel_nnz = len(weights)
 
-    def __call__(self, audio, channels_last8=True, chunk_offsets=None, chunk_samples=None):
+    def __call__(self, audio, channels_last8=True, chunk_offsets=None, chunk_samples=None, validate_offsets=True):
         """-> (B, T, 64, 8) float32 channels-last (8th channel zero) when ``channels_last8`` (what the
         encoder consumes), else (B, 7, T, 64) in the reference's layout (datasets.py:158-160).
 
@@ -108,6 +108,14 @@ class FeatureExtractor:
                     or chunk_samples is None or chunk_samples % HOP != 0 or chunk_samples < N_FFT):
                 raise _lib.AdyoloHipError("chunk_offsets must be a contiguous int64 device tensor and chunk_samples a "
                                           "multiple of 600 (>= 1200)")
+            if validate_offsets and chunk_offsets.numel():
+                # the kernel reads audio[off : off + chunk_samples] unchecked: an offset outside the buffer would be a silent
+                # out-of-bounds read.  One host sync per call (chunking is offline preprocessing, not the train step);
+                # validate_offsets=False skips it for offsets the caller has already checked
+                lo, hi = int(chunk_offsets.min()), int(chunk_offsets.max())
+                if lo < 0 or hi + int(chunk_samples) > b * n:
+                    raise _lib.AdyoloHipError("chunk_offsets must satisfy 0 <= off <= %d - chunk_samples (got min %d, max %d)"
+                                              % (b * n, lo, hi))
             offs, b, n = chunk_offsets, chunk_offsets.numel(), int(chunk_samples)
         t = n // HOP
         layout = 1 if channels_last8 else 0

@@ -98,15 +98,33 @@ class GradSink:
 
 
 SINK = GradSink()
-_PENDING_COUNTERS = []
+_COUNTER_SCOPE = []           # innermost active bn_counter_scope's list (empty: counters are bumped immediately)
 
 
-def flush_bn_counters():
-    """``num_batches_tracked += 1`` of every BatchNorm that took a training-mode step since the last flush, as ONE
-    multi-tensor launch (36 single-element launches per step otherwise).  The encoders call it at the end of forward."""
-    if _PENDING_COUNTERS:
-        torch._foreach_add_(_PENDING_COUNTERS, 1)
-        _PENDING_COUNTERS.clear()
+class bn_counter_scope:
+    """``with bn_counter_scope():`` around an encoder forward: the ``num_batches_tracked += 1`` of every BatchNorm that takes
+    a training-mode step inside is deferred and applied as ONE multi-tensor launch on exit (36 single-element launches per
+    step otherwise).  The list belongs to the scope: a forward that raises drops its pending bumps instead of leaving
+    them for another model, and a training-mode BatchNorm used outside any scope is bumped on the spot."""
+
+    def __enter__(self):
+        self.pending = []
+        _COUNTER_SCOPE.append(self.pending)
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        _COUNTER_SCOPE.pop()
+        if exc_type is None and self.pending:
+            torch._foreach_add_(self.pending, 1)
+        self.pending = []
+        return False
+
+
+def _bump_counter(t):
+    if _COUNTER_SCOPE:
+        _COUNTER_SCOPE[-1].append(t)
+    else:
+        t.add_(1)
 
 
 class _BNState:
@@ -119,7 +137,7 @@ class _BNState:
         m = self.mod
         if training:
             ssum, mean, invstd = ops.bn_stats(x, m.running_mean, m.running_var, m.momentum, m.eps)
-            _PENDING_COUNTERS.append(m.num_batches_tracked)
+            _bump_counter(m.num_batches_tracked)
         else:
             ssum = None
             mean, invstd = ops.bn_eval_stats(m.running_mean, m.running_var, m.eps)
@@ -134,7 +152,7 @@ class _BNState:
         g, b = affine if affine is not None else (None, None)
         if update:
             out = ops.bn_stats_tiles(tile_stats, n, hw, m.running_mean, m.running_var, m.momentum, m.eps, g, b)
-            _PENDING_COUNTERS.append(m.num_batches_tracked)
+            _bump_counter(m.num_batches_tracked)
             return out
         return ops.bn_stats_tiles(tile_stats, n, hw, None, None, m.momentum, m.eps, g, b)
 

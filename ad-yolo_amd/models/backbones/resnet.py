@@ -175,6 +175,10 @@ class SEResnet34(nn.Module):
         """x: (B, 7, T, F) float32 on the GPU (reference layout), or (B, T, F, 8) when ``channels_last8``."""
         if not x.is_cuda:
             raise RuntimeError("SEResnet34 (adyolo_amd) runs on MI355X only; move the model/input to a HIP device")
+        with Fn.bn_counter_scope():          # the BatchNorm step counters of this forward: one launch on exit
+            return self._forward(x, channels_last8)
+
+    def _forward(self, x, channels_last8):
         x8 = x if channels_last8 else ops.nchw_to_nhwc8(x.contiguous().float())
         first = self.layer1[0]
         holder = Fn.BlockLink() if (Fn.FUSE_STEM_AFFINE and not first.pool and first.downsample is None) else None
@@ -194,5 +198,4 @@ class SEResnet34(nn.Module):
         y = Fn.BiGRULayerFn.apply(y, *self.lstm.layer_params(0), save)
         y = self._dropout(y)
         y = Fn.BiGRULayerFn.apply(y, *self.lstm.layer_params(1), save)
-        Fn.flush_bn_counters()
         return Fn.LNTanhFn.apply(y, self.norm.weight, self.norm.bias, self.norm.eps)

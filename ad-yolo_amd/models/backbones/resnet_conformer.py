@@ -247,6 +247,10 @@ class ResnetConformer(nn.Module):
         """x: (B, 7, T, F) float32 on the GPU (reference layout), or (B, T, F, 8) when ``channels_last8``."""
         if not x.is_cuda:
             raise RuntimeError("ResnetConformer (adyolo_amd) runs on MI355X only; move the model/input to a HIP device")
+        with Fn.bn_counter_scope():          # the BatchNorm step counters of this forward: one launch on exit
+            return self._forward(x, channels_last8)
+
+    def _forward(self, x, channels_last8):
         x8 = x if channels_last8 else ops.nchw_to_nhwc8(x.contiguous().float())
         w = self.conv1.weight
         if w.shape[1] < 8:          # activations are padded 7 -> 8 channels: pad the weight with zero planes (copy only)
@@ -264,5 +268,4 @@ class ResnetConformer(nn.Module):
         y = y.view(b, t, c)
         y = Fn.LinearFn.apply(y, self.bottleneck.weight, None)
         y = self.conformer(y, self._rng)
-        Fn.flush_bn_counters()
         return self.t_pooling(y)

@@ -15,15 +15,20 @@ class DropoutStream:
     def __init__(self, salt):
         self.salt = int(salt)
         self.offset = 0
-        self._seed = None
+        self._base = None          # rank-independent: torch.initial_seed() mixed with the salt (what a checkpoint stores)
+        self._seed = None          # the base with this process's data-parallel rank mixed in (what the kernels get)
+
+    @staticmethod
+    def _rank():
+        return dist.get_rank() if dist.is_initialized() else int(os.environ.get("RANK", "0"))
 
     @property
     def seed(self):
         """Bound at first use: torch.initial_seed() mixed with the stream's salt and the data-parallel rank."""
         if self._seed is None:
-            rank = dist.get_rank() if dist.is_initialized() else int(os.environ.get("RANK", "0"))
-            s = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + self.salt) & _MASK64
-            self._seed = (s ^ ((rank * 0xD1B54A32D192ED03) & _MASK64)) & _MASK64
+            if self._base is None:
+                self._base = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + self.salt) & _MASK64
+            self._seed = (self._base ^ ((self._rank() * 0xD1B54A32D192ED03) & _MASK64)) & _MASK64
         return self._seed
 
     def mask(self, like, p):
@@ -48,10 +53,17 @@ class DropoutStream:
         return int((x ^ (x >> 31)) & 0xFFFFFFFF)
 
     def state(self):
-        return {"seed": self.seed, "offset": self.offset}
+        """What goes into the checkpoint's rng_state: the RANK-INDEPENDENT base seed and the offset (the one rank-0
+        checkpoint is restored on every rank; each re-applies its own rank, so resumed ranks keep drawing different masks)."""
+        _ = self.seed
+        return {"base_seed": self._base, "offset": self.offset}
 
     def set_state(self, st):
-        self._seed, self.offset = int(st["seed"]), int(st["offset"])
+        self.offset = int(st["offset"])
+        if "base_seed" in st:
+            self._base, self._seed = int(st["base_seed"]), None          # rank mixed in again at the next use
+        else:                                                            # round-2 checkpoints stored the rank-mixed seed
+            self._base, self._seed = None, int(st["seed"])
 
 
 def collect(model):

@@ -63,15 +63,33 @@ def self_launch(n_gpus, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    deadline = time.time() + 600
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()                             # exactly the PID this launcher started
-            rcs.append(-9)
+    # poll ALL children: when any rank dies, the others would sit in RCCL init / a collective until the launcher's
+    # deadline -- terminate them (exactly the PIDs started here) as soon as one exits non-zero
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("ADYOLO_BENCH_LAUNCH_TIMEOUT", "1500"))
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs) or time.time() > deadline:
+            failed = True
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=10)
+    out = b"".join(c for c in chunks if c)
+    rcs = [p.returncode if p.returncode is not None else -9 for p in procs]
     sys.stdout.write(out.decode())
     sys.stdout.flush()
     bad = [rc for rc in rcs if rc != 0]

@@ -159,3 +159,80 @@ def test_fused_adam_state_dict_uses_module_parameter_order():
         torch.testing.assert_close(back["state"][i]["exp_avg_sq"], ref_sd["state"][i]["exp_avg_sq"])
     adam2 = torch.optim.Adam(ref_params, lr=1e-3)
     adam2.load_state_dict(back)                        # and torch's own optimizer accepts what we write
+
+
+class _TinyEncoder(nn.Module):
+    """A module holding a DropoutStream and a BatchNorm buffer, like the encoders (rng.collect / rng.restore walk vars())."""
+
+    def __init__(self):
+        super().__init__()
+        from adyolo_amd.rng import DropoutStream
+        self.lin = nn.Linear(4, 4)
+        self.bn = nn.BatchNorm1d(4)
+        self.dropout_stream = DropoutStream(0x5EED)
+
+
+class _HostAdam:                                       # FusedAdam without the HIP step: only the state containers
+    def __init__(self, flat):
+        self.flat, self.lr, self.betas, self.eps, self.weight_decay = flat, 1e-3, (0.9, 0.999), 1e-8, 0.0
+        self.exp_avg, self.exp_avg_sq, self.step_count = torch.zeros_like(flat.flat), torch.zeros_like(flat.flat), 3
+
+
+def _worker_resume(rank, world, port, path, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from adyolo_amd import checkpoint
+    torch.manual_seed(100)
+    model = _TinyEncoder()
+    flat = FlatParameters(model)
+    opt = _HostAdam(flat)
+    s_before = model.dropout_stream.seed
+    model.dropout_stream.draw(1000 + rank)                     # ranks are at different offsets when the checkpoint is cut
+    model.bn.running_mean.fill_(float(rank + 1))
+    # every rank calls save_checkpoint (it averages the BatchNorm buffers over the ranks: a collective); rank 0 writes
+    checkpoint.save_checkpoint(path, model, opt, 7, 0.5, {}, [], "cpu")
+    dist.barrier()
+    assert os.path.exists(path)
+    torch.manual_seed(12345)                                   # a resumed process starts from some other seed
+    model2 = _TinyEncoder()
+    opt2 = _HostAdam(FlatParameters(model2))
+    ck = checkpoint.load_checkpoint(path, model2, opt2, device="cpu")
+    st = model2.dropout_stream
+    out.put((rank, s_before, st.seed, st.offset, float(model2.bn.running_mean[0]), ck["start_epoch_nb"], opt2.step_count))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_resume_keeps_rank_distinct_dropout_seeds_and_saves_averaged_buffers(tmp_path):
+    """the ONE rank-0 checkpoint is restored on every rank; the dropout stream stores its rank-independent
+    base seed and re-applies the rank on restore, so resumed ranks keep drawing different masks (and each continues its
+    own pre-checkpoint seed); offsets are rank 0's on every rank; the saved running statistics are the rank average."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    path = str(tmp_path / "model_ckpt.h5")
+    procs = [ctx.Process(target=_worker_resume, args=(r, 2, port, path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, b0, s0, o0, rm0, e0, c0), (_, b1, s1, o1, rm1, e1, c1) = got
+    assert s0 != s1, "resumed ranks must not share one dropout seed"
+    assert (s0, s1) == (b0, b1), "each rank continues the seed it had before the checkpoint"
+    assert o0 == o1 == 1000, "offsets come from the rank-0 checkpoint"
+    assert rm0 == rm1 == 1.5 and e0 == e1 == 7 and c0 == c1 == 3
+
+
+def test_dropout_stream_accepts_round2_state():
+    """Checkpoints written before the base seed was stored carry the rank-mixed ``seed``: still restorable (verbatim)."""
+    from adyolo_amd.rng import DropoutStream
+    s = DropoutStream(1)
+    s.set_state({"seed": 1234567, "offset": 8})
+    assert s.seed == 1234567 and s.offset == 8
+    torch.manual_seed(5)
+    a, b = DropoutStream(2), DropoutStream(2)
+    a.draw(16)
+    b.set_state(a.state())
+    assert b.seed == a.seed and b.offset == 16

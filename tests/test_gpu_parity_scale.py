@@ -563,3 +563,118 @@ def test_grad_sink_equals_autograd_accumulation(ops):
     # (a gradient may legitimately be all zero -- an SE bottleneck whose ReLU is dead for the whole batch -- but not many)
     nonzero = sum(float(grads[1][off:off + n].abs().sum()) > 0 for off, n in flat.offsets)
     assert nonzero >= 0.95 * len(flat.offsets), (nonzero, len(flat.offsets))
+
+
+# ------------------------------------------------------------------------------ BASELINE configs 3 and 5 on the real model
+def test_config3_dcase2022_c13_train_step_matches_oracle(ops):
+    """BASELINE config 3's model on one device: DCASE2022 = 13 classes (src/configs/hyp_data_DCASE2022.yaml:3) -> head
+    256 -> 8*4*5*16 = 2560 logits, C = 13 loss and label rows, features z-scored with the shipped DCASE2022 scaler
+    (tests/golden/scaler_DCASE2022.npz = the reference's data/DCASE2022_SELD/scaler_wts.pkl).  One training step from raw
+    int16-range audio: features, logits, loss (1e-3) and parameter gradients (stem, a stage-3 block, GRU, the 2560-wide
+    head layer) against the CPU oracle on the same inputs."""
+    from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
+    from adyolo_amd.features import FeatureExtractor, load_scaler_npz
+    from adyolo_amd.datasets import synthetic_audio, synthetic_targets
+    from oracle import features as ofeat, seresnet as onet, adyolo_loss as oloss
+    scaler = load_scaler_npz(os.path.join(G, "scaler_DCASE2022.npz"))
+    prm = _params(13)
+    torch.manual_seed(100)
+    model = WrapperModel((1, 7, 80, 64), (), prm).to("cuda:0")
+    assert model.head.yolo_head[1].weight.shape == (2560, 256)
+    crit = WrapperCriterion(prm)
+    model.train()
+    model.encoder.lstm.dropout = 0.0
+    audio = synthetic_audio(3, 24000 * 2, seed=33)                      # 3 clips x 2 s -> T = 80, T' = 20
+    target = synthetic_targets(3, 20, 13, seed=33)
+    assert int(target[:, 4].max()) == 12                                # class 12 only exists with 13 classes
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    feat = FeatureExtractor(scaler, "cuda:0")(audio.to("cuda:0"), channels_last8=True)
+    logit = model(feat, channels_last8=True)
+    loss = crit(logit, target)
+    loss.backward()
+    torch.cuda.synchronize()
+    f_ref = torch.stack([torch.from_numpy(ofeat.get_feature(audio[b].double().numpy(), scaler)[0]) for b in range(3)])
+    names = ["encoder.conv1.weight", "encoder.layer3.2.conv2.weight", "encoder.layer3.2.se.fc.0.weight",
+             "encoder.lstm.weight_hh_l1_reverse", "head.yolo_head.0.weight", "head.yolo_head.1.weight", "head.yolo_head.1.bias"]
+    for n in names:
+        sd[n].requires_grad_(True)
+    logit_ref = onet.model_forward(sd, f_ref, training=True)
+    loss_ref = oloss.adyolo_loss(logit_ref, target, 13)
+    loss_ref.backward()
+    assert logit_ref.shape == (3, 20, 2560)
+    assert float((feat[..., :7].permute(0, 3, 1, 2).cpu() - f_ref).abs().max()) < 1e-3
+    assert float((logit.detach().cpu() - logit_ref).abs().max()) <= 1e-3 * max(1.0, float(logit_ref.abs().max()))
+    assert abs(float(loss) - float(loss_ref)) <= 1e-3 * abs(float(loss_ref)), (float(loss), float(loss_ref))
+    named = dict(model.named_parameters())
+    for n in names:
+        got, ref = named[n].grad.cpu(), sd[n].grad
+        cos = float(torch.dot(got.reshape(-1).double(), ref.reshape(-1).double()) / (got.double().norm() * ref.double().norm()))
+        # toy shapes (T = 80) are ill-conditioned through 16 BatchNorm'd blocks: the statistical bound of DESIGN section 7
+        assert cos >= 0.999 and _rel(got, ref) <= 5e-2, "%s: cosine %.6f, max dev %.2e of absmax" % (n, cos, _rel(got, ref))
+    for n in ("head.yolo_head.1.weight", "head.yolo_head.1.bias", "head.yolo_head.0.weight"):
+        assert _rel(named[n].grad.cpu(), sd[n].grad) <= 1e-3, n         # the C = 13 loss gradient itself, through the head only
+
+
+def test_config5_adpit_bs64_train_step_matches_oracle(ops):
+    """BASELINE config 5's plugin surface at its batch size: se-resnet34 + ADPIT head (256 -> 9 * 12, tanh) + ADPIT loss
+    (linearheads.py:70-86, loss.py:70-153) on 64 x 20 s chunks.  The training-mode forward loss of the whole model vs the
+    oracle run on the same K1 features (1e-3; features are compared with the oracle elsewhere), then one ``TrainStep``
+    (gradient sink, fused Adam) on raw audio: same loss value, every parameter finite and moved."""
+    import time
+    from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
+    from adyolo_amd.features import FeatureExtractor
+    from adyolo_amd.datasets import synthetic_audio, ClasswiseLabelEncoder
+    from adyolo_amd.train import TrainStep
+    from oracle import seresnet as onet, other_losses as ol
+    B, n = 64, 24000 * 20
+    prm = _params(12)
+    prm["args"]["loss"] = "adpit"
+    torch.manual_seed(100)
+    model = WrapperModel((1, 7, 800, 64), (), prm).to("cuda:0")
+    crit = WrapperCriterion(prm)
+    model.train()
+    model.encoder.lstm.dropout = 0.0
+    audio = synthetic_audio(B, n, seed=55).to("cuda:0")
+    rng = np.random.default_rng(55)
+    enc = ClasswiseLabelEncoder(12)
+    labels = []
+    for b in range(B):
+        ev = {}
+        for fr in range(200):
+            k = rng.choice(4, p=[0.4, 0.35, 0.2, 0.05])
+            if k:        # same-class overlaps included: they exercise the B / C permutation targets of ADPIT
+                ev[fr] = [[int(rng.integers(0, 4)), j, float(rng.uniform(-180, 180)), float(rng.uniform(-60, 60))] for j in range(k)]
+        labels.append(enc.get_adpit_label(ev, 200))
+    target = torch.stack(labels)                                          # (64, 200, 6, 4, 12)
+    fx = FeatureExtractor(None, "cuda:0")
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        feat = fx(audio, channels_last8=True)
+        out = model(feat, channels_last8=True)
+        loss_fwd = float(crit(out, target))
+        f_cpu = feat[..., :7].permute(0, 3, 1, 2).contiguous().cpu()
+    enc_sd, _ = onet.split_state_dict(sd)
+    t0 = time.time()
+    with torch.no_grad():
+        y = onet.encoder_forward(enc_sd, f_cpu, training=True)
+        raw = torch.nn.functional.linear(torch.nn.functional.linear(y, sd["head.adpit_head.0.weight"], sd["head.adpit_head.0.bias"]),
+                                         sd["head.adpit_head.1.weight"], sd["head.adpit_head.1.bias"])
+        out_ref = torch.tanh(raw)
+        loss_ref = float(ol.adpit_loss(out_ref, target, 12))
+    print("oracle forward at 64 x 20 s: %.1f s" % (time.time() - t0))
+    assert out.shape == (B, 200, 108)
+    assert float((out.cpu() - out_ref).abs().max()) <= 1e-3
+    assert abs(loss_fwd - loss_ref) <= 1e-3 * abs(loss_ref), (loss_fwd, loss_ref)
+    # the BatchNorm running statistics moved in the no_grad forward above: rebuild so TrainStep starts from the same state
+    torch.manual_seed(100)
+    model = WrapperModel((1, 7, 800, 64), (), prm).to("cuda:0")
+    model.encoder.lstm.dropout = 0.0
+    trainer = TrainStep(model, crit, fx, prm)
+    before = trainer.flat.flat.clone()
+    l0 = float(trainer.step(audio, target.to("cuda:0")))
+    l1 = float(trainer.step(audio, target.to("cuda:0")))
+    torch.cuda.synchronize()
+    assert abs(l0 - loss_ref) <= 1e-3 * abs(loss_ref), (l0, loss_ref)
+    assert np.isfinite(l1) and l1 < l0
+    moved = (trainer.flat.flat != before)[:trainer.flat.numel]
+    assert bool(torch.isfinite(trainer.flat.flat).all()) and float(moved.float().mean()) > 0.99
