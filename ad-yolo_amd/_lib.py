@@ -64,6 +64,8 @@ SIGNATURES = {
     "adyolo_ln_tanh_bwd": (I, [P] * 8 + [L, I, F, P]),
     "adyolo_dropout_mask": (I, [P, L, F, U64, U64, P]),
     "adyolo_dropout_apply": (I, [P, P, L, F, U64, U64, P]),
+    "adyolo_dropout_apply_dev": (I, [P, P, L, F, U64, U64, P, P]),
+    "adyolo_counter_add": (I, [P, U64, P]),
     "adyolo_loss_workspace_words": (L, [I, I, I, I]),
     "adyolo_loss_fwd_bwd": (I, [P] * 6 + [I] * 7 + [P, P, F, F, F, F, P]),
     "adyolo_yolo_decode": (I, [P, P, L, I, I, I, I, F, F, F, P]),
@@ -100,6 +102,7 @@ SIGNATURES = {
     "adyolo_mask_ranges": (I, [P, P, I, I, I, I, P]),
     "adyolo_colstats": (I, [P, P, P, L, I, P]),
     "adyolo_adam_step": (I, [P] * 4 + [L, F, F, F, F, F, I, F, P]),
+    "adyolo_adam_step_dev": (I, [P] * 4 + [L, F, F, F, F, F, P, P, F, P]),
 }
 
 _lib = None

@@ -18,10 +18,18 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// DEV: step_size / inv_sqrt_bc2 come from device memory (`bc`, written by adam_prep_kernel from a device-side step
+// counter), so that a launch recorded in a hipGraph does the right bias correction at every replay
+template <bool DEV>
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                    float *__restrict__ m, float *__restrict__ v, long n, float beta1,
                                                    float beta2, float eps, float wd, float step_size,
-                                                   float inv_sqrt_bc2, float grad_scale) {
+                                                   float inv_sqrt_bc2, float grad_scale,
+                                                   const float *__restrict__ bc) {
+    if (DEV) {
+        step_size = bc[0];
+        inv_sqrt_bc2 = bc[1];
+    }
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         float gi = g[i] * grad_scale;
         const float pi = p[i];
@@ -35,6 +43,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
         v[i] = vi;
     }
 }
+
+// step counter += 1 on the device; bc = {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)} in double like the host entry point
+__global__ void adam_prep_kernel(unsigned long long *__restrict__ step, float *__restrict__ bc, float lr, float beta1,
+                                 float beta2) {
+    const unsigned long long s = *step + 1ull;
+    *step = s;
+    const double bc1 = 1.0 - pow((double)beta1, (double)s);
+    const double bc2 = 1.0 - pow((double)beta2, (double)s);
+    bc[0] = (float)((double)lr / bc1);
+    bc[1] = (float)(1.0 / sqrt(bc2));
+}
+
+__global__ void counter_add_kernel(unsigned long long *__restrict__ c, unsigned long long inc) { *c += inc; }
 
 __global__ __launch_bounds__(256) void nchw_to_nhwc8_kernel(const float *__restrict__ x, float *__restrict__ y, int C,
                                                             long HW, long total) {
@@ -66,9 +87,33 @@ extern "C" int adyolo_adam_step(float *param, const float *grad, float *exp_avg,
     const float step_size = (float)((double)lr / bc1);
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     const long g = (n + 255) / 256;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, as_stream(stream), param, grad,
-                       exp_avg, exp_avg_sq, n, beta1, beta2, eps, weight_decay, step_size, inv_sqrt_bc2, grad_scale);
+    hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, as_stream(stream), param,
+                       grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, weight_decay, step_size, inv_sqrt_bc2, grad_scale,
+                       (const float *)nullptr);
     return check_launch("adam_step");
+}
+
+extern "C" int adyolo_adam_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long n, float lr,
+                                    float beta1, float beta2, float eps, float weight_decay, uint64_t *step_dev,
+                                    float *bc_dev, float grad_scale, void *stream) {
+    ADYOLO_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step_dev && bc_dev, ADYOLO_EINVAL,
+                   "adam_step_dev: bad arguments");
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned long long *>(step_dev), bc_dev,
+                       lr, beta1, beta2);
+    int rc = check_launch("adam_prep");
+    if (rc) return rc;
+    const long g = (n + 255) / 256;
+    hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, st, param, grad, exp_avg,
+                       exp_avg_sq, n, beta1, beta2, eps, weight_decay, 0.f, 0.f, grad_scale, (const float *)bc_dev);
+    return check_launch("adam_step_dev");
+}
+
+extern "C" int adyolo_counter_add(uint64_t *counter, uint64_t inc, void *stream) {
+    ADYOLO_REQUIRE(counter, ADYOLO_EINVAL, "counter_add: null pointer");
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, as_stream(stream),
+                       reinterpret_cast<unsigned long long *>(counter), (unsigned long long)inc);
+    return check_launch("counter_add");
 }
 
 extern "C" int adyolo_nchw_to_nhwc8(const float *x, float *y, int B, int C, int H, int W, void *stream) {

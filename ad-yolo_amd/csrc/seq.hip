@@ -434,8 +434,12 @@ __global__ void dropout_mask_kernel(float *__restrict__ mask, long n, float p, f
 
 // y = x * mask with the SAME mask values dropout_mask_kernel writes for (seed, offset) -- generated on the fly, so neither
 // the forward nor the backward pass (dx = dy * mask: the same call on dy) moves a mask tensor
+// offset_dev (may be null): a device-side running offset added to `offset` -- a launch recorded in a hipGraph then draws a
+// fresh part of the stream at every replay (the host advances the counter with adyolo_counter_add at the end of a step)
 __global__ __launch_bounds__(256) void dropout_apply_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, long n4,
-                                                            float p, float keep_scale, uint64_t seed, uint64_t offset) {
+                                                            float p, float keep_scale, uint64_t seed, uint64_t offset,
+                                                            const uint64_t *__restrict__ offset_dev) {
+    if (offset_dev) offset += *offset_dev;
     const uint64_t s0 = splitmix64(seed);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const float4 v = x[i];
@@ -545,14 +549,19 @@ extern "C" int adyolo_ln_bwd(const float *dy, const float *x, const float *gamma
     return check_launch("ln_bwd_final");
 }
 
-extern "C" int adyolo_dropout_apply(const float *x, float *y, long n, float p, uint64_t seed, uint64_t offset, void *stream) {
+extern "C" int adyolo_dropout_apply_dev(const float *x, float *y, long n, float p, uint64_t seed, uint64_t offset,
+                                        const uint64_t *offset_dev, void *stream) {
     ADYOLO_REQUIRE(x && y && n > 0 && n % 4 == 0 && p >= 0.f && p < 1.f, ADYOLO_EINVAL,
                    "dropout_apply: n must be a positive multiple of 4, 0 <= p < 1");
     const long n4 = n / 4, g = (n4 + 255) / 256;
     hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const float4 *>(x), reinterpret_cast<float4 *>(y), n4, p, 1.0f / (1.0f - p), seed,
-                       offset);
+                       offset, offset_dev);
     return check_launch("dropout_apply");
+}
+
+extern "C" int adyolo_dropout_apply(const float *x, float *y, long n, float p, uint64_t seed, uint64_t offset, void *stream) {
+    return adyolo_dropout_apply_dev(x, y, n, p, seed, offset, nullptr, stream);
 }
 
 extern "C" int adyolo_dropout_mask(float *mask, long n, float p, uint64_t seed, uint64_t offset, void *stream) {

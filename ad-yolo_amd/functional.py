@@ -498,14 +498,14 @@ class DropoutHashFn(torch.autograd.Function):
     kernel -- the same mask values ``DropoutFn`` would read from a tensor, without the tensor."""
 
     @staticmethod
-    def forward(ctx, x, p, seed, offset):
-        ctx.key = (p, seed, offset)
-        return ops.dropout_apply(_c(x), p, seed, offset)
+    def forward(ctx, x, p, seed, offset, offset_dev=None):
+        ctx.key = (p, seed, offset, offset_dev)
+        return ops.dropout_apply(_c(x), p, seed, offset, offset_dev)
 
     @staticmethod
     def backward(ctx, dy):
-        p, seed, offset = ctx.key
-        return ops.dropout_apply(_c(dy), p, seed, offset), None, None, None
+        p, seed, offset, offset_dev = ctx.key
+        return ops.dropout_apply(_c(dy), p, seed, offset, offset_dev), None, None, None, None
 
 
 class ADYOLOLossFn(torch.autograd.Function):

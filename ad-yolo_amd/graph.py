@@ -1,0 +1,177 @@
+"""hipGraph capture of the hot path: one graph per input shape, replayed step after step.
+
+Why: a train step of se-resnet34 + adyolo is ~770 kernel launches issued through ctypes from Python autograd nodes
+(~15-25 us of host time each).  At the benchmark shape (64 x 60 s) 150 ms of kernel time hide that; at the REFERENCE's own
+shapes -- 16 x 20 s training chunks (src/configs/hyp_train.yaml:3), one 60 s clip at evaluation (src/train.py:130-133,
+src/test.py:81) -- the GPU work is shorter than its launch sequence and the step is host-bound.  Every entry point of
+libadyolo_hip.so takes its stream, never allocates and never synchronises, so the whole step (K1 features -> forward ->
+loss -> backward -> Adam) records into ONE hipGraph (``torch.cuda.CUDAGraph`` is hipGraph on ROCm; PyTorch is plumbing:
+the private memory pool and the capture stream).
+
+What had to move to the device for that: nothing in a recorded launch may change from step to step, so the Adam step
+counter (``adyolo_adam_step_dev``) and the running offset of the dropout stream (``adyolo_dropout_apply_dev`` +
+``adyolo_counter_add``) live in device memory and are advanced by the graph itself; the AD-YOLO target list (M rows, M
+varies from batch to batch) is padded to a fixed capacity with rows the assignment kernel skips (batch index -1).
+
+Results are bit-identical to the eager path (tests/test_gpu_graph.py compares losses and parameters with torch.equal).
+"""
+import torch
+
+from . import functional as Fn
+from . import ops
+from . import rng as _rng
+
+TARGET_QUANTUM = 4096          # AD-YOLO target rows are padded up to a multiple of this (bounds the number of graphs)
+
+
+class _Entry:
+    __slots__ = ("graph", "audio", "target", "loss", "deltas", "n_replays")
+
+
+class StepGraphs:
+    """The captured steps of one ``train.TrainStep`` (single process).  ``step(audio, target)``: the first call at a new
+    (audio shape, target capacity) runs eagerly (lazy initialisations, allocator warm-up -- and it IS a real step, nothing
+    is discarded), the second records the graph, every call from then on copies the inputs into the graph's static
+    buffers (skipped when the caller already works in them: ``static_inputs``) and replays it."""
+
+    def __init__(self, trainer, warm_calls=1):
+        self.trainer = trainer
+        self.warm_calls = warm_calls
+        self.entries = {}
+        self.seen = {}
+        self.streams = _rng.streams(trainer.model)
+        self.captures = self.replays = self.eager_steps = 0
+
+    # ---------------------------------------------------------------------------------------- input handling
+    @staticmethod
+    def _capacity(target):
+        if target.dim() == 2 and target.shape[1] == 7:        # AD-YOLO rows (M, 7): M varies per batch
+            return ((target.shape[0] + TARGET_QUANTUM - 1) // TARGET_QUANTUM) * TARGET_QUANTUM
+        return None
+
+    def _key(self, audio, target):
+        cap = self._capacity(target)
+        return (tuple(audio.shape), cap if cap is not None else tuple(target.shape))
+
+    def static_inputs(self, audio_shape, target_like):
+        """(audio, target) buffers of the graph for this shape once it exists (else None): a producer may write the next
+        batch straight into them and pass them to ``step`` (no copy then)."""
+        ent = self.entries.get((tuple(audio_shape), self._capacity(target_like) or tuple(target_like.shape)))
+        return (ent.audio, ent.target) if ent is not None else None
+
+    def _load(self, ent, audio, target):
+        if audio.data_ptr() != ent.audio.data_ptr():
+            ent.audio.copy_(audio, non_blocking=True)
+        if target.data_ptr() != ent.target.data_ptr():
+            if self._capacity(target) is not None:
+                m = target.shape[0]
+                ent.target[:m].copy_(target, non_blocking=True)
+                if m < ent.target.shape[0]:
+                    ent.target[m:, 0].fill_(-1.0)           # rows the assignment kernel skips (csrc/loss.hip: b < 0)
+            else:
+                ent.target.copy_(target, non_blocking=True)
+
+    # ---------------------------------------------------------------------------------------- capture / replay
+    def _capture(self, key, audio, target):
+        tr = self.trainer
+        dev = audio.device
+        ent = _Entry()
+        ent.audio = torch.empty_like(audio)
+        cap = self._capacity(target)
+        if cap is not None:
+            ent.target = torch.full((cap, 7), -1.0, dtype=torch.float32, device=dev)
+        else:
+            ent.target = torch.empty(tuple(target.shape), dtype=torch.float32, device=dev)
+        ent.n_replays = 0
+        self._load(ent, audio, target)
+        # host-side state the captured step advances: put back afterwards (recording runs nothing), re-applied per replay
+        step0 = tr.optimizer.step_count
+        tr.optimizer.sync_device_step()
+        for s in self.streams:
+            s.sync_device()
+            s.begin_capture(dev)
+            s.sync_device()
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph):
+                loss = tr.step_eager(ent.audio, ent.target)
+                for s in self.streams:
+                    ops.counter_add_(s.dev, s.offset - s.capture_base)
+        finally:
+            ent.deltas = [s.end_capture() for s in self.streams]
+            tr.optimizer.step_count = step0
+            tr.optimizer._dev_step_value = step0
+        ent.graph, ent.loss = graph, loss
+        self.entries[key] = ent
+        self.captures += 1
+        return ent
+
+    def step(self, audio, target):
+        tr = self.trainer
+        target = target.to(torch.float32)
+        key = self._key(audio, target)
+        ent = self.entries.get(key)
+        if ent is None:
+            n = self.seen.get(key, 0)
+            self.seen[key] = n + 1
+            if n < self.warm_calls:
+                self.eager_steps += 1
+                return tr.step_eager(audio, target)
+            ent = self._capture(key, audio, target)
+        else:
+            self._load(ent, audio, target)
+        tr.optimizer.sync_device_step()
+        for s in self.streams:
+            s.sync_device()
+        ent.graph.replay()
+        tr.optimizer.replayed()
+        for s, d in zip(self.streams, ent.deltas):
+            s.replayed(d)
+        ent.n_replays += 1
+        self.replays += 1
+        return ent.loss.clone()
+
+
+class ForwardGraphs:
+    """Evaluation forward (``test_epoch``, reference src/test.py:33-60: one clip at a time) as one hipGraph per clip length:
+    K1 features -> encoder + head (eval mode) -> AD-YOLO decode.  ``__call__(audio (B, n, 4))`` -> (logits, decoded or
+    None); both are the graph's static outputs, valid until the next call with the same shape."""
+
+    def __init__(self, model, features, postprocessor=None, warm_calls=1):
+        self.model, self.features, self.post = model, features, postprocessor
+        self.warm_calls = warm_calls
+        self.entries, self.seen = {}, {}
+        self.captures = self.replays = 0
+
+    def _run(self, audio):
+        out = self.model(self.features(audio, channels_last8=True), channels_last8=True)
+        dec = None
+        if self.post is not None:
+            p = self.post
+            dec = ops.yolo_decode(out.contiguous(), p.nb_classes, p.nb_grids, p.nb_anchors, p.grid_size, p.g_overlap)
+        return out, dec
+
+    def __call__(self, audio):
+        if self.model.training:
+            raise RuntimeError("ForwardGraphs records the evaluation forward: call model.eval() first")
+        key = tuple(audio.shape)
+        ent = self.entries.get(key)
+        with torch.no_grad():
+            if ent is None:
+                n = self.seen.get(key, 0)
+                self.seen[key] = n + 1
+                if n < self.warm_calls:
+                    return self._run(audio)
+                static = audio.clone()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    outs = self._run(static)
+                ent = (graph, static, outs)
+                self.entries[key] = ent
+                self.captures += 1
+            graph, static, outs = ent
+            if audio.data_ptr() != static.data_ptr():
+                static.copy_(audio, non_blocking=True)
+            graph.replay()
+            self.replays += 1
+            return outs

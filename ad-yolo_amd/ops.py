@@ -437,12 +437,26 @@ def dropout_mask(like, p, seed, offset):
     return mask
 
 
-def dropout_apply(x, p, seed, offset):
-    """x * mask, mask = dropout_mask(x, p, seed, offset) generated on the fly (no mask tensor)."""
+def dropout_apply(x, p, seed, offset, offset_dev=None):
+    """x * mask, mask = dropout_mask(x, p, seed, offset) generated on the fly (no mask tensor).
+    offset_dev (int64 tensor of one element on the device, or None): its value is added to ``offset`` inside the kernel --
+    the form a launch recorded in a hipGraph needs (``rng.DropoutStream`` while a step is being captured)."""
     _chk(x)
     y = torch.empty_like(x)
-    _c("adyolo_dropout_apply", _p(x), _p(y), x.numel(), float(p), ctypes.c_uint64(seed), ctypes.c_uint64(offset), _stream())
+    if offset_dev is None:
+        _c("adyolo_dropout_apply", _p(x), _p(y), x.numel(), float(p), ctypes.c_uint64(seed), ctypes.c_uint64(offset), _stream())
+    else:
+        _c("adyolo_dropout_apply_dev", _p(x), _p(y), x.numel(), float(p), ctypes.c_uint64(seed),
+           ctypes.c_uint64(offset & 0xFFFFFFFFFFFFFFFF), _p(offset_dev), _stream())
     return y
+
+
+def counter_add_(counter, inc):
+    """counter[0] += inc on the device (int64 tensor of one element): advances a device-side dropout offset."""
+    if not counter.is_cuda or counter.dtype != torch.int64 or counter.numel() != 1:
+        raise _lib.AdyoloHipError("counter_add_ needs a one-element int64 tensor on the device")
+    _c("adyolo_counter_add", _p(counter), ctypes.c_uint64(int(inc) & 0xFFFFFFFFFFFFFFFF), _stream())
+    return counter
 
 
 # ---------------------------------------------------------------------------------------------- loss / optim
@@ -517,6 +531,17 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999
     _chk(param, grad, exp_avg, exp_avg_sq)
     _c("adyolo_adam_step", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, betas[0], betas[1],
        eps, weight_decay, int(step), grad_scale, _stream())
+
+
+def adam_step_dev(param, grad, exp_avg, exp_avg_sq, step_dev, bc_dev, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                  weight_decay=0.0, grad_scale=1.0):
+    """``adam_step`` with the step counter on the device: step_dev (int64, one element) is incremented by the call, bc_dev
+    (2 floats) receives the bias corrections.  No argument changes from step to step (hipGraph-replayable)."""
+    _chk(param, grad, exp_avg, exp_avg_sq, bc_dev)
+    if not step_dev.is_cuda or step_dev.dtype != torch.int64 or step_dev.numel() != 1 or bc_dev.numel() < 2:
+        raise _lib.AdyoloHipError("adam_step_dev needs a one-element int64 step counter and 2 floats of scratch on the device")
+    _c("adyolo_adam_step_dev", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, betas[0], betas[1],
+       eps, weight_decay, _p(step_dev), _p(bc_dev), grad_scale, _stream())
 
 
 def nchw_to_nhwc8(x):

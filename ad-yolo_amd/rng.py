@@ -17,6 +17,11 @@ class DropoutStream:
         self.offset = 0
         self._base = None          # rank-independent: torch.initial_seed() mixed with the salt (what a checkpoint stores)
         self._seed = None          # the base with this process's data-parallel rank mixed in (what the kernels get)
+        # hipGraph support (graph.py): while a step is being CAPTURED, draws are relative to `capture_base` and the kernels
+        # add the device-side counter `dev` (which holds the stream's offset at the start of the step being replayed)
+        self.dev = None
+        self.dev_value = None      # what the host knows `dev` to hold
+        self.capture_base = None
 
     @staticmethod
     def _rank():
@@ -31,8 +36,37 @@ class DropoutStream:
             self._seed = (self._base ^ ((self._rank() * 0xD1B54A32D192ED03) & _MASK64)) & _MASK64
         return self._seed
 
+    def begin_capture(self, device):
+        if self.dev is None or self.dev.device != torch.device(device):
+            self.dev = torch.zeros(1, dtype=torch.int64, device=device)
+            self.dev_value = 0
+        self.capture_base = self.offset
+
+    def end_capture(self):
+        """-> the number of values one replay of the captured step draws; the host offset is put back (capturing ran nothing)."""
+        delta = self.offset - self.capture_base
+        self.offset, self.capture_base = self.capture_base, None
+        return delta
+
+    def sync_device(self):
+        """Make the device counter hold the host offset (no-op when it already does; one async fill otherwise)."""
+        if self.dev is not None and self.dev_value != self.offset:
+            self.dev.fill_(self.offset - (1 << 64) if self.offset >= (1 << 63) else self.offset)
+            self.dev_value = self.offset
+
+    def replayed(self, delta):
+        """A captured step was replayed: its last node advanced the device counter by ``delta``."""
+        self.offset += int(delta)
+        self.dev_value = self.offset
+
+    def _no_capture(self, what):
+        if self.capture_base is not None:
+            raise NotImplementedError("DropoutStream.%s is not hipGraph-capturable (host-computed values); "
+                                      "only draw() is" % what)
+
     def mask(self, like, p):
         from . import ops
+        self._no_capture("mask")
         m = ops.dropout_mask(like, p, self.seed, self.offset)
         self.offset += like.numel()
         return m
@@ -40,12 +74,16 @@ class DropoutStream:
     def draw(self, n):
         """(seed, offset) for ``n`` values generated inside a kernel (``ops.dropout_apply``); advances the stream by n.
         The values are the ones ``mask`` would have written."""
-        key = (self.seed, self.offset)
+        if self.capture_base is not None:
+            key = (self.seed, self.offset - self.capture_base, self.dev)
+        else:
+            key = (self.seed, self.offset)
         self.offset += int(n)
         return key
 
     def seed32(self, n):
         """A 32-bit seed for a kernel that draws ``n`` values from its own stateless hash; advances the stream by n."""
+        self._no_capture("seed32")
         x = (self.seed ^ ((self.offset * 0x9E3779B97F4A7C15) & _MASK64)) & _MASK64
         x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _MASK64
         x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _MASK64
@@ -64,6 +102,11 @@ class DropoutStream:
             self._base, self._seed = int(st["base_seed"]), None          # rank mixed in again at the next use
         else:                                                            # round-2 checkpoints stored the rank-mixed seed
             self._base, self._seed = None, int(st["seed"])
+
+
+def streams(model):
+    """Every DropoutStream attribute in ``model``, in module order."""
+    return [val for _, mod in model.named_modules() for val in vars(mod).values() if isinstance(val, DropoutStream)]
 
 
 def collect(model):

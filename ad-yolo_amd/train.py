@@ -5,6 +5,8 @@ backward -> [bucketed RCCL all-reduce] -> fused Adam.  Mirror of ``get_optimizer
 FusedAdam keeps torch.optim.Adam's hyper-parameters and produces a ``state_dict`` in the stock Adam
 format (train.py:149,236 save/restore it) while running one HIP launch over the flat parameter buffer.
 """
+import os
+
 import torch
 
 from . import functional as Fn
@@ -21,15 +23,41 @@ class FusedAdam:
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.exp_avg = torch.zeros_like(flat.flat)
         self.exp_avg_sq = torch.zeros_like(flat.flat)
-        self.step_count = 0
+        # the step counter lives ON THE DEVICE (incremented by the Adam launch itself), so that no kernel argument changes
+        # from step to step and a whole train step can be replayed from a hipGraph; `step_count` is the host's mirror of
+        # it (checkpoints, torch.optim.Adam's state_dict layout)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=flat.flat.device)
+        self.bc_dev = torch.zeros(2, dtype=torch.float32, device=flat.flat.device)
+        self._step_count = 0
+        self._dev_step_value = 0
+
+    @property
+    def step_count(self):
+        return self._step_count
+
+    @step_count.setter
+    def step_count(self, v):
+        self._step_count = int(v)
+
+    def sync_device_step(self):
+        if self._dev_step_value != self._step_count:
+            self.step_dev.fill_(self._step_count)
+            self._dev_step_value = self._step_count
+
+    def replayed(self):
+        """A captured step (graph.py) was replayed: the Adam launch inside it advanced the device counter."""
+        self._step_count += 1
+        self._dev_step_value = self._step_count
 
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()
 
     def step(self, grad_scale=1.0):
-        self.step_count += 1
-        ops.adam_step(self.flat.flat, self.flat.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
-                      self.betas, self.eps, self.weight_decay, grad_scale)
+        self.sync_device_step()
+        ops.adam_step_dev(self.flat.flat, self.flat.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_dev, self.bc_dev,
+                          self.lr, self.betas, self.eps, self.weight_decay, grad_scale)
+        self._step_count += 1
+        self._dev_step_value = self._step_count
 
     def state_dict(self):
         """torch.optim.Adam's layout with parameter indices in ``model.parameters()`` order -- the ONE format this build
@@ -55,16 +83,34 @@ class TrainStep:
     """One data-parallel optimisation step on raw audio.
 
     step(audio (B, n_samples, 4) float32 on the GPU, target (M,7)) -> loss tensor (1,) on the device (no host sync).
+
+
+    graph=True (default: the ADYOLO_GRAPH environment variable, off when unset): the whole step is recorded ONCE per input
+    shape in a hipGraph and replayed (``graph.StepGraphs``) -- ~770 kernel launches per step leave the Python / ctypes /
+    autograd path, which is what bounds the reference's own shapes (16 x 20 s chunks: the GPU work of a step is shorter than
+    its launch sequence).  The first step at a new shape runs eagerly, the second is captured; results are bit-identical to
+    the eager path.  Single-process only (under data parallelism the RCCL hooks stay eager).
     """
 
-    def __init__(self, model, criterion, feature_extractor, params=None, n_buckets=4, lr=1e-3):
+    def __init__(self, model, criterion, feature_extractor, params=None, n_buckets=4, lr=1e-3, graph=None):
         self.model, self.criterion, self.features = model, criterion, feature_extractor
         self.flat = FlatParameters(model)
         self.flat.broadcast(0)                   # no-op on one rank: all ranks start from rank 0's parameters / buffers
         self.optimizer = get_optimizers(params, self.flat) if params is not None else FusedAdam(self.flat, lr=lr)
         self.reducer = BucketedAllReduce(self.flat, n_buckets=n_buckets)
+        if graph is None:
+            graph = os.environ.get("ADYOLO_GRAPH", "0") == "1"
+        self.graphs = None
+        if graph and not self.reducer.active:
+            from .graph import StepGraphs
+            self.graphs = StepGraphs(self)
 
     def step(self, audio, target):
+        if self.graphs is not None:
+            return self.graphs.step(audio, target)
+        return self.step_eager(audio, target)
+
+    def step_eager(self, audio, target):
         self.model.train()
         feat = self.features(audio, channels_last8=True)
         output = self.model(feat, channels_last8=True)

@@ -220,7 +220,110 @@ def cpu_baseline(batch=8, clip_seconds=20, warmups=3, timed=5, budget_s=75.0):
             "thread_sweep_s": {str(k): round(v, 3) for k, v in sweep.items()},
             "sample": "median of %d train steps (after %d warm-ups) of %d x %d s clips (features on %d host threads + "
                       "fwd+loss+bwd+Adam on %d torch threads), PyTorch-CPU/NumPy oracle, %d host cpus"
-                      % (n_timed, n_warm + 1, batch, clip_seconds, min(batch, ncpu), best, ncpu)}
+                      % (n_timed, n_warm + 1, batch, clip_seconds, min(batch, ncpu), best, ncpu)
+                      + "; ONE process (the reference would run 16 DataLoader workers for the features beside the model, "
+                        "src/configs/hyp_train.yaml:4)"}
+
+
+# ---------------------------------------------------------------------------------------------- the reference's own shapes
+# Small shapes are launch-bound in eager mode (~770 launches per step through ctypes + autograd); they run from a hipGraph
+# (adyolo_amd/graph.py).  kernel_ms = sum of kernel durations per step from the committed rocprofv3 kernel trace of
+# `bench.py --only-extra <name>` (profiles/r03_small_shapes.json, tools/small_shapes_profile.sh); wall / kernel says how
+# much of the step is still not GPU work.
+EXTRA_CONFIGS = {
+    "train_bs16x20s": dict(kind="train", encoder="se-resnet34", batch=16, seconds=20, steps=10,
+                           ref="the reference's training shape: batch_size 16 (src/configs/hyp_train.yaml:3) x 20 s chunks"),
+    "train_bs8x20s": dict(kind="train", encoder="se-resnet34", batch=8, seconds=20, steps=10,
+                          ref="BASELINE.json configs[0]: bs = 8 x 20 s (the CPU-runnable plumbing case; cpu_baseline's shape)"),
+    "eval_bs1x60s": dict(kind="eval", encoder="se-resnet34", batch=1, seconds=60, steps=20,
+                         ref="test_epoch: one 60 s clip at a time (src/train.py:130-133, src/test.py:81): K1 + forward + decode"),
+    "conformer_bs32x20s": dict(kind="train", encoder="resnet-conformer", batch=32, seconds=20, steps=4,
+                               ref="BASELINE.json configs[3]: resnet-conformer + adyolo, bs = 32 x 20 s"),
+}
+
+
+def _small_shape_kernel_ms(name):
+    for fn in ("r03_small_shapes.json",):
+        try:
+            with open(os.path.join(ROOT, "profiles", fn)) as f:
+                return json.load(f).get(name, {}).get("kernel_ms_per_step")
+        except (OSError, ValueError):
+            pass
+    return None
+
+
+def run_extra_config(name, torch):
+    import adyolo_amd  # noqa: F401
+    from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
+    from adyolo_amd.features import FeatureExtractor
+    from adyolo_amd.datasets import synthetic_audio, synthetic_targets
+    from adyolo_amd.train import TrainStep
+    from adyolo_amd.graph import ForwardGraphs
+    from adyolo_amd.postprocess import LabelPostProcessor
+    cfg = EXTRA_CONFIGS[name]
+    device = "cuda:%d" % torch.cuda.current_device()
+    B, n = cfg["batch"], 24000 * cfg["seconds"]
+    T = n // 600
+    prm = params(device)
+    prm["args"]["encoder"] = cfg["encoder"]
+    prm["train_config"].update(conf_thresh=0.5, clss_thresh=0.5, unify_thresh=15.0, nms="conn-merge")
+    fx = FeatureExtractor(None, device)
+    audio = synthetic_audio(B, n, seed=4321).to(device)
+    target = synthetic_targets(B, T // 4, 12, seed=4321).to(device)
+    graphable = cfg["encoder"] == "se-resnet34"
+    ent = {"workload": cfg["ref"], "batch": B, "clip_seconds": cfg["seconds"], "steps": cfg["steps"]}
+
+    def timed(fn, k, warm):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / k * 1e3, out
+
+    if cfg["kind"] == "train":
+        res = {}
+        for mode in (("hipgraph", "eager") if graphable else ("eager",)):
+            torch.manual_seed(100)
+            model = WrapperModel((1, 7, T, 64), (), prm).to(device)
+            tr = TrainStep(model, WrapperCriterion(prm), fx, prm, graph=(mode == "hipgraph"))
+            ms, loss = timed(lambda: tr.step(audio, target), cfg["steps"], 3)
+            res[mode] = (ms, float(loss.reshape(-1)[0]))
+            del tr, model
+        mode = "hipgraph" if graphable else "eager"
+        ms = res[mode][0]
+        ent.update({"mode": mode, "ms_per_step": round(ms, 3), "audio_s_per_s": round(B * cfg["seconds"] / (ms * 1e-3), 1),
+                    "final_loss": round(res[mode][1], 6)})
+        if graphable:
+            ent["eager_ms_per_step"] = round(res["eager"][0], 3)
+            ent["graph_equals_eager_loss"] = res["hipgraph"][1] == res["eager"][1]
+    else:
+        torch.manual_seed(100)
+        model = WrapperModel((1, 7, T, 64), (), prm).to(device)
+        model.eval()
+        post = LabelPostProcessor(prm)
+        fg = ForwardGraphs(model, fx, post)
+        def graphed():
+            o, d = fg(audio)
+            return o, d.cpu()                        # the decoded tensor goes to the host for the NMS, like postprocess.decode
+        ms, outs = timed(graphed, cfg["steps"], 3)
+
+        def eager():
+            with torch.no_grad():
+                o = model(fx(audio, channels_last8=True), channels_last8=True)
+                return o, post.decode(o)
+        ms_e, outs_e = timed(eager, max(3, cfg["steps"] // 2), 2)
+        ent.update({"mode": "hipgraph", "ms_per_step": round(ms, 3), "clips_per_s": round(B / (ms * 1e-3), 1),
+                    "audio_s_per_s": round(B * cfg["seconds"] / (ms * 1e-3), 1), "eager_ms_per_step": round(ms_e, 3),
+                    "graph_equals_eager_logits": bool(torch.equal(outs[0], outs_e[0])),
+                    "note": "both figures include the device-to-host copy of the decoded tensor (the NMS runs on the host)"})
+    k_ms = _small_shape_kernel_ms(name)
+    ent["kernel_ms_per_step"] = k_ms
+    ent["wall_over_kernel"] = round(ent["ms_per_step"] / k_ms, 3) if k_ms else None
+    torch.cuda.empty_cache()
+    return ent
 
 
 # ---------------------------------------------------------------------------------------------- worker
@@ -233,6 +336,9 @@ def main():
     ap.add_argument("--seconds", type=int, default=60, help="clip length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true", help="skip the two extra instrumented steps")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs block (the reference's own shapes)")
+    ap.add_argument("--only-extra", default=None, help="run ONE extra config by name and print its entry (profiling)")
+    ap.add_argument("--graph", action="store_true", help="replay the headline step from a hipGraph too (no per-kernel events)")
     ap.add_argument("--encoder", default="se-resnet34", choices=["se-resnet34", "resnet-conformer"],
                     help="se-resnet34 = the headline workload (BASELINE configs[1]); resnet-conformer = config 4")
     args = ap.parse_args()
@@ -248,6 +354,11 @@ def main():
     from adyolo_amd.datasets import synthetic_audio, synthetic_targets
     from adyolo_amd.train import TrainStep
     import torch.distributed as dist
+
+    if args.only_extra:
+        torch.cuda.set_device(0)
+        print(json.dumps(run_extra_config(args.only_extra, torch)), flush=True)
+        return
 
     rank, world, local_rank = adist.init_from_env("nccl")
     if world != args.gpus:
@@ -270,7 +381,7 @@ def main():
     # parity gate at the benchmark shape: the first forward loss with the benchmarked (Winograd) convolutions must equal
     # the direct implicit-GEMM path within 1e-3 (both are checked against torch / the oracle in tests/)
     parity = None
-    if args.encoder == "se-resnet34" and wino and rank == 0:
+    if args.encoder == "se-resnet34" and wino and world == 1:      # (N > 1: a rank-0-only assert would strand the other ranks)
         model.train()
         vals = {}
         with torch.no_grad():
@@ -287,7 +398,7 @@ def main():
         assert rel <= 1e-3, "Winograd vs direct loss at the bench shape: %r" % (vals,)
         torch.manual_seed(100)                     # BatchNorm running statistics moved: rebuild the model
         model = WrapperModel((1, 7, T, 64), (), prm).to(device)
-    trainer = TrainStep(model, criterion, fx, prm)
+    trainer = TrainStep(model, criterion, fx, prm, graph=args.graph)
 
     timer = KernelTimer(torch)
     # work = (algorithmic FLOPs of the 3x3 convolution, matrix FLOPs actually issued: 16/36 of that in Winograd form)
@@ -329,7 +440,7 @@ def main():
     timer.wrap(ops, "avgpool2_bwd", "avgpool2_bwd", lambda dy, *a, **k: (5 * nb(dy), 0.0), gate)
     timer.wrap(ops, "adyolo_loss", "adyolo_loss (assign + main + final)",
                lambda logit, tgt, *a, **k: (2 * nb(logit) + nb(tgt), 0.0), gate)
-    timer.wrap(ops, "adam_step", "adam", lambda p, *a, **k: (7 * nb(p), 0.0), gate)
+    timer.wrap(ops, "adam_step_dev", "adam", lambda p, *a, **k: (7 * nb(p), 0.0), gate)
     timer.wrap(ops, "bn_stats_tiles", "bn_stats_tiles", lambda st, *a, **k: (nb(st), 0.0), gate)
     timer.wrap(ops, "sap_fwd", "sap_fwd", lambda x, *a, **k: (nb(x), 0.0), gate)
     timer.wrap(ops, "sap_bwd", "sap_bwd", lambda dy, x, *a, **k: (2 * nb(x), 0.0), gate)
@@ -346,7 +457,7 @@ def main():
     for _ in range(args.warmup):
         loss = trainer.step(audio, target)
     sync()
-    timer.active = True
+    timer.active = not args.graph                  # (HIP events cannot be recorded around launches that are replayed from a graph)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.step(audio, target)
@@ -361,7 +472,7 @@ def main():
     step_ms = dt / args.steps * 1e3
 
     stages = {}
-    if rank == 0 and not args.no_stages:
+    if rank == 0 and not args.no_stages and not args.graph:
         n_inst = 2
         stage["on"] = True
         t1 = time.perf_counter()
@@ -434,6 +545,10 @@ def main():
         line["stages"].update(stages)
         if parity is not None:
             line["parity_check"] = parity
+        if world == 1 and not args.no_extra and args.encoder == "se-resnet34":
+            del trainer, model                          # the headline model's 40 GB of cached activations go back first
+            torch.cuda.empty_cache()
+            line["extra_configs"] = {name: run_extra_config(name, torch) for name in EXTRA_CONFIGS}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -262,6 +262,11 @@ int adyolo_dropout_mask(float *mask, long n, float p, uint64_t seed, uint64_t of
  * x -> y; backward: the same call on the incoming gradient); n a multiple of 4.  Replaces nn.Dropout /
  * nn.GRU(dropout=) (reference resnet.py:153, resnet_conformer.py:46-47,199-206). */
 int adyolo_dropout_apply(const float *x, float *y, long n, float p, uint64_t seed, uint64_t offset, void *stream);
+/* same, with a device-side running offset added to `offset` (offset_dev may be NULL): a launch recorded in a hipGraph
+ * draws a fresh part of the stream at every replay; adyolo_counter_add advances the counter at the end of a step. */
+int adyolo_dropout_apply_dev(const float *x, float *y, long n, float p, uint64_t seed, uint64_t offset,
+                             const uint64_t *offset_dev, void *stream);
+int adyolo_counter_add(uint64_t *counter, uint64_t inc, void *stream);
 int adyolo_mul(const float *a, const float *b, float *y, long n, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -373,6 +378,12 @@ int adyolo_foa_rotate(const float *audio, float *out, const float *cfg, int B, l
 int adyolo_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long n,
                      float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                      float grad_scale, void *stream);
+/* same update with the step counter ON THE DEVICE (one uint64, incremented by the call itself; bc_dev = 2 floats of
+ * scratch for the bias corrections): nothing in the argument list changes from step to step, so the whole train step can
+ * be recorded once in a hipGraph and replayed (train.TrainStep(graph=True)). */
+int adyolo_adam_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long n, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, uint64_t *step_dev, float *bc_dev,
+                         float grad_scale, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K9a multi-head self-attention core, flash style on the exact-fp32 matrix cores (csrc/attention.hip).

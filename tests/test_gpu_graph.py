@@ -1,0 +1,156 @@
+"""GPU: the hipGraph-replayed train step and evaluation forward (ad-yolo_amd/graph.py) against the eager path.
+
+The graph path must be the SAME arithmetic: losses and parameters are compared with ``torch.equal`` (bit for bit), with
+the inter-layer GRU dropout active (its stream offset lives on the device in graph mode), with AD-YOLO target lists of
+different lengths from step to step (padded to the graph's capacity with rows the assignment kernel skips) and across a
+checkpoint of the optimizer / dropout state."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import adyolo_amd  # noqa: F401
+    from adyolo_amd import ops as _ops
+    return _ops
+
+
+def _params(nb_classes=12, loss="adyolo"):
+    return {"args": {"device": "cuda:0", "encoder": "se-resnet34", "loss": loss},
+            "data_config": {"nb_classes": nb_classes},
+            "train_config": {"grid_size": [45, 45], "nb_anchors": 5, "train_unify": [45.0, 25.0, 10.0], "g_overlap": 0.5,
+                             "conf_thresh": 0.5, "clss_thresh": 0.5, "unify_thresh": 15.0, "nms": "conn-merge",
+                             "loss_gains": {"angular_gain": 5.0, "object_gain": 1.0, "nonobj_gain": 5.0, "class_gain": 3.0},
+                             "optim": "Adam", "lr": 1e-3, "weight_decay": 0.0}}
+
+
+def _trainer(graph, loss="adyolo", t=80):
+    from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
+    from adyolo_amd.features import FeatureExtractor
+    from adyolo_amd.train import TrainStep
+    torch.manual_seed(100)
+    prm = _params(loss=loss)
+    model = WrapperModel((1, 7, t, 64), (), prm).to("cuda:0")
+    return TrainStep(model, WrapperCriterion(prm), FeatureExtractor(None, "cuda:0"), prm, graph=graph)
+
+
+def test_adam_device_step_matches_torch(ops):
+    """adyolo_adam_step_dev: the step counter and the bias corrections live on the device (what a replayed graph needs)."""
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(4099, generator=g)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    pg = p0.to("cuda:0")
+    m, v = torch.zeros_like(pg), torch.zeros_like(pg)
+    step_dev = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+    bc = torch.zeros(2, device="cuda:0")
+    for _ in range(7):
+        grad = torch.randn(p0.numel(), generator=g)
+        ref.grad = grad.clone()
+        opt.step()
+        ops.adam_step_dev(pg, (grad * 4.0).to("cuda:0"), m, v, step_dev, bc, grad_scale=0.25)
+    torch.cuda.synchronize()
+    assert int(step_dev) == 7
+    err = float((pg.cpu() - ref.detach()).abs().max())
+    assert err <= 1e-6, err
+
+
+def test_graphed_train_step_is_bit_identical_to_eager(ops):
+    """Six steps (2 clips x 2 s, dropout 0.3 active) with target lists of different lengths: eager trainer vs graph trainer
+    (step 0 eager warm-up, step 1 recorded + replayed, steps 2-5 replayed) -- identical losses and parameters, bit for bit;
+    host mirrors (Adam step count, dropout offset) equal too."""
+    from adyolo_amd.datasets import synthetic_audio, synthetic_targets
+    audios = [synthetic_audio(2, 24000 * 2, seed=70 + i).to("cuda:0") for i in range(3)]
+    targets = [synthetic_targets(2, 20, 12, seed=80 + i) for i in range(6)]
+    targets[3] = targets[3][: targets[3].shape[0] // 2].contiguous()         # a much shorter list: padding rows in play
+    assert len({t.shape[0] for t in targets}) > 1
+    te, tg = _trainer(False), _trainer(True)
+    assert tg.graphs is not None and te.graphs is None
+    le, lg = [], []
+    for i in range(6):
+        le.append(te.step(audios[i % 3], targets[i]).clone())
+        lg.append(tg.step(audios[i % 3], targets[i]).clone())
+    torch.cuda.synchronize()
+    assert tg.graphs.captures == 1 and tg.graphs.replays == 5 and tg.graphs.eager_steps == 1
+    for i, (a, b) in enumerate(zip(le, lg)):
+        assert torch.equal(a, b), "loss of step %d: eager %r graph %r" % (i, float(a), float(b))
+    assert torch.equal(te.flat.flat, tg.flat.flat), "parameters after 6 steps"
+    assert torch.equal(te.optimizer.exp_avg_sq, tg.optimizer.exp_avg_sq)
+    assert te.optimizer.step_count == tg.optimizer.step_count == 6
+    assert int(tg.optimizer.step_dev) == 6
+    se, sg = te.model.encoder.dropout_stream, tg.model.encoder.dropout_stream
+    assert se.offset == sg.offset > 0 and int(sg.dev) == sg.offset
+    for k, v in te.model.state_dict().items():                                # BatchNorm running statistics and counters
+        assert torch.equal(v, tg.model.state_dict()[k]), k
+    assert float(le[-1]) < float(le[0])
+
+
+def test_graphed_step_survives_a_checkpoint_round_trip(ops, tmp_path):
+    """Optimizer state and dropout stream are restored from a checkpoint INTO a trainer that already holds a recorded
+    graph: the device-side counters are re-synchronised from the host mirrors and the next steps equal the eager run."""
+    from adyolo_amd import checkpoint
+    from adyolo_amd.datasets import synthetic_audio, synthetic_targets
+    audio = synthetic_audio(2, 24000 * 2, seed=91).to("cuda:0")
+    targets = [synthetic_targets(2, 20, 12, seed=92 + i) for i in range(6)]
+    te, tg = _trainer(False), _trainer(True)
+    for i in range(3):
+        te.step(audio, targets[i])
+        tg.step(audio, targets[i])
+    path = str(tmp_path / "model_ckpt.h5")
+    checkpoint.save_checkpoint(path, te.model, te.optimizer, 1, 0.5, {}, [], "cuda:0")
+    for i in range(3, 5):                                                     # the graph trainer runs ahead ...
+        tg.step(audio, targets[i])
+    checkpoint.load_checkpoint(path, tg.model, tg.optimizer, device="cuda:0")      # ... and is rolled back to step 3
+    assert tg.optimizer.step_count == 3
+    for i in range(3, 6):
+        a, b = te.step(audio, targets[i]), tg.step(audio, targets[i])
+        assert torch.equal(a, b), i
+    assert torch.equal(te.flat.flat, tg.flat.flat)
+
+
+def test_graphed_step_with_a_fixed_shape_target(ops):
+    """ADPIT (config 5): the target is a dense (B, T', 6, 4, C) tensor -- copied into the graph's static buffer as is."""
+    from adyolo_amd.datasets import synthetic_audio, ClasswiseLabelEncoder
+    enc = ClasswiseLabelEncoder(12)
+    ev = {0: [[3, 0, 10.0, 5.0]], 2: [[3, 0, 10.0, 5.0], [3, 1, -170.0, 40.0]], 5: [[1, 0, 0.0, 0.0], [2, 1, 90.0, 10.0]]}
+    target = torch.stack([enc.get_adpit_label(ev, 20), enc.get_adpit_label({}, 20)]).to("cuda:0")
+    audio = synthetic_audio(2, 24000 * 2, seed=95).to("cuda:0")
+    te, tg = _trainer(False, "adpit"), _trainer(True, "adpit")
+    for i in range(4):
+        a, b = te.step(audio, target), tg.step(audio, target)
+        assert torch.equal(a.reshape(-1), b.reshape(-1)), i
+    assert tg.graphs.replays == 3 and torch.equal(te.flat.flat, tg.flat.flat)
+
+
+def test_graphed_evaluation_forward_matches_eager(ops):
+    """test_epoch's forward (B = 1): K1 -> encoder + head (eval) -> decode, replayed from a graph, equals the eager calls
+    bit for bit, for two clip lengths (two graphs) and changing audio."""
+    from adyolo_amd.wrapper import WrapperModel
+    from adyolo_amd.features import FeatureExtractor
+    from adyolo_amd.postprocess import LabelPostProcessor
+    from adyolo_amd.graph import ForwardGraphs
+    from adyolo_amd.datasets import synthetic_audio
+    torch.manual_seed(100)
+    prm = _params()
+    model = WrapperModel((1, 7, 80, 64), (), prm).to("cuda:0")
+    model.eval()
+    fx = FeatureExtractor(None, "cuda:0")
+    post = LabelPostProcessor(prm)
+    fg = ForwardGraphs(model, fx, post)
+    for seconds in (2, 3):
+        for i in range(4):
+            audio = synthetic_audio(1, 24000 * seconds, seed=100 + 10 * seconds + i).to("cuda:0")
+            with torch.no_grad():
+                ref = model(fx(audio, channels_last8=True), channels_last8=True)
+            dec_ref = post.decode(ref)
+            out, dec = fg(audio)
+            assert torch.equal(out, ref), (seconds, i)
+            assert np.array_equal(dec.cpu().numpy(), dec_ref)
+    assert fg.captures == 2 and fg.replays == 6
+    sd = model.state_dict()
+    assert int(sd["encoder.bn1.num_batches_tracked"]) == 0                    # eval mode: nothing was updated
