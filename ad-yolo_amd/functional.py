@@ -177,7 +177,10 @@ class StemFn(torch.autograd.Function):
         if holder is not None:
             holder.affine = (scale, shift)
             if training and FUSE_BNBWD:            # the consumer's dgrad epilogue can sum this BatchNorm's backward statistics
-                holder.stem_bn = (a, mean, invstd)
+                # (a detached alias: `a` itself is this node's OUTPUT, and node -> holder -> a -> grad_fn would be a
+                #  reference cycle that keeps the node and its AccumulateGrad edges alive until the garbage collector
+                #  runs -- stale AccumulateGrad nodes from an earlier stream break hipGraph capture of the next step)
+                holder.stem_bn = (a.detach(), mean, invstd)
                 ctx.holder = holder
             out = a
         else:
