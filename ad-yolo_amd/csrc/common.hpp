@@ -33,6 +33,11 @@ inline int check_launch(const char *what) {
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Workspace initialisation as a KERNEL (defined in optim.hip), not hipMemsetAsync: a memset recorded into a hipGraph becomes a
+// memset node, and on this stack a replayed memset node was seen to land out of order with the kernels around it (the
+// per-clip maxima of K1 were reset late in about half of the replays of one evaluation graph).  n32 = number of 32-bit words.
+int fill32(void *ptr, uint32_t value, size_t n32, hipStream_t st);
+
 // v_mfma_f32_32x32x2_f32: D(32x32) += A(32x2) * B(2x32); lane l holds A[l&31][l>>5], B[l>>5][l&31];
 // D register r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {

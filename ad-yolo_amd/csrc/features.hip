@@ -368,11 +368,8 @@ extern "C" int adyolo_feat_stft_mel(const float *audio, const int64_t *clip_offs
                    MAX_CHUNKS);
     hipStream_t st = as_stream(stream);
     const int T = n_samples / FHOP;
-    hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(chan_max), (int)0xFF800000, (size_t)B * 4, st);
-    if (e != hipSuccess) {
-        set_error("feat_stft_mel: memset failed: %s", hipGetErrorString(e));
-        return (int)e;
-    }
+    int rc0 = fill32(chan_max, 0xFF800000u, (size_t)B * 4, st);          // -inf (a kernel, not a memset node: see common.hpp)
+    if (rc0) return rc0;
     hipLaunchKernelGGL(feat_stft_mel_kernel, dim3(cdiv(T, FR), B), dim3(256), 0, st, audio, reinterpret_cast<const long *>(clip_offset), twiddle, chunk_mel,
                        chunk_start, chunk_len, chunk_off, mel_w, n_chunks, n_mel_w, scaler_mean, scaler_rstd, out,
                        chan_max, n_samples, T, layout);

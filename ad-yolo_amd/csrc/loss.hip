@@ -34,6 +34,10 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) {
     return (float)((double)(long long)q * (1.0 / 4294967296.0));
 }
 
+// 8 lanes per target row: lane a of the octet owns anchor a (one decode + great-circle distance per lane instead of a
+// serial loop over the anchors: 8x the parallelism of a one-lane-per-row kernel, which was latency-bound at 137 k rows);
+// the arg-min is three shuffle steps inside the octet (ties -> the lowest anchor index, like the reference's argmin);
+// distinct-positive counts go to the header as ONE atomic per wave and threshold (ballot + popcount).
 __global__ __launch_bounds__(256) void loss_assign_kernel(const float *__restrict__ logit,
                                                           const float *__restrict__ target, LossGeom g,
                                                           unsigned *__restrict__ hdr, unsigned *__restrict__ pos_bits,
@@ -43,25 +47,30 @@ __global__ __launch_bounds__(256) void loss_assign_kernel(const float *__restric
                                                           long NA) {
     __shared__ float red_sum[4];
     __shared__ int red_cnt[4];
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = (int)(gt >> 3), a = threadIdx.x & 7;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float my_sum = 0.f;
     int my_pairs = 0;
+    float D = INFINITY, gu = 0.f, gv = 0.f;
+    long cell = 0;
+    int cl = 0;
+    bool valid = false;
     if (m < g.M) {
         const float *tr = target + (size_t)m * 7;
-        const int b = (int)tr[0], t = (int)tr[1], gi = (int)tr[2], gj = (int)tr[3], cl = (int)tr[4];
+        const int b = (int)tr[0], t = (int)tr[1], gi = (int)tr[2], gj = (int)tr[3];
+        cl = (int)tr[4];
         const float U = tr[5], V = tr[6];
         if (b >= 0 && b < g.B && t >= 0 && t < g.T && gi >= 0 && gi < g.Gaz && gj >= 0 && gj < g.Gel && cl >= 0 &&
             cl < g.C) {
-            const long cell = (((long)b * g.T + t) * g.Gaz + gi) * g.Gel + gj;
-            const int CH = g.C + 3;
-            const float off_u = gi * g.grid_az - 180.f + 0.5f * g.grid_az;
-            const float off_v = gj * g.grid_el - 90.f + 0.5f * g.grid_el;
-            const float u2 = deg2rad_(U), v2 = deg2rad_(V);
-            const float sv2 = sinf(v2), cv2 = cosf(v2);
-            float D[8], gu[8], gv[8];
-            int amin = 0;
-            for (int a = 0; a < g.A; ++a) {
+            valid = true;
+            cell = (((long)b * g.T + t) * g.Gaz + gi) * g.Gel + gj;
+            if (a < g.A) {
+                const int CH = g.C + 3;
+                const float off_u = gi * g.grid_az - 180.f + 0.5f * g.grid_az;
+                const float off_v = gj * g.grid_el - 90.f + 0.5f * g.grid_el;
+                const float u2 = deg2rad_(U), v2 = deg2rad_(V);
+                const float sv2 = sinf(v2), cv2 = cosf(v2);
                 const float *lp = logit + ((size_t)cell * g.A + a) * CH + g.C + 1;
                 const float tu = tanhf(lp[0]), tv = tanhf(lp[1]);
                 float ud = tu * g.span * g.grid_az + off_u;
@@ -75,7 +84,7 @@ __global__ __launch_bounds__(256) void loss_assign_kernel(const float *__restric
                 const float cs = sv1 * sv2 + cv1 * cv2 * cosf(adu);
                 const float lo = -1.f + 1e-7f, hi = 1.f - 1e-7f;
                 const float cc = fminf(fmaxf(cs, lo), hi);
-                D[a] = rad2deg_(acosf(cc));
+                D = rad2deg_(acosf(cc));
                 float dD_dcs = 0.f;
                 if (cs >= lo && cs <= hi) dD_dcs = -57.29577951308232f / sqrtf(1.f - cc * cc);
                 const float sgn = du > 0.f ? 1.f : (du < 0.f ? -1.f : 0.f);
@@ -83,36 +92,53 @@ __global__ __launch_bounds__(256) void loss_assign_kernel(const float *__restric
                 const float dcs_dv1 = cv1 * sv2 - sv1 * cv2 * cosf(adu);
                 const float dU_dl = (1.f - tu * tu) * g.span * g.grid_az;
                 const float dV_dl = (vraw >= -90.f && vraw <= 90.f) ? (1.f - tv * tv) * g.span * g.grid_el : 0.f;
-                gu[a] = dD_dcs * dcs_du1 * 0.017453292519943295f * dU_dl;
-                gv[a] = dD_dcs * dcs_dv1 * 0.017453292519943295f * dV_dl;
-                if (D[a] < D[amin]) amin = a;
-                if (dist) dist[(size_t)m * g.A + a] = D[a];
-            }
-            for (int a = 0; a < g.A; ++a) {
-                unsigned bits = 0;
-                for (int i = 0; i < 3; ++i)
-                    if (D[a] < g.thr[i] || a == amin) bits |= 1u << i;
-                if (!bits) continue;
-                const long anchor = cell * g.A + a;
-                const unsigned old = atomicOr(&pos_bits[anchor], bits);
-                const unsigned fresh = bits & ~old;
-                for (int i = 0; i < 3; ++i) {
-                    if (fresh & (1u << i)) atomicAdd(&hdr[i], 1u);
-                    if (bits & (1u << i)) atomicOr(&cls_bits[(size_t)i * NA + anchor], 1u << cl);
-                }
-                if (bits & 1u) {          // angular term uses the first threshold only (loss.py:241-243)
-                    my_sum += D[a] / 180.f;
-                    my_pairs += 1;
-                    // several targets can share an anchor: their gradients are summed in 32.32 fixed point, so the
-                    // result does not depend on the order the atomics land in (bit-reproducible training steps)
-                    atomicAdd(&ang_grad[anchor * 2 + 0], to_fixed(gu[a] / 180.f));
-                    atomicAdd(&ang_grad[anchor * 2 + 1], to_fixed(gv[a] / 180.f));
-                }
+                gu = dD_dcs * dcs_du1 * 0.017453292519943295f * dU_dl;
+                gv = dD_dcs * dcs_dv1 * 0.017453292519943295f * dV_dl;
+                if (dist) dist[(size_t)m * g.A + a] = D;
             }
         }
     }
+    // first index of the minimum over the octet (all 64 lanes take part in the shuffles)
+    float dmin = D;
+    int amin = a;
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+        const float od = __shfl_xor(dmin, o, 64);
+        const int oa = __shfl_xor(amin, o, 64);
+        if (od < dmin || (od == dmin && oa < amin)) {
+            dmin = od;
+            amin = oa;
+        }
+    }
+    unsigned bits = 0, fresh = 0;
+    if (valid && a < g.A) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (D < g.thr[i] || a == amin) bits |= 1u << i;
+    }
+    if (bits) {
+        const long anchor = cell * g.A + a;
+        const unsigned old = atomicOr(&pos_bits[anchor], bits);
+        fresh = bits & ~old;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (bits & (1u << i)) atomicOr(&cls_bits[(size_t)i * NA + anchor], 1u << cl);
+        if (bits & 1u) {          // angular term uses the first threshold only (loss.py:241-243)
+            my_sum = D / 180.f;
+            my_pairs = 1;
+            // several targets can share an anchor: their gradients are summed in 32.32 fixed point, so the
+            // result does not depend on the order the atomics land in (bit-reproducible training steps)
+            atomicAdd(&ang_grad[anchor * 2 + 0], to_fixed(gu / 180.f));
+            atomicAdd(&ang_grad[anchor * 2 + 1], to_fixed(gv / 180.f));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int cnt = __popcll(__ballot((fresh >> i) & 1u));
+        if (lane == 0 && cnt) atomicAdd(&hdr[i], (unsigned)cnt);
+    }
     my_sum = wave_sum(my_sum);
-    for (int o = 32; o > 0; o >>= 1) my_pairs += __shfl_xor(my_pairs, o, 64);
+    my_pairs = __popcll(__ballot(my_pairs != 0));
     if (lane == 0) {
         red_sum[wave] = my_sum;
         red_cnt[wave] = my_pairs;
@@ -130,6 +156,12 @@ __device__ __forceinline__ float bce_grad_logit(float s, float y) {
     return (s - y) / fmaxf(q, 1e-12f) * q;
 }
 
+// One pass over the logits, tile by tile (LM_TILE anchors = LM_TILE * (C + 3) consecutive floats): the tile is copied into
+// LDS with coalesced 16-byte loads, one lane then owns one ANCHOR (row stride odd: conflict-free) -- a negative anchor costs
+// one sigmoid / log pair (its class and angle gradients are zero), a positive one the C class terms and the angular
+// gradient -- and the gradients leave through the same LDS tile with coalesced 16-byte stores.
+constexpr int LM_TILE = 256;
+template <bool PAD>
 __global__ __launch_bounds__(256) void loss_main_kernel(const float *__restrict__ logit, LossGeom g,
                                                         const unsigned *__restrict__ hdr,
                                                         const unsigned *__restrict__ pos_bits,
@@ -137,9 +169,11 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const float *__restrict_
                                                         const unsigned long long *__restrict__ ang_grad,
                                                         float *__restrict__ dlogit,
                                                         float *__restrict__ partial, long NA, float grad_scale) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];      // [LM_TILE][CHP]
     __shared__ float red[4][9];
     const int CH = g.C + 3;
-    const long total = NA * CH;
+    const int CHP = PAD ? CH + 1 : CH;              // PAD: CH is even -> odd row stride
+    const int tid = threadIdx.x;
     float npos[3], nneg[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -158,28 +192,42 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const float *__restrict_
     float acc[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = 0.f;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        // 32-bit index arithmetic when it fits (always, at the shapes of this path): a 64-bit division per logit costs
-        // more than the rest of the loop body
-        long anchor;
-        int ch;
-        if (total <= 0xFFFFFFFFL) {
-            const unsigned eu = (unsigned)e, au = eu / (unsigned)CH;
-            anchor = (long)au;
-            ch = (int)(eu - au * (unsigned)CH);
-        } else {
-            anchor = e / CH;
-            ch = (int)(e - anchor * CH);
+    const long ntiles = (NA + LM_TILE - 1) / LM_TILE;
+    for (long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const long a0 = tl * LM_TILE;
+        const int na = (int)((NA - a0) < LM_TILE ? (NA - a0) : LM_TILE);
+        const int nel = na * CH, n4 = nel >> 2;
+        const float *src = logit + (size_t)a0 * CH;         // LM_TILE * CH * 4 bytes is a multiple of 16
+        for (int i = tid; i < n4; i += 256) {
+            const float4 v = reinterpret_cast<const float4 *>(src)[i];
+            if (PAD) {
+                const unsigned e = 4u * i, r = e / (unsigned)CH, c = e - r * (unsigned)CH;
+                float *d = tile + r * CHP + c;               // CH even and e % 4 == 0: c is even, c + 3 may cross the row end
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned ck = c + k;
+                    (ck < (unsigned)CH ? d + k : tile + (r + 1) * CHP + (ck - CH))[0] = vv[k];
+                }
+            } else {
+                reinterpret_cast<float4 *>(tile)[i] = v;
+            }
         }
-        const float xl = logit[e];
-        float grad = 0.f;
-        if (ch <= g.C) {
+        for (int e = 4 * n4 + tid; e < nel; e += 256) {
+            const int r = e / CH;
+            tile[r * CHP + (e - r * CH)] = src[e];
+        }
+        __syncthreads();
+        if (tid < na) {
+            const long anchor = a0 + tid;
+            float *x = tile + tid * CHP;
             const unsigned pb = pos_bits[anchor];
-            const float s = sigmoidf_(xl);
-            const float lp = -fmaxf(logf(s), -100.f);           // -log(s), clamped like nn.BCELoss
-            const float lq = -fmaxf(logf(1.f - s), -100.f);     // -log(1-s)
-            if (ch == 0) {
+            {
+                const float s = sigmoidf_(x[0]);
+                const float lp = -fmaxf(logf(s), -100.f);           // -log(s), clamped like nn.BCELoss
+                const float lq = -fmaxf(logf(1.f - s), -100.f);     // -log(1-s)
                 const float g1 = bce_grad_logit(s, 1.f), g0 = bce_grad_logit(s, 0.f);
+                float grad = 0.f;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     if (pb & (1u << i)) {
@@ -190,32 +238,72 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const float *__restrict_
                         grad += wneg[i] * g0;
                     }
                 }
-            } else if (pb) {
-                const float g1 = bce_grad_logit(s, 1.f), g0 = bce_grad_logit(s, 0.f);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    if (pb & (1u << i)) {
-                        const unsigned yb = (cls_bits[(size_t)i * NA + anchor] >> (ch - 1)) & 1u;
-                        acc[6 + i] += yb ? lp : lq;
-                        grad += wcls[i] * (yb ? g1 : g0);
-                    }
-                }
+                x[0] = grad * grad_scale;
             }
-        } else {
-            grad = wang * from_fixed(ang_grad[anchor * 2 + (ch - g.C - 1)]);
+            if (pb) {
+                unsigned cb[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) cb[i] = (pb & (1u << i)) ? cls_bits[(size_t)i * NA + anchor] : 0u;
+                for (int ch = 1; ch <= g.C; ++ch) {
+                    const float s = sigmoidf_(x[ch]);
+                    const float lp = -fmaxf(logf(s), -100.f);
+                    const float lq = -fmaxf(logf(1.f - s), -100.f);
+                    const float g1 = bce_grad_logit(s, 1.f), g0 = bce_grad_logit(s, 0.f);
+                    float grad = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        if (pb & (1u << i)) {
+                            const unsigned yb = (cb[i] >> (ch - 1)) & 1u;
+                            acc[6 + i] += yb ? lp : lq;
+                            grad += wcls[i] * (yb ? g1 : g0);
+                        }
+                    }
+                    x[ch] = grad * grad_scale;
+                }
+                // (only anchors responsible at the first threshold ever received an angular gradient)
+                const ulonglong2 ag = (pb & 1u) ? *reinterpret_cast<const ulonglong2 *>(ang_grad + anchor * 2)
+                                                : make_ulonglong2(0ull, 0ull);
+                x[g.C + 1] = wang * from_fixed(ag.x) * grad_scale;
+                x[g.C + 2] = wang * from_fixed(ag.y) * grad_scale;
+            } else {
+                for (int ch = 1; ch < CH; ++ch) x[ch] = 0.f;
+            }
         }
-        if (dlogit) dlogit[e] = grad * grad_scale;
+        __syncthreads();
+        if (dlogit) {
+            float *dst = dlogit + (size_t)a0 * CH;
+            for (int i = tid; i < n4; i += 256) {
+                float4 v;
+                if (PAD) {
+                    const unsigned e = 4u * i, r = e / (unsigned)CH, c = e - r * (unsigned)CH;
+                    float vv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned ck = c + k;
+                        vv[k] = (ck < (unsigned)CH ? tile + r * CHP + ck : tile + (r + 1) * CHP + (ck - CH))[0];
+                    }
+                    v = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                } else {
+                    v = reinterpret_cast<const float4 *>(tile)[i];
+                }
+                reinterpret_cast<float4 *>(dst)[i] = v;
+            }
+            for (int e = 4 * n4 + tid; e < nel; e += 256) {
+                const int r = e / CH;
+                dst[e] = tile[r * CHP + (e - r * CH)];
+            }
+        }
+        __syncthreads();
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         const float v = wave_sum(acc[i]);
         if (lane == 0) red[wave][i] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 9)
-        partial[(size_t)blockIdx.x * 9 + threadIdx.x] =
-            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (tid < 9)
+        partial[(size_t)blockIdx.x * 9 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
 __global__ __launch_bounds__(256) void loss_final_kernel(const float *__restrict__ partial, int nblk,
@@ -249,10 +337,10 @@ constexpr int LOSS_MAIN_BLOCKS = 2048;
 
 using namespace adyolo;
 
-// workspace (32-bit words): [hdr 64][pos_bits NA][cls_bits 3*NA][ang_grad 2*NA x int64][ang_partial ceil(M/256)][partial 9*2048]
+// workspace (32-bit words): [hdr 64][pos_bits NA][cls_bits 3*NA][ang_grad 2*NA x int64][ang_partial ceil(M/32)][partial 9*2048]
 extern "C" long adyolo_loss_workspace_words(int BT, int G, int A, int M) {
     const long NA = (long)BT * G * A;
-    return LOSS_HDR + 8 * NA + (long)cdiv(M > 0 ? M : 1, 256) + 9L * LOSS_MAIN_BLOCKS + 64;
+    return LOSS_HDR + 8 * NA + (long)cdiv(M > 0 ? M : 1, 32) + 9L * LOSS_MAIN_BLOCKS + 64;
 }
 
 extern "C" int adyolo_loss_fwd_bwd(const float *logit, const float *target, float *ws, float *loss, float *dlogit,
@@ -276,23 +364,24 @@ extern "C" int adyolo_loss_fwd_bwd(const float *logit, const float *target, floa
     unsigned *cls_bits = pos_bits + NA;
     unsigned long long *ang_grad = reinterpret_cast<unsigned long long *>(cls_bits + 3 * NA);   // 8-byte aligned: 64 + 4 NA words
     float *ang_partial = reinterpret_cast<float *>(ang_grad + 2 * NA);
-    const int nang = cdiv(M, 256);
+    const int nang = cdiv(M, 32);           // 8 lanes per target row: 32 rows per workgroup
     float *partial = ang_partial + nang;
 
-    hipError_t e = hipMemsetAsync(ws, 0, (size_t)(LOSS_HDR + 8 * NA) * 4, st);
-    if (e != hipSuccess) {
-        set_error("loss: memset failed: %s", hipGetErrorString(e));
-        return (int)e;
-    }
+    int rc = fill32(ws, 0u, (size_t)(LOSS_HDR + 8 * NA), st);             // (a kernel, not a memset node: see common.hpp)
+    if (rc) return rc;
     hipLaunchKernelGGL(loss_assign_kernel, dim3(nang), dim3(256), 0, st, logit, target, g, hdr, pos_bits, cls_bits,
                        ang_grad, ang_partial, dist, NA);
-    int rc = check_launch("loss_assign");
+    rc = check_launch("loss_assign");
     if (rc) return rc;
-    const long total = NA * (C + 3);
-    long nb = (total + 255) / 256;
+    long nb = (NA + LM_TILE - 1) / LM_TILE;
     if (nb > LOSS_MAIN_BLOCKS) nb = LOSS_MAIN_BLOCKS;
-    hipLaunchKernelGGL(loss_main_kernel, dim3((unsigned)nb), dim3(256), 0, st, logit, g, hdr, pos_bits, cls_bits,
-                       ang_grad, dlogit, partial, NA, grad_scale);
+    const int CH = C + 3;
+    if (CH & 1)
+        hipLaunchKernelGGL(loss_main_kernel<false>, dim3((unsigned)nb), dim3(256), (size_t)LM_TILE * CH * 4, st, logit, g, hdr,
+                           pos_bits, cls_bits, ang_grad, dlogit, partial, NA, grad_scale);
+    else
+        hipLaunchKernelGGL(loss_main_kernel<true>, dim3((unsigned)nb), dim3(256), (size_t)(LM_TILE + 1) * (CH + 1) * 4, st, logit, g,
+                           hdr, pos_bits, cls_bits, ang_grad, dlogit, partial, NA, grad_scale);
     rc = check_launch("loss_main");
     if (rc) return rc;
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, partial, (int)nb, ang_partial, nang, hdr, g, NA,

@@ -55,6 +55,27 @@ __global__ void adam_prep_kernel(unsigned long long *__restrict__ step, float *_
     bc[1] = (float)(1.0 / sqrt(bc2));
 }
 
+__global__ __launch_bounds__(256) void fill32_kernel(uint32_t *__restrict__ p, uint32_t v, size_t n) {
+    const size_t n4 = n >> 2;
+    uint4 *p4 = reinterpret_cast<uint4 *>(p);
+    const uint4 v4 = make_uint4(v, v, v, v);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) p4[i] = v4;
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[n4 * 4 + threadIdx.x] = v;
+}
+
+int fill32(void *ptr, uint32_t value, size_t n32, hipStream_t st) {
+    if (n32 == 0) return 0;
+    if (reinterpret_cast<uintptr_t>(ptr) & 15) {          // (never the case for the workspaces of this library)
+        set_error("fill32: pointer not 16-byte aligned");
+        return ADYOLO_EINVAL;
+    }
+    size_t g = ((n32 >> 2) + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(fill32_kernel, dim3((unsigned)g), dim3(256), 0, st, reinterpret_cast<uint32_t *>(ptr), value, n32);
+    return check_launch("fill32");
+}
+
 __global__ void counter_add_kernel(unsigned long long *__restrict__ c, unsigned long long inc) { *c += inc; }
 
 __global__ __launch_bounds__(256) void nchw_to_nhwc8_kernel(const float *__restrict__ x, float *__restrict__ y, int C,

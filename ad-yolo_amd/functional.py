@@ -96,6 +96,26 @@ class GradSink:
             for q in ptrs:
                 self.notify(self.views[q][0])
 
+    def params(self, *tensors):
+        """Gradient views of ALL the given parameter tensors (None entries allowed and passed through), each checked to be
+        the whole parameter (same storage start and element count: a slice or a copy of a parameter must keep going
+        through autograd); None when inactive or when any of them is not a sinkable parameter."""
+        if self.views is None:
+            return None
+        out = []
+        for t in tensors:
+            if t is None:
+                out.append(None)
+                continue
+            ent = self.views.get(t.data_ptr())
+            if ent is None or ent[1].numel() != t.numel() or not t.is_contiguous():
+                return None
+            out.append(ent[1].view(t.shape))
+        return out
+
+    def done_params(self, *tensors):
+        self.done(*[t.data_ptr() for t in tensors if t is not None])
+
 
 SINK = GradSink()
 _COUNTER_SCOPE = []           # innermost active bn_counter_scope's list (empty: counters are bumped immediately)
@@ -471,6 +491,7 @@ class LinearFn(torch.autograd.Function):
         k = x.shape[-1]
         x = _c(x)
         y = ops.linear(x.view(-1, k), w, b)
+        ctx.bias = b                           # (only its storage address and shape are used: GradSink)
         ctx.save_for_backward(x, w)
         return y.view(*x.shape[:-1], w.shape[0])
 
@@ -478,6 +499,13 @@ class LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         k = x.shape[-1]
+        b = ctx.bias
+        sunk = SINK.params(w, b) if (ctx.needs_input_grad[1] and (b is None or ctx.needs_input_grad[2])) else None
+        if sunk is not None:          # weight / bias gradients written straight into the flat gradient buffer
+            dx, _, _ = ops.linear_bwd(x.view(-1, k), w, _c(dy).view(-1, w.shape[0]), need_dx=ctx.needs_input_grad[0],
+                                      out_dw=sunk[0], out_db=sunk[1], need_db=b is not None)
+            SINK.done_params(w, b)
+            return (dx.view_as(x) if dx is not None else None), None, None
         dx, dw, db = ops.linear_bwd(x.view(-1, k), w, _c(dy).view(-1, w.shape[0]), need_dx=ctx.needs_input_grad[0])
         return (dx.view_as(x) if dx is not None else None), dw, (db if ctx.needs_input_grad[2] else None)
 
@@ -591,10 +619,14 @@ class ConvFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         n, h, ww, cin, cout, kh, kw = ctx.geom[:7]
         dy = _c(dy)
-        dw = ops.unpack_wk(ops.conv_gemm(2, x, dy, *ctx.geom), cout, cin, kh, kw)
+        sunk = SINK.params(w)
+        dw = ops.unpack_wk(ops.conv_gemm(2, x, dy, *ctx.geom), cout, cin, kh, kw, out=sunk[0] if sunk is not None else None)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv_gemm(1, dy, ops.pack_wk(w.transpose(0, 1).contiguous()), *ctx.geom)
+        if sunk is not None:
+            SINK.done_params(w)
+            dw = None
         return dx, dw, None, None
 
 
@@ -607,14 +639,19 @@ class Conv3x3S1Fn(torch.autograd.Function):
         wpk, wpkd = ops.pack_w3x3(w, cin)
         ctx.save_for_backward(x, wpkd)
         ctx.cin = w.shape[1]
+        ctx.w = w                              # (storage address / shape for GradSink)
         return ops.conv3x3(x, wpk, w.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         x, wpkd = ctx.saved_tensors
         dy = _c(dy)
-        dw = ops.conv3x3_wgrad(x, dy, ctx.cin)
+        sunk = SINK.params(ctx.w)
+        dw = ops.conv3x3_wgrad(x, dy, ctx.cin, out=sunk[0] if sunk is not None else None)
         dx = ops.conv3x3(dy, wpkd, x.shape[-1]) if ctx.needs_input_grad[0] else None
+        if sunk is not None:
+            SINK.done_params(ctx.w)
+            dw = None
         return dx, dw
 
 
@@ -650,6 +687,7 @@ class BatchNormFn(torch.autograd.Function):
         else:
             y = ops.affine(x, scale, shift)
         ctx.training, ctx.relu, ctx.has_res = training, relu or residual is not None, residual is not None
+        ctx.beta = beta                        # (storage address / shape for GradSink)
         ctx.save_for_backward(x, y, gamma, mean, invstd)
         return y
 
@@ -659,6 +697,11 @@ class BatchNormFn(torch.autograd.Function):
             raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
         x, y, gamma, mean, invstd = ctx.saved_tensors
         g = ops.relu_bwd(_c(dy), y) if ctx.relu else _c(dy)
+        sunk = SINK.params(gamma, ctx.beta)
+        if sunk is not None:
+            dx, _, _ = ops.bn_bwd(g, x, gamma, mean, invstd, relu_mask=False, out_dgamma=sunk[0], out_dbeta=sunk[1])
+            SINK.done_params(gamma, ctx.beta)
+            return dx, None, None, None, None, None, (g if ctx.has_res else None)
         dx, dgamma, dbeta = ops.bn_bwd(g, x, gamma, mean, invstd, relu_mask=False)
         return dx, dgamma, dbeta, None, None, None, (g if ctx.has_res else None)
 
@@ -685,6 +728,7 @@ class LNFn(torch.autograd.Function):
         c = x.shape[-1]
         y = ops.ln_fwd(_c(x).view(-1, c), gamma, beta, eps)
         ctx.eps = eps
+        ctx.beta = beta                        # (storage address / shape for GradSink)
         ctx.save_for_backward(x, gamma)
         return y.view_as(x)
 
@@ -692,6 +736,11 @@ class LNFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, gamma = ctx.saved_tensors
         c = x.shape[-1]
+        sunk = SINK.params(gamma, ctx.beta)
+        if sunk is not None:                   # the kernel adds into the (zeroed) gradient slices
+            dx, _, _ = ops.ln_bwd(_c(dy).view(-1, c), _c(x).view(-1, c), gamma, ctx.eps, acc_dgamma=sunk[0], acc_dbeta=sunk[1])
+            SINK.done_params(gamma, ctx.beta)
+            return dx.view_as(x), None, None, None
         dx, dg, db = ops.ln_bwd(_c(dy).view(-1, c), _c(x).view(-1, c), gamma, ctx.eps)
         return dx.view_as(x), dg, db, None
 
@@ -728,6 +777,7 @@ class DWConv3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, dilation):
         ctx.dilation = dilation
+        ctx.bias = bias                        # (storage address / shape for GradSink)
         ctx.save_for_backward(x, w)
         return ops.dwconv3(_c(x), w.view(-1, 3), bias, dilation)
 
@@ -736,6 +786,11 @@ class DWConv3Fn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dy = _c(dy)
         dx = ops.dwconv3(dy, w.view(-1, 3), None, ctx.dilation, flip=True)
+        sunk = SINK.params(w, ctx.bias) if ctx.bias is not None else None
+        if sunk is not None:
+            ops.dwconv3_wgrad(dy, _c(x), ctx.dilation, out_dw=sunk[0].view(-1, 3), out_db=sunk[1])
+            SINK.done_params(w, ctx.bias)
+            return dx, None, None, None
         dw, db = ops.dwconv3_wgrad(dy, _c(x), ctx.dilation)
         return dx, dw.view_as(w), db, None
 

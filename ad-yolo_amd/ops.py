@@ -167,14 +167,15 @@ def linear(x2d, w, bias=None):
     return gemm(x2d, w, r, w.shape[0], k, k, k, bias=bias)
 
 
-def linear_bwd(x2d, w, dy2d, need_dx=True):
-    """-> dx [R][K], dw [N][K], db [N]."""
+def linear_bwd(x2d, w, dy2d, need_dx=True, out_dw=None, out_db=None, need_db=True):
+    """-> dx [R][K], dw [N][K], db [N].  out_dw / out_db: write there instead (e.g. the parameters' slices of the flat
+    gradient buffer, ``functional.GradSink``)."""
     _chk(x2d, w, dy2d)
     r, k = x2d.shape
     n = w.shape[0]
     dx = gemm(dy2d, w, r, k, n, n, k, trans_b=True) if need_dx else None
-    dw = gemm(dy2d, x2d, n, k, r, n, k, trans_a=True, trans_b=True, splits=wgrad_splits(n, k, r))
-    db = colsum(dy2d)
+    dw = gemm(dy2d, x2d, n, k, r, n, k, trans_a=True, trans_b=True, splits=wgrad_splits(n, k, r), out=out_dw)
+    db = colsum(dy2d, out=out_db) if need_db else None
     return dx, dw, db
 
 
@@ -608,8 +609,8 @@ def pack_wk(w):
     return wk
 
 
-def unpack_wk(wk, cout, cin, kh, kw):
-    w = _new(wk, cout, cin, kh, kw)
+def unpack_wk(wk, cout, cin, kh, kw, out=None):
+    w = out if out is not None else _new(wk, cout, cin, kh, kw)
     _c("adyolo_pack_wk", _p(w), _p(wk), cout, cin, kh, kw, 0, _stream())
     return w
 
@@ -692,10 +693,11 @@ def dwconv3(x, w, bias, dilation, flip=False):
     return y
 
 
-def dwconv3_wgrad(dy, x, dilation):
+def dwconv3_wgrad(dy, x, dilation, out_dw=None, out_db=None):
     _chk(dy, x)
     b, t, c = x.shape
-    dw, db = _new(x, c, 3), _new(x, c)
+    dw = out_dw if out_dw is not None else _new(x, c, 3)
+    db = out_db if out_db is not None else _new(x, c)
     partial, cws = _new(x, 1024, 4 * c), _new(x, 1024, 3 * c)
     _c("adyolo_dwconv3_wgrad", _p(dy), _p(x), _p(dw), _p(db), _p(partial), _p(cws), b, t, c, int(dilation), _stream())
     return dw, db
@@ -738,11 +740,14 @@ def ln_fwd(x2d, gamma, beta, eps=1e-5):
     return y
 
 
-def ln_bwd(dy2d, x2d, gamma, eps=1e-5):
+def ln_bwd(dy2d, x2d, gamma, eps=1e-5, acc_dgamma=None, acc_dbeta=None):
+    """acc_dgamma / acc_dbeta: the kernel ADDS the two gradients into these (the parameters' slices of the flat gradient
+    buffer, zeroed at the start of the step) instead of into fresh zeros."""
     _chk(dy2d, x2d, gamma)
     r, c = x2d.shape
     dx = torch.empty_like(x2d)
-    dgamma, dbeta = _zeros(x2d, c), _zeros(x2d, c)
+    dgamma = acc_dgamma if acc_dgamma is not None else _zeros(x2d, c)
+    dbeta = acc_dbeta if acc_dbeta is not None else _zeros(x2d, c)
     partial = _new(x2d, 1024 * 512)
     _c("adyolo_ln_bwd", _p(dy2d), _p(x2d), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), _p(partial), r, c, eps, _stream())
     return dx, dgamma, dbeta

@@ -252,7 +252,7 @@ def _small_shape_kernel_ms(name):
     return None
 
 
-def run_extra_config(name, torch):
+def run_extra_config(name, torch, modes="both"):
     import adyolo_amd  # noqa: F401
     from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
     from adyolo_amd.features import FeatureExtractor
@@ -285,18 +285,20 @@ def run_extra_config(name, torch):
 
     if cfg["kind"] == "train":
         res = {}
-        for mode in (("hipgraph", "eager") if graphable else ("eager",)):
+        want = ("hipgraph", "eager") if modes == "both" else (modes,)
+        for mode in ([m for m in want if graphable or m == "eager"] or ["eager"]):
             torch.manual_seed(100)
             model = WrapperModel((1, 7, T, 64), (), prm).to(device)
             tr = TrainStep(model, WrapperCriterion(prm), fx, prm, graph=(mode == "hipgraph"))
             ms, loss = timed(lambda: tr.step(audio, target), cfg["steps"], 3)
             res[mode] = (ms, float(loss.reshape(-1)[0]))
             del tr, model
-        mode = "hipgraph" if graphable else "eager"
+        mode = "hipgraph" if "hipgraph" in res else "eager"
         ms = res[mode][0]
+        ent["steps_executed"] = {m: cfg["steps"] + 3 for m in res}
         ent.update({"mode": mode, "ms_per_step": round(ms, 3), "audio_s_per_s": round(B * cfg["seconds"] / (ms * 1e-3), 1),
                     "final_loss": round(res[mode][1], 6)})
-        if graphable:
+        if len(res) == 2:
             ent["eager_ms_per_step"] = round(res["eager"][0], 3)
             ent["graph_equals_eager_loss"] = res["hipgraph"][1] == res["eager"][1]
     else:
@@ -338,6 +340,8 @@ def main():
     ap.add_argument("--no-stages", action="store_true", help="skip the two extra instrumented steps")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs block (the reference's own shapes)")
     ap.add_argument("--only-extra", default=None, help="run ONE extra config by name and print its entry (profiling)")
+    ap.add_argument("--extra-mode", default="both", choices=["both", "hipgraph", "eager"],
+                    help="with --only-extra: run only the graph or only the eager variant (profiling: a known step count)")
     ap.add_argument("--graph", action="store_true", help="replay the headline step from a hipGraph too (no per-kernel events)")
     ap.add_argument("--encoder", default="se-resnet34", choices=["se-resnet34", "resnet-conformer"],
                     help="se-resnet34 = the headline workload (BASELINE configs[1]); resnet-conformer = config 4")
@@ -357,7 +361,7 @@ def main():
 
     if args.only_extra:
         torch.cuda.set_device(0)
-        print(json.dumps(run_extra_config(args.only_extra, torch)), flush=True)
+        print(json.dumps(run_extra_config(args.only_extra, torch, args.extra_mode)), flush=True)
         return
 
     rank, world, local_rank = adist.init_from_env("nccl")

@@ -149,7 +149,7 @@ def test_graphed_evaluation_forward_matches_eager(ops):
                 ref = model(fx(audio, channels_last8=True), channels_last8=True)
             dec_ref = post.decode(ref)
             out, dec = fg(audio)
-            assert torch.equal(out, ref), (seconds, i)
+            assert torch.equal(out, ref), "clip of %d s, call %d: max abs diff %.3e" % (seconds, i, float((out - ref).abs().max()))
             assert np.array_equal(dec.cpu().numpy(), dec_ref)
     assert fg.captures == 2 and fg.replays == 6
     sd = model.state_dict()
