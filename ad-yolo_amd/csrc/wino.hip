@@ -819,30 +819,44 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float *__r
     }
 }
 
-// Work items = (sample, 16-pixel column strip, segment of seg_rows tile rows).  Every item pays one exposed prologue
-// (8 x rows + 4 dy rows), so segments are as long as they can be while each of the ~512 resident workgroups still
-// gets about four items (measured: 32-row segments 3.53 ms, 64-row 3.31 ms at stage 4).
+// Work items = (sample, 16-pixel column strip, segment of seg_rows tile rows), dealt STATICALLY to the nsplit workgroups of
+// a (cin, cout) block pair (item = split, split + nsplit, ...); all pairs x nsplit = ~512 workgroups are resident together
+// (2 per CU).  Every item pays one exposed prologue (8 x rows + 4 dy rows: about 1.5 steps' worth; measured: 32-row
+// segments 3.53 ms, 64-row 3.31 ms at stage 4), so the launch takes  rounds x (seg_rows / 2 + 1.5)  steps with
+// rounds = ceil(items / nsplit): the segment length is the one that minimises that.  Round 2 aimed at "about four items per
+// workgroup" regardless: at the benchmark shape that cut the strips into 4-8 segments (2-7 % more steps than one item per
+// workgroup), and at the reference's own shapes (16 x 20 s) into 16-row crumbs with partly idle rounds (20-30 % more).
 static int wino_wgrad_geometry(int N, int H, int W, int Cin, int Cout, int *nt_o, int *nseg_o, int *seg_rows_o,
                                int *nitems_o) {
     const int nt = Cout % 64 == 0 ? 2 : 1;
     const int tilesH = cdiv(H, 2), tilesW = cdiv(W, 16);
     const int pairs = (Cout / (32 * nt)) * (Cin / 32);
-    int nsplit = 512 / pairs;
-    if (nsplit < 1) nsplit = 1;
+    int nsplit0 = 512 / pairs;
+    if (nsplit0 < 1) nsplit0 = 1;
     const int strips = N * tilesW;
-    int nseg = cdiv(4 * nsplit, strips);                  // segments per strip for ~4 items per workgroup
-    if (nseg < 1) nseg = 1;
-    int seg_rows = cdiv(tilesH, nseg);
-    seg_rows += seg_rows & 1;                             // even: a step is two tile rows
-    if (seg_rows < 16) seg_rows = 16;
-    nseg = cdiv(tilesH, seg_rows);
-    const int nitems = strips * nseg;
-    if (nsplit > nitems) nsplit = nitems;
+    double best_cost = 0.0;
+    int best_seg = 0, best_nseg = 1, best_split = 1;
+    for (int want = 1; want <= tilesH / 4 + 1; ++want) {
+        int seg_rows = cdiv(tilesH, want);
+        seg_rows += seg_rows & 1;                         // even: a step is two tile rows
+        if (seg_rows < 8) seg_rows = 8;
+        const int nseg = cdiv(tilesH, seg_rows);
+        const long nitems = (long)strips * nseg;
+        const int nsplit = nitems < nsplit0 ? (int)nitems : nsplit0;
+        const double cost = (double)cdiv(nitems, nsplit) * (0.5 * seg_rows + 1.5);
+        if (best_seg == 0 || cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best_seg = seg_rows;
+            best_nseg = nseg;
+            best_split = nsplit;
+        }
+        if (seg_rows == 8) break;
+    }
     if (nt_o) *nt_o = nt;
-    if (nseg_o) *nseg_o = nseg;
-    if (seg_rows_o) *seg_rows_o = seg_rows;
-    if (nitems_o) *nitems_o = nitems;
-    return nsplit;
+    if (nseg_o) *nseg_o = best_nseg;
+    if (seg_rows_o) *seg_rows_o = best_seg;
+    if (nitems_o) *nitems_o = strips * best_nseg;
+    return best_split;
 }
 
 }  // namespace adyolo

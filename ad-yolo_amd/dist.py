@@ -120,25 +120,34 @@ class BucketedAllReduce:
 
     def reset(self):
         self._pending = [len(mem) for (_, _, mem) in self.buckets]
+        self._arrived = [False] * len(self.flat.params)
         self._works = []
+
+    def _arrive(self, idx):
+        """Gradient ``idx`` is complete.  Counted ONCE per step: a parameter whose gradient a kernel wrote straight into
+        the flat buffer (functional.GradSink -> ``notify``) is reported a second time by autograd itself, because the
+        post-accumulate-grad hook of a parameter also fires when the node handed back None for it (PyTorch 2.10).  Counting
+        both made every bucket look complete after HALF of its members -- its all-reduce then summed gradients that had
+        not been written yet and wrote those zeros back over the real ones (found by the two-rank test on the real model,
+        tests/test_gpu_parity_scale.py; with one rank the in-place reduction is an identity and hid it)."""
+        if self._arrived[idx]:
+            return
+        self._arrived[idx] = True
+        b = self._bucket_of[idx]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self.fired_from_hooks += 1
+            self._launch(b)
 
     def _make_hook(self, idx):
         def hook(_param):
-            b = self._bucket_of[idx]
-            self._pending[b] -= 1
-            if self._pending[b] == 0:
-                self.fired_from_hooks += 1
-                self._launch(b)
+            self._arrive(idx)
         return hook
 
     def notify(self, idx):
         """Gradient ``idx`` (position in flat.params) is complete although autograd never saw it (functional.GradSink)."""
         if self.active:
-            b = self._bucket_of[idx]
-            self._pending[b] -= 1
-            if self._pending[b] == 0:
-                self.fired_from_hooks += 1
-                self._launch(b)
+            self._arrive(idx)
 
     def _launch(self, b):
         s, e, _ = self.buckets[b]

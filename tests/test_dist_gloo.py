@@ -236,3 +236,84 @@ def test_dropout_stream_accepts_round2_state():
     a.draw(16)
     b.set_state(a.state())
     assert b.seed == a.seed and b.offset == 16
+
+
+class _SinkLinear(torch.autograd.Function):
+    """A node that behaves like the gfx950 gradient producers under ``functional.GradSink``: it writes the weight gradient
+    straight into the parameter's slice of the flat gradient buffer, tells the reducer by hand and hands autograd None."""
+
+    @staticmethod
+    def forward(ctx, x, w, red, idx):
+        ctx.save_for_backward(x, w)
+        ctx.red, ctx.idx = red, idx
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        w.grad.add_(dy.t() @ x)                  # "kernel" writing into the flat buffer's view
+        ctx.red.notify(ctx.idx)
+        return dy @ w, None, None, None
+
+
+def _worker_sink(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    ws = nn.ParameterList([nn.Parameter(torch.randn(6, 6) * 0.3) for _ in range(6)])
+    flat = FlatParameters(ws)
+    red = BucketedAllReduce(flat, n_buckets=3)
+    index = {id(p): i for i, p in enumerate(flat.params)}
+    torch.manual_seed(10 + rank)
+    x = torch.randn(5, 6)
+    early = []
+    launch = red._launch
+
+    def spy(b):                                  # at launch time every member's gradient must already be in the buffer
+        s, e, mem = red.buckets[b]
+        early.append(any(float(flat.params[i].grad.abs().sum()) == 0.0 for i in mem))
+        launch(b)
+    red._launch = spy
+    flat.zero_grad()
+    h = x
+    for k, w in enumerate(ws):                   # every second layer is "sunk" (each bucket's FIRST gradient), the others go through autograd
+        h = _SinkLinear.apply(h, w, red, index[id(w)]) if k % 2 == 1 else h @ w.t()
+        h = torch.tanh(h)
+    h.sum().backward()
+    scale = red.finish()
+    out.put((rank, (flat.flat_grad * scale).numpy().copy(), early, red.fired_from_hooks, red.fired_from_finish))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sunk_gradients_are_counted_once_per_step():
+    """Round-3 bug: a parameter whose gradient bypasses autograd (GradSink) was counted twice (by ``notify`` and by its
+    post-accumulate-grad hook, which PyTorch fires even for a None gradient), so buckets were all-reduced when half of
+    their gradients were still unwritten.  World size 2: no bucket may be launched with an empty member, and the result
+    must be the mean of the two ranks' gradients."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sink, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, g0, early0, h0, f0), (_, g1, early1, h1, f1) = got
+    assert not any(early0) and not any(early1), "a bucket was reduced before all of its gradients were written"
+    assert (g0 == g1).all() and h0 + f0 == 3 and (h0, f0) == (h1, f1)
+    # reference: the two ranks' gradients by plain autograd, averaged
+    refs = []
+    for rank in range(2):
+        torch.manual_seed(0)
+        ws = [torch.nn.Parameter(torch.randn(6, 6) * 0.3) for _ in range(6)]
+        torch.manual_seed(10 + rank)
+        h = torch.randn(5, 6)
+        for w in ws:
+            h = torch.tanh(h @ w.t())
+        h.sum().backward()
+        refs.append(torch.cat([w.grad.reshape(-1) for w in reversed(ws)]))
+    ref = ((refs[0] + refs[1]) / 2).numpy()
+    assert abs(g0[:ref.size] - ref).max() < 1e-6

@@ -726,14 +726,20 @@ if mode == "rank":
         sys.exit(0)
     tr = make()
     audio, target = data(rank)
-    losses, fired = [], []
+    losses, fired, gdig = [], [], []
+    opt_step = tr.optimizer.step
+
+    def spy(grad_scale=1.0):                            # the reduced gradients, bucket by bucket, as Adam sees them
+        gdig.append([digest(tr.flat.flat_grad[s:e]) for s, e, _ in tr.reducer.buckets])
+        opt_step(grad_scale=grad_scale)
+    tr.optimizer.step = spy
     for _ in range(3):
         h0, f0 = tr.reducer.fired_from_hooks, tr.reducer.fired_from_finish
         losses.append(float(tr.step(audio, target)))
         fired.append((tr.reducer.fired_from_hooks - h0, tr.reducer.fired_from_finish - f0))
     torch.cuda.synchronize()
     print(json.dumps({"rank": rank, "world": world, "active": tr.reducer.active, "buckets": len(tr.reducer.buckets),
-                      "fired": fired, "losses": losses, "params": digest(tr.flat.flat),
+                      "fired": fired, "losses": losses, "params": digest(tr.flat.flat), "grads": gdig,
                       "bn": digest(tr.model.encoder.bn1.running_mean)}))
     dist.barrier()
     dist.destroy_process_group()
@@ -741,6 +747,7 @@ else:
     trs = [make(), make()]
     dat = [data(0), data(1)]
     losses = [[], []]
+    gdig = []
     for _ in range(3):
         for r, tr in enumerate(trs):                    # what rank r computes before the exchange
             tr.model.train()
@@ -754,11 +761,12 @@ else:
                 Fn.SINK.end()
             losses[r].append(float(loss))
         total = trs[0].flat.flat_grad + trs[1].flat.flat_grad      # the all-reduce (sum of two floats: order-free)
+        gdig.append([digest(total[s:e]) for s, e, _ in trs[0].reducer.buckets])
         for tr in trs:
             tr.flat.flat_grad.copy_(total)
             tr.optimizer.step(grad_scale=0.5)
     torch.cuda.synchronize()
-    print(json.dumps({"emulated": True, "losses": losses, "params": [digest(t.flat.flat) for t in trs],
+    print(json.dumps({"emulated": True, "losses": losses, "params": [digest(t.flat.flat) for t in trs], "grads": gdig,
                       "bn": [digest(t.model.encoder.bn1.running_mean) for t in trs]}))
 """
 
@@ -804,6 +812,9 @@ def test_two_ranks_on_the_real_model_match_the_sequential_emulation(ops):
     for o in outs:
         assert o["world"] == 2 and o["active"] and o["buckets"] == 4
         assert all(f == [4, 0] for f in o["fired"]), o["fired"]          # all four buckets overlapped with backward
+    where = [(st, bk, outs[0]["grads"][st][bk] == outs[1]["grads"][st][bk], outs[0]["grads"][st][bk] == emu["grads"][st][bk])
+             for st in range(3) for bk in range(4)]
+    assert all(a and b for _, _, a, b in where), "reduced gradients (step, bucket, rank0 == rank1, rank0 == emulation): %r" % where
     assert outs[0]["params"] == outs[1]["params"], "ranks diverged"
     assert outs[0]["params"] == emu["params"][0] == emu["params"][1], "two ranks != sequential emulation"
     for rk in range(2):
