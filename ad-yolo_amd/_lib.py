@@ -26,6 +26,7 @@ SIGNATURES = {
     "adyolo_conv3x3_tiles": (I, [I] * 3),
     "adyolo_conv3x3_fwd": (I, [P] * 13 + [I] * 7 + [P]),
     "adyolo_wino_pack_w": (I, [P, P, P, I, I, I, P]),
+    "adyolo_wino_pack_many": (I, [P, I, I, I, P]),
     "adyolo_wino_tiles": (I, [I] * 3),
     "adyolo_wino_fwd": (I, [P] * 13 + [I] * 7 + [P]),
     "adyolo_wino_wgrad_slabs": (I, [I] * 5),

@@ -13,7 +13,8 @@
 
 namespace adyolo {
 
-constexpr int LOSS_HDR = 64;        // counters: [0..2] Npos_i, [3] Npairs, [4] n_partials_assign
+constexpr int LOSS_HDR = 64;        // counters: [0..2] Npos_i, [3] Npairs, [4] arrival counter of the assign workgroups
+constexpr int LOSS_MAIN_BLOCKS = 2048, LOSS_ASSIGN_BLOCKS = 1024;
 
 struct LossGeom {
     int B, T, Gaz, Gel, A, C, M;
@@ -37,7 +38,7 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) {
 // 8 lanes per target row: lane a of the octet owns anchor a (one decode + great-circle distance per lane instead of a
 // serial loop over the anchors: 8x the parallelism of a one-lane-per-row kernel, which was latency-bound at 137 k rows);
 // the arg-min is three shuffle steps inside the octet (ties -> the lowest anchor index, like the reference's argmin);
-// distinct-positive counts go to the header as ONE atomic per wave and threshold (ballot + popcount).
+// distinct-positive counts are kept per wave (ballot + popcount) and leave once per workgroup.
 __global__ __launch_bounds__(256) void loss_assign_kernel(const float *__restrict__ logit,
                                                           const float *__restrict__ target, LossGeom g,
                                                           unsigned *__restrict__ hdr, unsigned *__restrict__ pos_bits,
@@ -46,10 +47,15 @@ __global__ __launch_bounds__(256) void loss_assign_kernel(const float *__restric
                                                           float *__restrict__ ang_partial, float *__restrict__ dist,
                                                           long NA) {
     __shared__ float red_sum[4];
-    __shared__ int red_cnt[4];
-    const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int m = (int)(gt >> 3), a = threadIdx.x & 7;
+    __shared__ int red_cnt[4][4];
+    __shared__ bool is_last;
+    const int a = threadIdx.x & 7;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float blk_sum = 0.f;                      // this thread's share of sum(D / 180) over responsible pairs
+    int cnt0 = 0, cnt1 = 0, cnt2 = 0, cntp = 0;     // wave-uniform: distinct positives per threshold, responsible pairs
+    const long nlanes = (long)g.M * 8;
+    for (long gt = (long)blockIdx.x * blockDim.x + threadIdx.x; gt - threadIdx.x < nlanes; gt += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(gt >> 3);
     float my_sum = 0.f;
     int my_pairs = 0;
     float D = INFINITY, gu = 0.f, gv = 0.f;
@@ -132,21 +138,52 @@ __global__ __launch_bounds__(256) void loss_assign_kernel(const float *__restric
             atomicAdd(&ang_grad[anchor * 2 + 1], to_fixed(gv / 180.f));
         }
     }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int cnt = __popcll(__ballot((fresh >> i) & 1u));
-        if (lane == 0 && cnt) atomicAdd(&hdr[i], (unsigned)cnt);
+    // distinct positives / pairs of this wave (same-address atomics are serialised by the memory system at ~12 ns each: one
+    // per wave and counter cost 0.65 ms at 137 k rows -- the counts are kept in registers and leave once per workgroup)
+    cnt0 += __popcll(__ballot(fresh & 1u));
+    cnt1 += __popcll(__ballot((fresh >> 1) & 1u));
+    cnt2 += __popcll(__ballot((fresh >> 2) & 1u));
+    cntp += __popcll(__ballot(my_pairs != 0));
+    blk_sum += my_sum;
     }
-    my_sum = wave_sum(my_sum);
-    my_pairs = __popcll(__ballot(my_pairs != 0));
+    blk_sum = wave_sum(blk_sum);
     if (lane == 0) {
-        red_sum[wave] = my_sum;
-        red_cnt[wave] = my_pairs;
+        red_sum[wave] = blk_sum;
+        red_cnt[wave][0] = cnt0;
+        red_cnt[wave][1] = cnt1;
+        red_cnt[wave][2] = cnt2;
+        red_cnt[wave][3] = cntp;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        ang_partial[blockIdx.x] = red_sum[0] + red_sum[1] + red_sum[2] + red_sum[3];
-        atomicAdd(&hdr[3], (unsigned)(red_cnt[0] + red_cnt[1] + red_cnt[2] + red_cnt[3]));
+    // per-workgroup results go to plain arrays; the LAST workgroup to arrive (one atomic per workgroup) adds the counts up
+    // in a fixed order and publishes them in the header
+    unsigned *cnt_partial = reinterpret_cast<unsigned *>(ang_partial + LOSS_ASSIGN_BLOCKS);
+    if (threadIdx.x < 4)
+        cnt_partial[blockIdx.x * 4 + threadIdx.x] = (unsigned)(red_cnt[0][threadIdx.x] + red_cnt[1][threadIdx.x] +
+                                                                red_cnt[2][threadIdx.x] + red_cnt[3][threadIdx.x]);
+    if (threadIdx.x == 0) ang_partial[blockIdx.x] = red_sum[0] + red_sum[1] + red_sum[2] + red_sum[3];
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(&hdr[4], 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (is_last) {
+        __threadfence();
+        unsigned t4[4] = {0u, 0u, 0u, 0u};
+        for (unsigned bk = threadIdx.x; bk < gridDim.x; bk += blockDim.x) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)        // (device-scope loads: the other workgroups' stores, not a stale L1 line)
+                t4[i] += __hip_atomic_load(cnt_partial + 4 * bk + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                  // integer sums: any order gives the same result
+            unsigned v = t4[i];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) red_cnt[wave][i] = (int)v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4)
+            hdr[threadIdx.x] = (unsigned)(red_cnt[0][threadIdx.x] + red_cnt[1][threadIdx.x] + red_cnt[2][threadIdx.x] +
+                                          red_cnt[3][threadIdx.x]);
     }
 }
 
@@ -331,16 +368,15 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const float *__restrict
     }
 }
 
-constexpr int LOSS_MAIN_BLOCKS = 2048;
 
 }  // namespace adyolo
 
 using namespace adyolo;
 
-// workspace (32-bit words): [hdr 64][pos_bits NA][cls_bits 3*NA][ang_grad 2*NA x int64][ang_partial ceil(M/32)][partial 9*2048]
+// workspace (32-bit words): [hdr 64][pos_bits NA][cls_bits 3*NA][ang_grad 2*NA x int64][ang_partial 1024][cnt_partial 4*1024][partial 9*2048]
 extern "C" long adyolo_loss_workspace_words(int BT, int G, int A, int M) {
     const long NA = (long)BT * G * A;
-    return LOSS_HDR + 8 * NA + (long)cdiv(M > 0 ? M : 1, 32) + 9L * LOSS_MAIN_BLOCKS + 64;
+    return LOSS_HDR + 8 * NA + 5L * LOSS_ASSIGN_BLOCKS + 9L * LOSS_MAIN_BLOCKS + 64;
 }
 
 extern "C" int adyolo_loss_fwd_bwd(const float *logit, const float *target, float *ws, float *loss, float *dlogit,
@@ -364,8 +400,9 @@ extern "C" int adyolo_loss_fwd_bwd(const float *logit, const float *target, floa
     unsigned *cls_bits = pos_bits + NA;
     unsigned long long *ang_grad = reinterpret_cast<unsigned long long *>(cls_bits + 3 * NA);   // 8-byte aligned: 64 + 4 NA words
     float *ang_partial = reinterpret_cast<float *>(ang_grad + 2 * NA);
-    const int nang = cdiv(M, 32);           // 8 lanes per target row: 32 rows per workgroup
-    float *partial = ang_partial + nang;
+    int nang = cdiv(M, 32);                 // 8 lanes per target row: 32 rows per workgroup and round
+    if (nang > LOSS_ASSIGN_BLOCKS) nang = LOSS_ASSIGN_BLOCKS;
+    float *partial = ang_partial + 5 * LOSS_ASSIGN_BLOCKS;
 
     int rc = fill32(ws, 0u, (size_t)(LOSS_HDR + 8 * NA), st);             // (a kernel, not a memset node: see common.hpp)
     if (rc) return rc;

@@ -384,12 +384,9 @@ __global__ __launch_bounds__(256, (WinoCfg<NT, ONE>::WG_PER_CU)) void wino_fwd_k
 // U = G g G^T in fragment order [16 pos][Cout/32][Cin/8][64 lanes][4]: lane (n, h) element j = U_pos[cin 8g+4h+j][cout 32cb+n].
 // mode 0: forward filter g = w[cout][cin];  mode 1: data-gradient filter g[ky][kx] = w[k][n][2-ky][2-kx]
 // (the GEMM's "cin" runs over the forward Cout and its "cout" over the forward, padded, Cin).
-__global__ __launch_bounds__(256) void wino_pack_kernel(const float *__restrict__ w, float *__restrict__ u, int Cout_f,
-                                                        int Cin_real, int K, int Nn, int mode) {
+__device__ __forceinline__ void wino_pack_one(const float *__restrict__ w, float *__restrict__ u, int Cin_real, int K,
+                                              int Nn, int mode, long idx, long total) {
     // K = GEMM reduction channels, Nn = GEMM output channels
-    const long total = (long)(Nn / 32) * (K / 8) * 256;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
     const int j = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
     const long rest = idx >> 8;
     const int g = (int)(rest % (K / 8)), cbk = (int)(rest / (K / 8));
@@ -407,7 +404,6 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float *__restrict_
             }
             f[a][b] = v;
         }
-    (void)Cout_f;
     // t = G f  (4x3), U = t G^T (4x4);  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
     float tt[4][3];
 #pragma unroll
@@ -427,6 +423,29 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float *__restrict_
         u[(size_t)(a * 4 + 2) * ps + idx] = u2;
         u[(size_t)(a * 4 + 3) * ps + idx] = u3;
     }
+}
+
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float *__restrict__ w, float *__restrict__ u, int Cout_f,
+                                                        int Cin_real, int K, int Nn, int mode) {
+    (void)Cout_f;
+    const long total = (long)(Nn / 32) * (K / 8) * 256;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < total) wino_pack_one(w, u, Cin_real, K, Nn, mode, idx, total);
+}
+
+// Every 3x3 filter of a model in ONE launch (64 pack launches per train step of SE-ResNet34 otherwise: the packed filters
+// change once per optimizer step, not per layer call).  table: [n][6] int64 = {w, u_fwd, u_dgrad (or 0), Cout, Cin_real, Cin};
+// grid (ceil(largest total / 256), n)
+__global__ __launch_bounds__(256) void wino_pack_many_kernel(const long long *__restrict__ table) {
+    const long long *d = table + 6 * blockIdx.y;
+    const float *w = reinterpret_cast<const float *>(d[0]);
+    float *uf = reinterpret_cast<float *>(d[1]), *ud = reinterpret_cast<float *>(d[2]);
+    const int Cout = (int)d[3], Cin_real = (int)d[4], Cin = (int)d[5];
+    const long total = (long)(Cout / 32) * (Cin / 8) * 256;       // same count for both packings
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    if (uf) wino_pack_one(w, uf, Cin_real, Cin, Cout, 0, idx, total);
+    if (ud) wino_pack_one(w, ud, Cin_real, Cout, Cin, 1, idx, total);
 }
 
 }  // namespace adyolo
@@ -458,6 +477,15 @@ extern "C" int adyolo_wino_pack_w(const float *w, float *u_fwd, float *u_dgrad, 
         hipLaunchKernelGGL(wino_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w, u_dgrad, Cout,
                            Cin_real, Cout, Cin, 1);
     return check_launch("wino_pack_w");
+}
+
+extern "C" int adyolo_wino_pack_many(const int64_t *table, int n, int max_cout, int max_cin, void *stream) {
+    ADYOLO_REQUIRE(table && n > 0 && max_cout > 0 && max_cin > 0 && max_cout % 32 == 0 && max_cin % 32 == 0, ADYOLO_EINVAL,
+                   "wino_pack_many: bad arguments");
+    const long total = (long)(max_cout / 32) * (max_cin / 8) * 256;
+    hipLaunchKernelGGL(wino_pack_many_kernel, dim3(cdiv(total, 256), n), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const long long *>(table));
+    return check_launch("wino_pack_many");
 }
 
 extern "C" int adyolo_wino_fwd(const float *x, const float *u, const float *bias, const float *addend,

@@ -245,12 +245,17 @@ class SEBlockFn(torch.autograd.Function):
         bn1, bn2, bnd, link_in, link_out = bns[:5]
         p_aff = bns[5] if len(bns) > 5 else None      # (scale, shift): the input is seen through this per-channel affine
         ctx.stem_holder = bns[6] if len(bns) > 6 else None    # BlockLink of the stem: its BatchNorm backward sums come from our dgrad
+        packs = bns[7] if len(bns) > 7 else None              # (u_fwd1, u_dgrad1, u_fwd2, u_dgrad2) from ops.WinoPackSet, or None
         if p_aff is not None and (pool or wd is not None):
             raise NotImplementedError("p_affine is only supported for identity-shortcut blocks without pooling")
         p = ops.avgpool2(x) if pool else x
         n, h, w_, cin = p.shape
         c = w1.shape[0]
-        wpk1, wpk1d = ops.pack_w3x3(w1, cin)
+        if packs is not None:
+            wpk1, wpk1d, wpk2, wpk2d = packs
+        else:
+            wpk1, wpk1d = ops.pack_w3x3(w1, cin)
+            wpk2, wpk2d = ops.pack_w3x3(w2, c)
         if training and FUSE_STATS:
             a, st1 = ops.conv3x3(p, wpk1, c, relu=True, want_stats=True, in_affine=p_aff)
             _, mean1, invstd1, scale1, shift1 = _BNState(bn1).stats_tiles(st1, a, affine=(g1, b1))
@@ -258,7 +263,6 @@ class SEBlockFn(torch.autograd.Function):
             a = ops.conv3x3(p, wpk1, c, relu=True, in_affine=p_aff)
             _, mean1, invstd1 = _BNState(bn1).stats(a, training)
             scale1, shift1 = ops.bn_scale_shift(g1, b1, mean1, invstd1)
-        wpk2, wpk2d = ops.pack_w3x3(w2, c)
         if FUSE_AFFINE:
             # BN1's affine is applied while conv2 stages its input: bn1(a) is never written to HBM
             src, aff = a, (scale1, shift1)

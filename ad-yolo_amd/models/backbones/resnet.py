@@ -82,13 +82,14 @@ class SEBasicBlock(nn.Module):
         else:
             self.downsample = None
 
-    def forward(self, x, link_in=None, link_out=None, in_affine=None, stem_holder=None):
+    def forward(self, x, link_in=None, link_out=None, in_affine=None, stem_holder=None, packs=None):
         """link_in / link_out: ``functional.BlockLink`` shared with the block below / above (see FUSE_SEBWD);
-        in_affine = (scale, shift): x is seen through this per-channel affine (the stem's un-materialised BatchNorm)."""
+        in_affine = (scale, shift): x is seen through this per-channel affine (the stem's un-materialised BatchNorm);
+        packs = the Winograd-packed filters of conv1 / conv2 from the encoder's ``ops.WinoPackSet`` (one launch for all)."""
         fc0, fc2 = self.se.fc["0"], self.se.fc["2"]
         args = [x, self.training, self.pool,
                 (self.bn1, self.bn2, self.downsample["1"] if self.downsample is not None else None, link_in, link_out,
-                 in_affine, stem_holder),
+                 in_affine, stem_holder, packs),
                 self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight, self.bn2.weight, self.bn2.bias,
                 fc0.weight, fc0.bias, fc2.weight, fc2.bias]
         if self.downsample is not None:
@@ -158,6 +159,7 @@ class SEResnet34(nn.Module):
         # running offset; saved / restored with the checkpoint's rng_state)
         self.dropout_stream = DropoutStream(0x5EED)
         self.dropout_mask_override = None       # tests inject a (B,T',256) mask here
+        self._packs = ops.WinoPackSet()          # Winograd forms of the 32 block filters, refreshed by one launch per forward
 
     def _dropout(self, y):
         p = self.lstm.dropout
@@ -186,13 +188,17 @@ class SEResnet34(nn.Module):
                             self.training, holder)
         stem_affine = holder.affine if holder is not None else None     # the stem's BatchNorm is applied by its consumer
         link = None                              # BlockLink between consecutive blocks (functional.FUSE_SEBWD)
-        for li in range(1, 5):
-            for blk in getattr(self, "layer%d" % li):
-                nxt = Fn.BlockLink()
-                y = blk(y, link_in=link, link_out=nxt, in_affine=stem_affine,
-                        stem_holder=holder if stem_affine is not None else None)
-                stem_affine = None
-                link = nxt
+        blocks = [blk for li in range(1, 5) for blk in getattr(self, "layer%d" % li)]
+        packs = None
+        if ops.conv_algo() == "winograd":        # every block filter packed by ONE launch (64 otherwise)
+            packs = self._packs.refresh([w for blk in blocks for w in (blk.conv1.weight, blk.conv2.weight)])
+        for bi, blk in enumerate(blocks):
+            nxt = Fn.BlockLink()
+            pk = (packs.get(2 * bi) + packs.get(2 * bi + 1)) if packs is not None else None
+            y = blk(y, link_in=link, link_out=nxt, in_affine=stem_affine,
+                    stem_holder=holder if stem_affine is not None else None, packs=pk)
+            stem_affine = None
+            link = nxt
         y = Fn.SAPFn.apply(y, self.attention.W.weight, self.attention.W.bias)
         save = self.training and torch.is_grad_enabled()
         y = Fn.BiGRULayerFn.apply(y, *self.lstm.layer_params(0), save)

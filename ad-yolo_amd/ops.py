@@ -74,6 +74,39 @@ def pack_w3x3(w, cin_pad, want_dgrad=True, algo=None):
     return wf, wd
 
 
+class WinoPackSet:
+    """The Winograd-packed forms (forward + data-gradient) of a fixed list of 3x3 filters, refreshed by ONE launch
+    (``adyolo_wino_pack_many``) instead of two per filter: ``refresh()`` at the start of a forward pass, ``get(i)`` ->
+    (u_fwd, u_dgrad) of filter i.  The buffers and the descriptor table are allocated once and rebuilt only when a filter's
+    storage moves (``.to()``, re-homing into a flat parameter buffer)."""
+
+    def __init__(self):
+        self.key = None
+
+    def refresh(self, weights):
+        key = tuple(w.data_ptr() for w in weights)
+        if key != self.key:
+            dev = weights[0].device
+            self.packs, rows = [], []
+            for w in weights:
+                _chk(w)
+                cout, cin = w.shape[0], w.shape[1]
+                if cout % 32 or cin % 32:
+                    raise _lib.AdyoloHipError("WinoPackSet: channel counts must be multiples of 32")
+                uf, ud = _new(w, 16, cout // 32, cin // 8, 256), _new(w, 16, cin // 32, cout // 8, 256)
+                self.packs.append((uf, ud))
+                rows.append([w.data_ptr(), uf.data_ptr(), ud.data_ptr(), cout, cin, cin])
+            self.table = torch.tensor(rows, dtype=torch.int64, device=dev)
+            self.max_cout = max(w.shape[0] for w in weights)
+            self.max_cin = max(w.shape[1] for w in weights)
+            self.key = key
+        _c("adyolo_wino_pack_many", _p(self.table), len(self.packs), self.max_cout, self.max_cin, _stream())
+        return self
+
+    def get(self, i):
+        return self.packs[i]
+
+
 def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, in_affine=None, want_stats=False,
             stat_bn=None, stat_mask=None):
     """x [N][H][W][Cin] -> [N][H][W][cout];  wpk from ``pack_w3x3`` (direct [cout][9][Cin] or Winograd, rank 4).

@@ -99,6 +99,10 @@ int adyolo_conv3x3_fwd(const float *x, const float *wpk, const float *bias, cons
  *      `u` in place of `wpk`; its `stats` rows are 8x16-pixel patches: adyolo_wino_tiles(N,H,W) of them. */
 int adyolo_wino_pack_w(const float *w /*[Cout][Cin_real][3][3]*/, float *u_fwd /*or NULL*/, float *u_dgrad /*or NULL*/,
                        int Cout, int Cin_real, int Cin, void *stream);
+/* the same for EVERY 3x3 filter of a model in one launch (the packed filters change once per optimizer step, not per layer
+ * call: 64 pack launches per SE-ResNet34 train step become one).  table (device) = n rows of 6 int64:
+ * {w, u_fwd, u_dgrad or 0, Cout, Cin_real, Cin}; max_cout / max_cin = the largest channel counts in the table. */
+int adyolo_wino_pack_many(const int64_t *table, int n, int max_cout, int max_cin, void *stream);
 int adyolo_wino_tiles(int N, int H, int W);
 int adyolo_wino_fwd(const float *x, const float *u, const float *bias, const float *addend,
                     const float *addend_mask, const float *in_scale, const float *in_shift, float *y, float *stats,
