@@ -43,7 +43,9 @@ SIGNATURES = {
     "adyolo_affine_nhwc": (I, [P] * 4 + [L, I, P]),
     "adyolo_bn_bwd_reduce": (I, [P] * 7 + [L, I, P]),
     "adyolo_bn_bwd_tiles": (I, [P, P, P, P, I, I, P]),
-    "adyolo_bn_bwd_apply": (I, [P] * 12 + [L, I, I, P]),
+    "adyolo_bn_bwd_apply": (I, [P] * 12 + [L, I, I, F, P]),
+    "adyolo_bn_persample": (I, [P, P, P, I, I, I, P]),
+    "adyolo_bn_finish": (I, [P] * 10 + [I, I, I, F, F, P]),
     "adyolo_se_fc_fwd": (I, [P] * 10 + [I, I, I, I, P]),
     "adyolo_relu_mask_words": (L, [I, I, I]),
     "adyolo_se_tail_fwd": (I, [P] * 9 + [I, I, I, P]),
@@ -51,7 +53,7 @@ SIGNATURES = {
     "adyolo_se_tail_bwd_tiles": (I, [P, P, P, I, I, I, P]),
     "adyolo_se_fc_bwd_words": (L, [I, I]),
     "adyolo_se_fc_bwd": (I, [P] * 16 + [I, I, I, I, P]),
-    "adyolo_se_tail_bwd_apply": (I, [P] * 13 + [I, I, I, P]),
+    "adyolo_se_tail_bwd_apply": (I, [P] * 13 + [I, I, I, F, P]),
     "adyolo_avgpool2_fwd": (I, [P, P, I, I, I, I, P]),
     "adyolo_avgpool2_bwd": (I, [P, P, I, I, I, I, P]),
     "adyolo_add": (I, [P, P, P, L, P]),
@@ -69,6 +71,7 @@ SIGNATURES = {
     "adyolo_counter_add": (I, [P, U64, P]),
     "adyolo_loss_workspace_words": (L, [I, I, I, I]),
     "adyolo_loss_fwd_bwd": (I, [P] * 6 + [I] * 7 + [P, P, F, F, F, F, P]),
+    "adyolo_loss_phase": (I, [P] * 6 + [I] * 7 + [P, P, F, F, F, F, I, L, P]),
     "adyolo_yolo_decode": (I, [P, P, L, I, I, I, I, F, F, F, P]),
     "adyolo_act_fwd": (I, [P, P, L, I, I, P]),
     "adyolo_act_bwd": (I, [P, P, P, L, I, I, P]),

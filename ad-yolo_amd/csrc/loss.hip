@@ -205,7 +205,9 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const float *__restrict_
                                                         const unsigned *__restrict__ cls_bits,
                                                         const unsigned long long *__restrict__ ang_grad,
                                                         float *__restrict__ dlogit,
-                                                        float *__restrict__ partial, long NA, float grad_scale) {
+                                                        float *__restrict__ partial, long NA, long NA_total,
+                                                        float grad_scale) {
+    // NA_total: anchors of the whole (data-parallel) batch the header's counts refer to (== NA on one device)
     extern __shared__ __attribute__((aligned(16))) float tile[];      // [LM_TILE][CHP]
     __shared__ float red[4][9];
     const int CH = g.C + 3;
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void loss_main_kernel(const float *__restrict_
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         npos[i] = (float)hdr[i];
-        nneg[i] = (float)(NA - (long)hdr[i]);
+        nneg[i] = (float)(NA_total - (long)hdr[i]);
     }
     const float npairs = (float)hdr[3];
     float wpos[3], wneg[3], wcls[3];
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const float *__restrict
         for (int k = 0; k < 256; ++k) ang += red[k];
         double total = (double)g.gain_ang * ang / (double)hdr[3];
         for (int i = 0; i < 3; ++i) {
-            const double np_ = (double)hdr[i], nn_ = (double)(NA - (long)hdr[i]);
+            const double np_ = (double)hdr[i], nn_ = (double)(NA - (long)hdr[i]);   // (NA here = the batch total)
             total += ((double)g.gain_obj * tot[i] / np_ + (double)g.gain_nonobj * tot[3 + i] / nn_ +
                       (double)g.gain_cls * tot[6 + i] / (np_ * (double)g.C)) / 3.0;
         }
@@ -379,16 +381,23 @@ extern "C" long adyolo_loss_workspace_words(int BT, int G, int A, int M) {
     return LOSS_HDR + 8 * NA + 5L * LOSS_ASSIGN_BLOCKS + 9L * LOSS_MAIN_BLOCKS + 64;
 }
 
-extern "C" int adyolo_loss_fwd_bwd(const float *logit, const float *target, float *ws, float *loss, float *dlogit,
-                                   float *dist, int B, int T, int Gaz, int Gel, int A, int C, int M,
-                                   const float *thr_host, const float *gains_host, float grid_az, float grid_el,
-                                   float g_overlap, float grad_scale, void *stream) {
+// phases: 1 = workspace reset + assignment (fills the header's counts), 2 = the pass over the logits + the final sum.  One
+// device runs both back to back (adyolo_loss_fwd_bwd).  Under EXACT data parallelism the header's four counts (distinct
+// positives per threshold, responsible pairs) are all-reduced between the phases and phase 2 gets the anchor count of the
+// whole batch (na_total): every term is then normalised like the single-device loss on the concatenated batch
+// (loss.py:236-243), and the per-rank loss values add up to it.
+extern "C" int adyolo_loss_phase(const float *logit, const float *target, float *ws, float *loss, float *dlogit,
+                                 float *dist, int B, int T, int Gaz, int Gel, int A, int C, int M,
+                                 const float *thr_host, const float *gains_host, float grid_az, float grid_el,
+                                 float g_overlap, float grad_scale, int phases, long na_total, void *stream) {
     ADYOLO_REQUIRE(logit && target && ws && loss && thr_host && gains_host, ADYOLO_EINVAL, "loss: null pointer");
     ADYOLO_REQUIRE(B > 0 && T > 0 && Gaz > 0 && Gel > 0 && A > 0 && A <= 8 && C > 0 && C <= 32, ADYOLO_ENOSUP,
                    "loss: unsupported geometry A=%d (<=8) C=%d (<=32)", A, C);
     ADYOLO_REQUIRE(M > 0, ADYOLO_EINVAL, "loss: M == 0 (the reference fails on an empty target too, loss.py:224)");
     hipStream_t st = as_stream(stream);
     const long NA = (long)B * T * Gaz * Gel * A;
+    ADYOLO_REQUIRE((phases & ~3) == 0 && phases != 0 && (na_total == 0 || na_total >= NA), ADYOLO_EINVAL, "loss: bad phases / na_total");
+    if (na_total == 0) na_total = NA;
     LossGeom g;
     g.B = B; g.T = T; g.Gaz = Gaz; g.Gel = Gel; g.A = A; g.C = C; g.M = M;
     for (int i = 0; i < 3; ++i) g.thr[i] = thr_host[i];
@@ -403,27 +412,40 @@ extern "C" int adyolo_loss_fwd_bwd(const float *logit, const float *target, floa
     int nang = cdiv(M, 32);                 // 8 lanes per target row: 32 rows per workgroup and round
     if (nang > LOSS_ASSIGN_BLOCKS) nang = LOSS_ASSIGN_BLOCKS;
     float *partial = ang_partial + 5 * LOSS_ASSIGN_BLOCKS;
+    int rc = 0;
+    if (phases & 1) {
+        rc = fill32(ws, 0u, (size_t)(LOSS_HDR + 8 * NA), st);             // (a kernel, not a memset node: see common.hpp)
+        if (rc) return rc;
+        hipLaunchKernelGGL(loss_assign_kernel, dim3(nang), dim3(256), 0, st, logit, target, g, hdr, pos_bits, cls_bits,
+                           ang_grad, ang_partial, dist, NA);
+        rc = check_launch("loss_assign");
+        if (rc) return rc;
+    }
+    if (phases & 2) {
+        long nb = (NA + LM_TILE - 1) / LM_TILE;
+        if (nb > LOSS_MAIN_BLOCKS) nb = LOSS_MAIN_BLOCKS;
+        const int CH = C + 3;
+        if (CH & 1)
+            hipLaunchKernelGGL(loss_main_kernel<false>, dim3((unsigned)nb), dim3(256), (size_t)LM_TILE * CH * 4, st, logit, g,
+                               hdr, pos_bits, cls_bits, ang_grad, dlogit, partial, NA, na_total, grad_scale);
+        else
+            hipLaunchKernelGGL(loss_main_kernel<true>, dim3((unsigned)nb), dim3(256), (size_t)(LM_TILE + 1) * (CH + 1) * 4, st,
+                               logit, g, hdr, pos_bits, cls_bits, ang_grad, dlogit, partial, NA, na_total, grad_scale);
+        rc = check_launch("loss_main");
+        if (rc) return rc;
+        hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, partial, (int)nb, ang_partial, nang, hdr, g,
+                           na_total, loss);
+        rc = check_launch("loss_final");
+    }
+    return rc;
+}
 
-    int rc = fill32(ws, 0u, (size_t)(LOSS_HDR + 8 * NA), st);             // (a kernel, not a memset node: see common.hpp)
-    if (rc) return rc;
-    hipLaunchKernelGGL(loss_assign_kernel, dim3(nang), dim3(256), 0, st, logit, target, g, hdr, pos_bits, cls_bits,
-                       ang_grad, ang_partial, dist, NA);
-    rc = check_launch("loss_assign");
-    if (rc) return rc;
-    long nb = (NA + LM_TILE - 1) / LM_TILE;
-    if (nb > LOSS_MAIN_BLOCKS) nb = LOSS_MAIN_BLOCKS;
-    const int CH = C + 3;
-    if (CH & 1)
-        hipLaunchKernelGGL(loss_main_kernel<false>, dim3((unsigned)nb), dim3(256), (size_t)LM_TILE * CH * 4, st, logit, g, hdr,
-                           pos_bits, cls_bits, ang_grad, dlogit, partial, NA, grad_scale);
-    else
-        hipLaunchKernelGGL(loss_main_kernel<true>, dim3((unsigned)nb), dim3(256), (size_t)(LM_TILE + 1) * (CH + 1) * 4, st, logit, g,
-                           hdr, pos_bits, cls_bits, ang_grad, dlogit, partial, NA, grad_scale);
-    rc = check_launch("loss_main");
-    if (rc) return rc;
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, partial, (int)nb, ang_partial, nang, hdr, g, NA,
-                       loss);
-    return check_launch("loss_final");
+extern "C" int adyolo_loss_fwd_bwd(const float *logit, const float *target, float *ws, float *loss, float *dlogit,
+                                   float *dist, int B, int T, int Gaz, int Gel, int A, int C, int M,
+                                   const float *thr_host, const float *gains_host, float grid_az, float grid_el,
+                                   float g_overlap, float grad_scale, void *stream) {
+    return adyolo_loss_phase(logit, target, ws, loss, dlogit, dist, B, T, Gaz, Gel, A, C, M, thr_host, gains_host, grid_az,
+                             grid_el, g_overlap, grad_scale, 3, 0, stream);
 }
 
 // ---- K8b: AD-YOLO decode for inference (reference datasets.py:752-771, LabelPostProcessor.get_yolo_output) ----

@@ -613,6 +613,25 @@ extern "C" int adyolo_bn_stats_tiles(const float *tile_stats, float *ssum, float
     return check_launch("bn_stats_tiles_final");
 }
 
+// the two halves of adyolo_bn_stats_tiles as separate calls: under exact data parallelism the per-sample sums of all ranks
+// are gathered between them, so that N ranks compute the statistics of the concatenated batch (bit-identical to one device)
+extern "C" int adyolo_bn_persample(const float *tile_stats, float *ps0, float *ps1, int N, int G, int C, void *stream) {
+    ADYOLO_REQUIRE(tile_stats && ps0 && ps1 && N > 0 && G > 0 && C > 0, ADYOLO_EINVAL, "bn_persample: bad arguments");
+    hipLaunchKernelGGL(persample_reduce_kernel, dim3(cdiv(C, 32), N), dim3(256), 0, as_stream(stream), tile_stats, ps0, ps1,
+                       N, G, C);
+    return check_launch("bn_persample");
+}
+
+extern "C" int adyolo_bn_finish(const float *ps0, const float *ps1, float *mean, float *invstd, float *running_mean,
+                                float *running_var, const float *gamma, const float *beta, float *scale, float *shift,
+                                int N, int HW, int C, float momentum, float eps, void *stream) {
+    ADYOLO_REQUIRE(ps0 && ps1 && mean && invstd && N > 0 && HW > 0 && C > 0, ADYOLO_EINVAL, "bn_finish: bad arguments");
+    ADYOLO_REQUIRE(!scale || (gamma && beta && shift), ADYOLO_EINVAL, "bn_finish: scale needs gamma, beta and shift");
+    hipLaunchKernelGGL(bn_finish_kernel, dim3(cdiv(C, 32)), dim3(256), 0, as_stream(stream), ps0, ps1, mean, invstd,
+                       running_mean, running_var, gamma, beta, scale, shift, N, C, (double)N * (double)HW, momentum, eps);
+    return check_launch("bn_finish");
+}
+
 extern "C" int adyolo_bn_eval_stats(const float *running_mean, const float *running_var, float *mean, float *invstd,
                                     int C, float eps, void *stream) {
     ADYOLO_REQUIRE(running_mean && running_var && mean && invstd && C > 0, ADYOLO_EINVAL, "bn_eval_stats: bad arguments");
@@ -680,9 +699,10 @@ extern "C" int adyolo_bn_bwd_tiles(const float *tile_stats, float *sdy, float *s
 extern "C" int adyolo_bn_bwd_apply(const float *dy, const float *x, const float *gamma, const float *mean,
                                    const float *invstd, const float *sdy, const float *sdyx, float *dx, float *dgamma,
                                    float *dbeta, float *dx_colsum, float *colsum_partial, long rows, int C,
-                                   int relu_mask, void *stream) {
-    ADYOLO_REQUIRE(dy && x && gamma && mean && invstd && sdy && sdyx && dx && rows > 0 && C % 4 == 0, ADYOLO_EINVAL,
-                   "bn_bwd_apply: bad arguments");
+                                   int relu_mask, float count_scale, void *stream) {
+    ADYOLO_REQUIRE(dy && x && gamma && mean && invstd && sdy && sdyx && dx && rows > 0 && C % 4 == 0 && count_scale >= 1.f,
+                   ADYOLO_EINVAL, "bn_bwd_apply: bad arguments");
+    const float inv_r = (float)(1.0 / ((double)rows * (double)count_scale));      // batch sums over count_scale equal micro-batches
     hipStream_t st = as_stream(stream);
     const long n4 = rows * (C / 4);
     ADYOLO_REQUIRE(!dx_colsum || (colsum_partial && 256 % (C / 4) == 0), ADYOLO_EINVAL,
@@ -691,10 +711,10 @@ extern "C" int adyolo_bn_bwd_apply(const float *dy, const float *x, const float 
     const int grid = ew_grid(inv ? cdiv(n4, (long)EW_U) : n4);
     if (inv)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid), dim3(256), 0, st, dy, x, gamma, mean, invstd, sdy, sdyx, dx,
-                           dx_colsum ? colsum_partial : (float *)nullptr, n4, C / 4, (float)(1.0 / (double)rows), relu_mask);
+                           dx_colsum ? colsum_partial : (float *)nullptr, n4, C / 4, inv_r, relu_mask);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0, st, dy, x, gamma, mean, invstd, sdy, sdyx, dx,
-                           dx_colsum ? colsum_partial : (float *)nullptr, n4, C / 4, (float)(1.0 / (double)rows), relu_mask);
+                           dx_colsum ? colsum_partial : (float *)nullptr, n4, C / 4, inv_r, relu_mask);
     int rc = check_launch("bn_bwd_apply");
     if (rc) return rc;
     if (dx_colsum) {
@@ -791,10 +811,11 @@ extern "C" int adyolo_se_fc_bwd(const float *sg, const float *sgx, const float *
 extern "C" int adyolo_se_tail_bwd_apply(const float *de, const float *e, const uint64_t *mask, const float *c,
                                         const float *gamma, const float *mean, const float *invstd, const float *s,
                                         const float *dpool, const float *sdd, const float *sddx, float *dc, float *dr,
-                                        int N, int HW, int C, void *stream) {
+                                        int N, int HW, int C, float count_scale, void *stream) {
     ADYOLO_REQUIRE(de && (e || mask) && c && gamma && mean && invstd && s && dpool && sdd && sddx && dc && N > 0 &&
-                       HW > 0 && C % 4 == 0,
+                       HW > 0 && C % 4 == 0 && count_scale >= 1.f,
                    ADYOLO_EINVAL, "se_tail_bwd_apply: bad arguments");
+    const float inv_r = (float)(1.0 / ((double)N * (double)HW * (double)count_scale));
     const long hw4 = (long)HW * (C / 4);
     const bool inv = 256 % (C / 4) == 0;
     int gx = ew_grid(inv ? cdiv(hw4, (long)EW_U) : hw4);
@@ -802,11 +823,11 @@ extern "C" int adyolo_se_tail_bwd_apply(const float *de, const float *e, const u
     if (inv)
         hipLaunchKernelGGL(se_tail_bwd_apply_kernel<true>, dim3(gx, N), dim3(256), 0, as_stream(stream), de, e, c, gamma,
                            mean, invstd, s, dpool, sdd, sddx, dc, dr, reinterpret_cast<const unsigned long long *>(mask),
-                           hw4, C / 4, 1.0f / (float)HW, (float)(1.0 / ((double)N * (double)HW)));
+                           hw4, C / 4, 1.0f / (float)HW, inv_r);
     else
         hipLaunchKernelGGL(se_tail_bwd_apply_kernel<false>, dim3(gx, N), dim3(256), 0, as_stream(stream), de, e, c, gamma,
                            mean, invstd, s, dpool, sdd, sddx, dc, dr, reinterpret_cast<const unsigned long long *>(mask),
-                           hw4, C / 4, 1.0f / (float)HW, (float)(1.0 / ((double)N * (double)HW)));
+                           hw4, C / 4, 1.0f / (float)HW, inv_r);
     return check_launch("se_tail_bwd_apply");
 }
 

@@ -44,6 +44,50 @@ def _zeros(like, *shape):
     return torch.zeros(shape, dtype=torch.float32, device=like.device)
 
 
+# ---------------------------------------------------------------------------------------------- exact data parallelism
+class ExactDP:
+    """Switch + collectives of EXACT data parallelism (``train.TrainStep(exact=True)`` / ADYOLO_DP_EXACT=1): every quantity
+    the reference normalises over the batch is formed over the batch of ALL ranks, so N ranks on N equal shards compute what
+    one device computes on the concatenated batch (SURVEY.md section 8e "optional"; the reference itself is single-device,
+    src/train.py:40-62).  Three places need an exchange, all tiny:
+      * BatchNorm forward (36 layers): the per-sample sums (sum, sum of squares) [B][C] of every rank are all-gathered in rank
+        order and finished by the same kernel as on one device -> bit-identical batch statistics and running statistics;
+      * BatchNorm backward (36 layers, incl. the BatchNorm folded into the SE tail): the two per-channel sums are all-reduced
+        for the dx formula; the parameter gradients written to the flat buffer stay local (the bucket all-reduce sums them);
+      * the AD-YOLO loss: the four counts (distinct positives per threshold, responsible pairs) are all-reduced between the
+        assignment and the pass over the logits; the returned loss is the sum of the ranks' shares.
+    Gradients are then SUMMED over the ranks (not averaged).  Off (world 1, or not enabled): everything is local, the
+    DDP-conventional semantics of ``dist.py``."""
+
+    def __init__(self):
+        self.on, self.world, self.group = False, 1, None
+
+    def enable(self, group=None):
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.on = self.world > 1
+        return self.on
+
+    def disable(self):
+        self.on = False
+
+    def all_reduce(self, t):
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def gather_rows(self, t):
+        """[n][c] of every rank -> [world * n][c] in rank order (== the row order of the concatenated batch)."""
+        import torch.distributed as dist
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(parts, t.contiguous(), group=self.group)
+        return torch.cat(parts, 0)
+
+
+EXACT = ExactDP()
+
+
 # ---------------------------------------------------------------------------------------------- conv
 def conv_algo():
     """'winograd' (default: F(2x2,3x3) on the fp32 MFMA, 2.25x fewer matrix FLOPs) or 'direct' (implicit GEMM);
@@ -252,6 +296,13 @@ def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
     hw = x.numel() // (n * c)
     ssum, mean, invstd = _new(x, n, c), _new(x, c), _new(x, c)
     partial = _new(x, 4 * 1024 * c)
+    if EXACT.on and running_mean is not None:         # training statistics over the batch of all ranks
+        _c("adyolo_bn_stats", _p(x), _p(ssum), _p(mean), _p(invstd), NULL, NULL, _p(partial), n, hw, c, momentum, eps, _stream())
+        ps1 = partial[3 * 1024 * c:3 * 1024 * c + n * c].view(n, c)          # per-sample sums of squares (layout of the C side)
+        g0, g1 = EXACT.gather_rows(ssum), EXACT.gather_rows(ps1)
+        _c("adyolo_bn_finish", _p(g0), _p(g1), _p(mean), _p(invstd), _p(running_mean), _p(running_var), NULL, NULL, NULL, NULL,
+           g0.shape[0], hw, c, momentum, eps, _stream())
+        return ssum, mean, invstd
     _c("adyolo_bn_stats", _p(x), _p(ssum), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(partial), n,
        hw, c, momentum, eps, _stream())
     return ssum, mean, invstd
@@ -265,9 +316,16 @@ def bn_stats_tiles(tile_stats, n, hw, running_mean=None, running_var=None, momen
     tiles, c = tile_stats.shape[1], tile_stats.shape[2]
     ssum, mean, invstd = _new(tile_stats, n, c), _new(tile_stats, c), _new(tile_stats, c)
     scale, shift = (_new(tile_stats, c), _new(tile_stats, c)) if gamma is not None else (None, None)
-    partial = _new(tile_stats, 2 * 1024 * c)
-    _c("adyolo_bn_stats_tiles", _p(tile_stats), _p(ssum), _p(mean), _p(invstd), _p(running_mean), _p(running_var),
-       _p(gamma), _p(beta), _p(scale), _p(shift), _p(partial), n, tiles // n, hw, c, momentum, eps, _stream())
+    if EXACT.on and running_mean is not None:         # training statistics over the batch of all ranks
+        ps1 = _new(tile_stats, n, c)
+        _c("adyolo_bn_persample", _p(tile_stats), _p(ssum), _p(ps1), n, tiles // n, c, _stream())
+        g0, g1 = EXACT.gather_rows(ssum), EXACT.gather_rows(ps1)
+        _c("adyolo_bn_finish", _p(g0), _p(g1), _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(gamma), _p(beta),
+           _p(scale), _p(shift), g0.shape[0], hw, c, momentum, eps, _stream())
+    else:
+        partial = _new(tile_stats, 2 * 1024 * c)
+        _c("adyolo_bn_stats_tiles", _p(tile_stats), _p(ssum), _p(mean), _p(invstd), _p(running_mean), _p(running_var),
+           _p(gamma), _p(beta), _p(scale), _p(shift), _p(partial), n, tiles // n, hw, c, momentum, eps, _stream())
     if gamma is not None:
         return ssum, mean, invstd, scale, shift
     return ssum, mean, invstd
@@ -317,8 +375,12 @@ def bn_bwd(dy, x, gamma, mean, invstd, relu_mask=False, tile_stats=None, out_dga
     colsum = part = None
     if want_dx_colsum:          # channel sums of dx from the same pass (e.g. the bias gradient of the producing convolution)
         colsum, part = _new(x, c), _new(x, 8192, c)
-    _c("adyolo_bn_bwd_apply", _p(dy), _p(x), _p(gamma), _p(mean), _p(invstd), _p(sdy), _p(sdyx), _p(dx), NULL, NULL,
-       _p(colsum), _p(part), rows, c, int(relu_mask), _stream())
+    a_sdy, a_sdyx, cs = sdy, sdyx, 1.0
+    if EXACT.on:                # the dx formula needs the sums over the batch of ALL ranks; sdy / sdyx (= the parameter
+        glob = EXACT.all_reduce(torch.stack([sdy, sdyx]))      # gradients, possibly slices of the flat buffer) stay local
+        a_sdy, a_sdyx, cs = glob[0], glob[1], float(EXACT.world)
+    _c("adyolo_bn_bwd_apply", _p(dy), _p(x), _p(gamma), _p(mean), _p(invstd), _p(a_sdy), _p(a_sdyx), _p(dx), NULL, NULL,
+       _p(colsum), _p(part), rows, c, int(relu_mask), cs, _stream())
     if want_dx_colsum:
         return dx, sdyx, sdy, colsum
     return dx, sdyx, sdy
@@ -386,8 +448,12 @@ def se_tail_bwd(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1,
     dgamma, dbeta = sddx, sdd
     dc = torch.empty_like(c_t)
     dr = torch.empty_like(c_t) if want_dr else None
+    a_sdd, a_sddx, cs = sdd, sddx, 1.0
+    if EXACT.on:                # BN2's batch sums over all ranks for the dc formula; the packed parameter gradients stay local
+        glob = EXACT.all_reduce(torch.stack([sdd, sddx]))
+        a_sdd, a_sddx, cs = glob[0], glob[1], float(EXACT.world)
     _c("adyolo_se_tail_bwd_apply", _p(de), _p(e), _p(mask), _p(c_t), _p(gamma), _p(mean), _p(invstd), _p(s), _p(dpool),
-       _p(sdd), _p(sddx), _p(dc), _p(dr), n, hw, ch, _stream())
+       _p(a_sdd), _p(a_sddx), _p(dc), _p(dr), n, hw, ch, cs, _stream())
     return dc, dr, dgamma, dbeta, dw1, db1, dw2, db2
 
 
@@ -508,9 +574,17 @@ def adyolo_loss(logit, target, nb_classes, grid=(8, 4), anchors=5, thr=(45.0, 25
     dist = _new(logit, m, anchors) if want_dist else None
     thr_h = (ctypes.c_float * 3)(*[float(v) for v in thr])
     gains_h = (ctypes.c_float * 4)(*[float(v) for v in gains])
-    _c("adyolo_loss_fwd_bwd", _p(logit), _p(target), _p(ws), _p(loss), _p(dlogit), _p(dist), b, t, grid[0], grid[1],
-       anchors, nb_classes, m, ctypes.cast(thr_h, ctypes.c_void_p), ctypes.cast(gains_h, ctypes.c_void_p),
-       float(grid_size[0]), float(grid_size[1]), float(g_overlap), float(grad_scale), _stream())
+    args = (_p(logit), _p(target), _p(ws), _p(loss), _p(dlogit), _p(dist), b, t, grid[0], grid[1],
+            anchors, nb_classes, m, ctypes.cast(thr_h, ctypes.c_void_p), ctypes.cast(gains_h, ctypes.c_void_p),
+            float(grid_size[0]), float(grid_size[1]), float(g_overlap), float(grad_scale))
+    if EXACT.on:                # counts over the batch of all ranks between the assignment and the pass over the logits
+        _c("adyolo_loss_phase", *args, 1, 0, _stream())
+        EXACT.all_reduce(ws[:4].view(torch.int32))
+        na = b * t * grid[0] * grid[1] * anchors
+        _c("adyolo_loss_phase", *args, 2, na * EXACT.world, _stream())
+        EXACT.all_reduce(loss)                          # the ranks' shares add up to the loss of the concatenated batch
+    else:
+        _c("adyolo_loss_fwd_bwd", *args, _stream())
     return loss, dlogit, dist
 
 

@@ -92,12 +92,15 @@ class TrainStep:
     the eager path.  Single-process only (under data parallelism the RCCL hooks stay eager).
     """
 
-    def __init__(self, model, criterion, feature_extractor, params=None, n_buckets=4, lr=1e-3, graph=None):
+    def __init__(self, model, criterion, feature_extractor, params=None, n_buckets=4, lr=1e-3, graph=None, exact=None):
         self.model, self.criterion, self.features = model, criterion, feature_extractor
         self.flat = FlatParameters(model)
         self.flat.broadcast(0)                   # no-op on one rank: all ranks start from rank 0's parameters / buffers
         self.optimizer = get_optimizers(params, self.flat) if params is not None else FusedAdam(self.flat, lr=lr)
         self.reducer = BucketedAllReduce(self.flat, n_buckets=n_buckets)
+        # exact=True (default: ADYOLO_DP_EXACT=1): batch statistics and loss normalisers over the batch of ALL ranks
+        # (ops.ExactDP) -- N ranks on N equal shards == one device on the concatenated batch; gradients are summed
+        self.exact = (os.environ.get("ADYOLO_DP_EXACT", "0") == "1") if exact is None else bool(exact)
         if graph is None:
             graph = os.environ.get("ADYOLO_GRAPH", "0") == "1"
         self.graphs = None
@@ -112,17 +115,21 @@ class TrainStep:
 
     def step_eager(self, audio, target):
         self.model.train()
-        feat = self.features(audio, channels_last8=True)
-        output = self.model(feat, channels_last8=True)
-        self.optimizer.zero_grad()
-        loss = self.criterion(output, target)
-        Fn.SINK.begin(self.flat, self.reducer)       # weight / BatchNorm / SE gradients go straight into the flat buffer
+        exact = self.exact and ops.EXACT.enable(self.reducer.group)
         try:
-            loss.backward()
+            feat = self.features(audio, channels_last8=True)
+            output = self.model(feat, channels_last8=True)
+            self.optimizer.zero_grad()
+            loss = self.criterion(output, target)
+            Fn.SINK.begin(self.flat, self.reducer)       # weight / BatchNorm / SE gradients go straight into the flat buffer
+            try:
+                loss.backward()
+            finally:
+                Fn.SINK.end()
         finally:
-            Fn.SINK.end()
+            ops.EXACT.disable()
         scale = self.reducer.finish()
-        self.optimizer.step(grad_scale=scale)
+        self.optimizer.step(grad_scale=1.0 if exact else scale)       # exact: the ranks' gradients ADD UP to the batch's
         return loss.detach()
 
 

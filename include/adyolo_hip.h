@@ -163,6 +163,14 @@ int adyolo_bn_stats(const float *x, float *ssum, float *mean, float *invstd, flo
 int adyolo_bn_stats_tiles(const float *tile_stats, float *ssum, float *mean, float *invstd, float *running_mean,
                           float *running_var, const float *gamma, const float *beta, float *scale, float *shift,
                           float *partial, int N, int G, int HW, int C, float momentum, float eps, void *stream);
+/* the two halves of adyolo_bn_stats_tiles as separate calls (per-patch sums -> per-sample sums ps0 / ps1 [N][C];  per-sample
+ * sums -> mean / invstd / running statistics / scale / shift over N samples of HW positions).  Exact data parallelism
+ * all-gathers the per-sample sums of all ranks between the two, so N ranks compute the statistics of the concatenated
+ * batch bit-identically to one device. */
+int adyolo_bn_persample(const float *tile_stats, float *ps0, float *ps1, int N, int G, int C, void *stream);
+int adyolo_bn_finish(const float *ps0, const float *ps1, float *mean, float *invstd, float *running_mean,
+                     float *running_var, const float *gamma, const float *beta, float *scale, float *shift, int N,
+                     int HW, int C, float momentum, float eps, void *stream);
 int adyolo_bn_eval_stats(const float *running_mean, const float *running_var, float *mean,
                          float *invstd, int C, float eps, void *stream);
 int adyolo_bn_scale_shift(const float *gamma, const float *beta, const float *mean,
@@ -177,7 +185,9 @@ int adyolo_bn_bwd_tiles(const float *tile_stats, float *sdy, float *sdyx, float 
 int adyolo_bn_bwd_apply(const float *dy, const float *x, const float *gamma, const float *mean,
                         const float *invstd, const float *sdy, const float *sdyx, float *dx,
                         float *dgamma, float *dbeta, float *dx_colsum /*or NULL: [C] channel sums of dx*/,
-                        float *colsum_partial /*[8192][C] workspace when dx_colsum*/, long rows, int C, int relu_mask, void *stream);
+                        float *colsum_partial /*[8192][C] workspace when dx_colsum*/, long rows, int C, int relu_mask,
+                        float count_scale /*1, or the number of equal data-parallel micro-batches sdy / sdyx were summed over*/,
+                        void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K3b squeeze-excite + residual tail of SEBasicBlock (resnet.py:38-47, SELayer :91-106), fused:
@@ -220,7 +230,7 @@ int adyolo_se_fc_bwd(const float *sg, const float *sgx, const float *ssum, const
 int adyolo_se_tail_bwd_apply(const float *de, const float *e, const uint64_t *mask /*or NULL*/, const float *c,
                              const float *gamma, const float *mean, const float *invstd, const float *s,
                              const float *dpool, const float *sdd, const float *sddx, float *dc,
-                             float *dr, int N, int HW, int C, void *stream);
+                             float *dr, int N, int HW, int C, float count_scale /*as in adyolo_bn_bwd_apply*/, void *stream);
 
 /* K4  AvgPool2d(2,2) (resnet.py:13,27-29), channels-last; H and W even.  bwd: dx = dy/4 broadcast (+= if accumulate) */
 int adyolo_avgpool2_fwd(const float *x, float *y, int N, int H, int W, int C, void *stream);
@@ -287,6 +297,14 @@ int  adyolo_loss_fwd_bwd(const float *logit, const float *target, float *ws, flo
                          float *dlogit, float *dist, int B, int T, int Gaz, int Gel, int A, int C,
                          int M, const float *thr_host, const float *gains_host, float grid_az,
                          float grid_el, float g_overlap, float grad_scale, void *stream);
+/* the same in two phases (phases bit 0: workspace reset + assignment, bit 1: pass over the logits + final sum).  Exact data
+ * parallelism all-reduces the first four 32-bit words of the workspace (distinct positives per threshold, responsible pairs)
+ * between the phases and passes na_total = anchors of the whole batch (0: this call's own), so that every loss term is
+ * normalised as on one device over the concatenated batch (loss.py:236-243). */
+int  adyolo_loss_phase(const float *logit, const float *target, float *ws, float *loss,
+                       float *dlogit, float *dist, int B, int T, int Gaz, int Gel, int A, int C,
+                       int M, const float *thr_host, const float *gains_host, float grid_az,
+                       float grid_el, float g_overlap, float grad_scale, int phases, long na_total, void *stream);
 
 /* K8b inference decode (LabelPostProcessor.get_yolo_output, src/datasets.py:752-771): per anchor
  *   out = [sigmoid(obj), sigmoid(cls_c)*sigmoid(obj) x C, U deg in [-180,180), V deg in [-90, 90-1e-7]];

@@ -821,3 +821,112 @@ def test_two_ranks_on_the_real_model_match_the_sequential_emulation(ops):
         assert outs[rk]["losses"] == emu["losses"][rk]
         assert outs[rk]["bn"] == emu["bn"][rk]
     assert outs[0]["bn"] != outs[1]["bn"]                                 # per-rank running statistics (different shards)
+
+
+_DPX_CHILD = r"""
+import json, os, sys
+sys.path.insert(0, os.environ["ADYOLO_REPO"])
+import torch
+import torch.distributed as dist
+import adyolo_amd
+import bench
+from adyolo_amd import dist as adist
+from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
+from adyolo_amd.features import FeatureExtractor
+from adyolo_amd.datasets import synthetic_audio, synthetic_targets
+from adyolo_amd.train import TrainStep
+
+mode = os.environ["ADYOLO_DPX_MODE"]                    # "rank": one of two exact-mode processes; "single": the whole batch
+b, n = 2, 24000 * 4                                     # clips per rank
+
+
+def data(r):
+    return synthetic_audio(b, n, seed=50 + r), synthetic_targets(b, n // 2400, 12, seed=60 + r)
+
+
+if mode == "rank":
+    rank, world, _ = adist.init_from_env("gloo")        # two ranks on ONE GPU: gloo (RCCL refuses that)
+    audio, target = data(rank)
+else:
+    rank, world = 0, 1
+    (a0, t0), (a1, t1) = data(0), data(1)
+    t1 = t1.clone()
+    t1[:, 0] += b                                       # rank 1's clips are samples b .. 2b-1 of the concatenated batch
+    audio, target = torch.cat([a0, a1]), torch.cat([t0, t1])
+torch.manual_seed(100)
+prm = bench.params("cuda:0")
+model = WrapperModel((1, 7, n // 600, 64), (), prm).to("cuda:0")
+model.encoder.lstm.dropout = 0.0
+tr = TrainStep(model, WrapperCriterion(prm), FeatureExtractor(None, "cuda:0"), prm, exact=True)
+audio, target = audio.to("cuda:0"), target.to("cuda:0")
+grads, losses = [], []
+opt_step = tr.optimizer.step
+
+
+def spy(grad_scale=1.0):
+    grads.append(tr.flat.flat_grad.clone())
+    assert grad_scale == 1.0                            # exact mode (and one device): gradients are sums, never averaged
+    opt_step(grad_scale=grad_scale)
+tr.optimizer.step = spy
+for _ in range(3):
+    losses.append(float(tr.step(audio, target)))
+torch.cuda.synchronize()
+sd = tr.model.state_dict()
+torch.save({"grad0": grads[0].cpu(), "params": tr.flat.flat.cpu(), "losses": losses,
+            "bn": {k: v.cpu() for k, v in sd.items() if "running_" in k},
+            "layout": [(off, cnt) for off, cnt in tr.flat.offsets]}, os.environ["ADYOLO_DPX_OUT"])
+print(json.dumps({"ok": True, "rank": rank, "losses": losses}))
+if dist.is_initialized():
+    dist.barrier()
+    dist.destroy_process_group()
+"""
+
+
+def test_exact_data_parallel_equals_one_device_on_the_concatenated_batch(ops, tmp_path):
+    """``TrainStep(exact=True)`` (ops.ExactDP; SURVEY 8e "optional"): two ranks on two different 2-clip shards (two processes
+    on this one GPU, gloo) against ONE process on the 4-clip concatenation, real SE-ResNet34 + AD-YOLO model, 3 Adam steps.
+    BatchNorm statistics are formed over all ranks' samples by the same finishing kernel on the gathered per-sample sums
+    -> running statistics BIT-identical after step 1 and within 1e-6 after 3; the loss counts are all-reduced -> the loss
+    values agree to 1e-6; the gradients Adam sees in step 0 (summed over the ranks, not averaged) agree per parameter tensor
+    to 2e-5 of its absmax (only summation orders differ); both ranks hold the same parameters."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, ADYOLO_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base.pop("ADYOLO_FORCE_DP_HOOKS", None)
+    outs = [str(tmp_path / ("r%d.pt" % r)) for r in range(2)] + [str(tmp_path / "single.pt")]
+    procs = [subprocess.Popen([sys.executable, "-c", _DPX_CHILD],
+                              env=dict(base, ADYOLO_DPX_MODE="rank", WORLD_SIZE="2", RANK=str(r), LOCAL_RANK="0", ADYOLO_DPX_OUT=outs[r]),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, e[-3000:]
+    r = subprocess.run([sys.executable, "-c", _DPX_CHILD], env=dict(base, ADYOLO_DPX_MODE="single", WORLD_SIZE="1", RANK="0", ADYOLO_DPX_OUT=outs[2]),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r0, r1, one = (torch.load(f) for f in outs)
+    assert torch.equal(r0["params"], r1["params"]) and torch.equal(r0["grad0"], r1["grad0"]), "ranks diverged"
+    for a, c in zip(r0["losses"], one["losses"]):
+        assert abs(a - c) <= 1e-6 * abs(c) + 1e-7, (r0["losses"], one["losses"])
+    worst = 0.0
+    for off, cnt in one["layout"]:
+        g, h = r0["grad0"][off:off + cnt].double(), one["grad0"][off:off + cnt].double()
+        am = float(h.abs().max())
+        if am > 0:
+            worst = max(worst, float((g - h).abs().max()) / am)
+    assert worst <= 2e-5, "step-0 gradients: worst tensor deviates by %.2e of its absmax" % worst
+    for k, v in one["bn"].items():
+        d = float((r0["bn"][k] - v).abs().max())
+        assert d <= 1e-6 * max(1.0, float(v.abs().max())), (k, d)
+    rel = float((r0["params"] - one["params"]).abs().mean()) / float(one["params"].abs().mean())
+    assert rel <= 1e-5, "parameters after 3 steps: mean deviation %.2e of the mean magnitude" % rel
