@@ -132,7 +132,7 @@ def load_traffic(wino):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r0N_traffic.json: rocprofv3
     --pmc FETCH_SIZE and --pmc WRITE_SIZE over this same command, corrected as MI355X_MICROARCH.md prescribes);
     counters cannot be collected inside the timed run, so this is null when no PMC summary matches the algorithm."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)
@@ -292,6 +292,43 @@ def run_extra_config(name, torch, modes="both"):
             tr = TrainStep(model, WrapperCriterion(prm), fx, prm, graph=(mode == "hipgraph"))
             ms, loss = timed(lambda: tr.step(audio, target), cfg["steps"], 3)
             res[mode] = (ms, float(loss.reshape(-1)[0]))
+            del tr, model
+        if not graphable and modes != "hipgraph":
+            # resnet-conformer: where the step goes, family by family (HIP events in two extra steps; FLOPs = the matrix
+            # products each launch stands for)
+            from adyolo_amd import ops as _ops
+            kt = KernelTimer(torch)
+            fl = lambda v: (float(v), 1.0)                                              # noqa: E731
+            kt.wrap(_ops, "conv_gemm", "implicit-GEMM convolutions (fwd / dgrad / wgrad)",
+                    lambda mode_, src, other, n_, h, w, cin, cout, kh, kw, sh, sw, ph, pw:
+                    fl(2.0 * n_ * _ops.conv_out_hw(h, w, kh, kw, sh, sw, ph, pw)[0] * _ops.conv_out_hw(h, w, kh, kw, sh, sw, ph, pw)[1]
+                       * cout * kh * kw * cin))
+            kt.wrap(_ops, "gemm", "plain GEMMs (linear layers, projections)", lambda a_, b_, m, n_, k_, *r, **kw: fl(2.0 * m * n_ * k_))
+            kt.wrap(_ops, "attn_fwd", "attention forward", lambda q, k, v, heads, *a, **kw: fl(4.0 * q.shape[0] * q.shape[1] ** 2 * q.shape[2]))
+            kt.wrap(_ops, "attn_bwd", "attention backward (7 products)",
+                    lambda q, *a, **kw: fl(14.0 * q.shape[0] * q.shape[1] ** 2 * q.shape[2]))
+            kt.wrap(_ops, "conv3x3", "Winograd 3x3 forward / dgrad [issued FLOPs]",
+                    lambda x, wpk, cout, **kw: fl(2.0 * x.shape[0] * x.shape[1] * x.shape[2] * cout * 9 * x.shape[3] * (16.0 / 36.0 if wpk.dim() == 4 else 1.0)))
+            kt.wrap(_ops, "conv3x3_wgrad", "Winograd 3x3 weight-gradient [issued FLOPs]",
+                    lambda x, dy, cin_real, **kw: fl(2.0 * x.shape[0] * x.shape[1] * x.shape[2] * dy.shape[3] * 9 * x.shape[3] * 16.0 / 36.0))
+            torch.manual_seed(100)
+            model = WrapperModel((1, 7, T, 64), (), prm).to(device)
+            tr = TrainStep(model, WrapperCriterion(prm), fx, prm, graph=False)
+            for _ in range(2):
+                tr.step(audio, target)
+            torch.cuda.synchronize()
+            kt.active = True
+            for _ in range(2):
+                tr.step(audio, target)
+            torch.cuda.synchronize()
+            kt.active = False
+            fam = {}
+            for name_ in kt.records:
+                n_l, ms_f, work, _ = kt.summary(name_)
+                fam[name_] = {"launches_per_step": n_l // 2, "ms_per_step": round(ms_f / 2, 3),
+                              "tflops": round(work / (ms_f * 1e-3) / 1e12, 1) if ms_f > 0 else 0.0,
+                              "frac_of_mfma_peak": round(work / (ms_f * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3) if ms_f > 0 else 0.0}
+            ent["stages"] = fam
             del tr, model
         mode = "hipgraph" if "hipgraph" in res else "eager"
         ms = res[mode][0]

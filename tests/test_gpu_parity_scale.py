@@ -860,6 +860,7 @@ model.encoder.lstm.dropout = 0.0
 tr = TrainStep(model, WrapperCriterion(prm), FeatureExtractor(None, "cuda:0"), prm, exact=True)
 audio, target = audio.to("cuda:0"), target.to("cuda:0")
 grads, losses = [], []
+params0 = tr.flat.flat.detach().cpu().clone()
 opt_step = tr.optimizer.step
 
 
@@ -868,11 +869,14 @@ def spy(grad_scale=1.0):
     assert grad_scale == 1.0                            # exact mode (and one device): gradients are sums, never averaged
     opt_step(grad_scale=grad_scale)
 tr.optimizer.step = spy
-for _ in range(3):
+bn_first = None
+for i in range(3):
     losses.append(float(tr.step(audio, target)))
+    if i == 0:
+        bn_first = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items() if "running_" in k}
 torch.cuda.synchronize()
 sd = tr.model.state_dict()
-torch.save({"grad0": grads[0].cpu(), "params": tr.flat.flat.cpu(), "losses": losses,
+torch.save({"grad0": grads[0].cpu(), "params": tr.flat.flat.cpu(), "params0": params0, "losses": losses, "bn_first": bn_first,
             "bn": {k: v.cpu() for k, v in sd.items() if "running_" in k},
             "layout": [(off, cnt) for off, cnt in tr.flat.offsets]}, os.environ["ADYOLO_DPX_OUT"])
 print(json.dumps({"ok": True, "rank": rank, "losses": losses}))
@@ -886,9 +890,10 @@ def test_exact_data_parallel_equals_one_device_on_the_concatenated_batch(ops, tm
     """``TrainStep(exact=True)`` (ops.ExactDP; SURVEY 8e "optional"): two ranks on two different 2-clip shards (two processes
     on this one GPU, gloo) against ONE process on the 4-clip concatenation, real SE-ResNet34 + AD-YOLO model, 3 Adam steps.
     BatchNorm statistics are formed over all ranks' samples by the same finishing kernel on the gathered per-sample sums
-    -> running statistics BIT-identical after step 1 and within 1e-6 after 3; the loss counts are all-reduced -> the loss
-    values agree to 1e-6; the gradients Adam sees in step 0 (summed over the ranks, not averaged) agree per parameter tensor
-    to 2e-5 of its absmax (only summation orders differ); both ranks hold the same parameters."""
+    -> running statistics BIT-identical after the first step (the whole forward pass is) and within 1e-3 after 3 Adam steps; the loss counts are all-reduced -> the first loss value agrees to
+    1e-6 (measured 7e-8), the later ones to 1e-4 (measured 3e-6); the gradients Adam sees in step 0 (summed over the ranks, not averaged) agree per parameter tensor
+    to 2e-5 of its absmax (only summation orders differ); both ranks hold the same parameters, and their 3-step update is
+    the one-device update (cosine >= 0.999)."""
     import json
     import socket
     import subprocess
@@ -916,8 +921,8 @@ def test_exact_data_parallel_equals_one_device_on_the_concatenated_batch(ops, tm
     assert r.returncode == 0, r.stderr[-3000:]
     r0, r1, one = (torch.load(f) for f in outs)
     assert torch.equal(r0["params"], r1["params"]) and torch.equal(r0["grad0"], r1["grad0"]), "ranks diverged"
-    for a, c in zip(r0["losses"], one["losses"]):
-        assert abs(a - c) <= 1e-6 * abs(c) + 1e-7, (r0["losses"], one["losses"])
+    for i, (a, c) in enumerate(zip(r0["losses"], one["losses"])):      # step 0: only summation orders differ; later steps
+        assert abs(a - c) <= (1e-6 if i == 0 else 1e-4) * abs(c), (r0["losses"], one["losses"])      # carry Adam's amplification
     worst = 0.0
     for off, cnt in one["layout"]:
         g, h = r0["grad0"][off:off + cnt].double(), one["grad0"][off:off + cnt].double()
@@ -925,8 +930,16 @@ def test_exact_data_parallel_equals_one_device_on_the_concatenated_batch(ops, tm
         if am > 0:
             worst = max(worst, float((g - h).abs().max()) / am)
     assert worst <= 2e-5, "step-0 gradients: worst tensor deviates by %.2e of its absmax" % worst
-    for k, v in one["bn"].items():
+    for k, v in one["bn_first"].items():                  # the whole first forward pass is bit-identical
+        assert torch.equal(r0["bn_first"][k], v) and torch.equal(r1["bn_first"][k], v), k
+    for k, v in one["bn"].items():                        # after 3 Adam steps: round-off amplified by Adam's normalisation
         d = float((r0["bn"][k] - v).abs().max())
-        assert d <= 1e-6 * max(1.0, float(v.abs().max())), (k, d)
+        assert d <= 1e-3 * max(1.0, float(v.abs().max())), (k, d)
+    # Adam divides every gradient element by its own magnitude, so an element whose gradient is round-off-sized moves by +-lr
+    # either way: compare the 3-step UPDATES as vectors (measured: mean deviation 7e-4 of the mean parameter magnitude)
+    assert torch.equal(r0["params0"], one["params0"])
+    ua, ub = (r0["params"] - r0["params0"]).double(), (one["params"] - one["params0"]).double()
+    cos = float(torch.dot(ua, ub) / (ua.norm() * ub.norm()))
+    assert cos >= 0.999, "3-step parameter updates: cosine %.6f" % cos
     rel = float((r0["params"] - one["params"]).abs().mean()) / float(one["params"].abs().mean())
-    assert rel <= 1e-5, "parameters after 3 steps: mean deviation %.2e of the mean magnitude" % rel
+    assert rel <= 3e-3, "parameters after 3 steps: mean deviation %.2e of the mean magnitude" % rel
