@@ -78,8 +78,6 @@ SIGNATURES = {
     "adyolo_seddoa_loss": (I, [P] * 5 + [L, I, I, I, F, F, P]),
     "adyolo_adpit_loss": (I, [P] * 5 + [L, I, P]),
     "adyolo_conv_gemm": (I, [P, P, P, P] + [I] * 13 + [P]),
-    "adyolo_im2col": (I, [P, P] + [I] * 10 + [P]),
-    "adyolo_col2im": (I, [P, P] + [I] * 10 + [P]),
     "adyolo_pack_wk": (I, [P, P, I, I, I, I, I, P]),
     "adyolo_maxpool3_fwd": (I, [P, P, P, I, I, I, I, P]),
     "adyolo_maxpool3_bwd": (I, [P, P, P, I, I, I, I, P]),

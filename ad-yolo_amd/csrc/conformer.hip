@@ -1,6 +1,6 @@
 // Kernels of the ResNet-Conformer encoder (BASELINE config 4; /root/reference/src/models/backbones/resnet_conformer.py):
-//   * general strided convolution as im2col + the fp32-MFMA GEMM (7x7 s(1,2) stem :347, torchvision BasicBlock 3x3
-//     s(1,2) / 1x1 s(1,2) convolutions :353-393) -- correctness-first path for the small-F ResNet front end
+//   * filter packing for the general strided convolution (adyolo_conv_gemm in gemm.hip: 7x7 s(1,2) stem :347, torchvision
+//     BasicBlock 3x3 s(1,2) / 1x1 s(1,2) convolutions :353-393; the im2col / col2im buffers of round 1 are gone)
 //   * MaxPool2d(3, s(1,2), p1) :350, BN->ReLU fusions of BasicBlock
 //   * LayerNorm :160,211,236,262, Swish :142-150, GLU :167, depthwise dilated Conv1d :169, row softmax of the
 //     attention scores :74, AvgPool1d :288-295, a*x + b*z residual mixing :98
@@ -14,58 +14,6 @@ static inline int ew_grid_c(long n) {
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
 }
 
-// ---------------------------------------------------------------------------------------------- im2col / col2im
-// col[(n,ho,wo)][(kh,kw,c)] = x[n][ho*SH-PH+kh][wo*SW-PW+kw][c]  (0 outside)
-__global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ x, float *__restrict__ col, int H, int W,
-                                                     int C, int Ho, int Wo, int KH, int KW, int SH, int SW, int PH,
-                                                     int PW, int Kp, long total) {
-    // one thread per (output pixel, kh, kw, c); Kp = row length (K rounded up to a multiple of 4, zero filled)
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int k = (int)(i % Kp);
-        const long p = i / Kp;
-        float v = 0.f;
-        if (k < KH * KW * C) {
-            const int c = k % C;
-            const int kw = (k / C) % KW;
-            const int kh = k / (C * KW);
-            const int wo = (int)(p % Wo);
-            const long q = p / Wo;
-            const int ho = (int)(q % Ho);
-            const long n = q / Ho;
-            const int h = ho * SH - PH + kh, w = wo * SW - PW + kw;
-            if (h >= 0 && h < H && w >= 0 && w < W) v = x[(((size_t)n * H + h) * W + w) * C + c];
-        }
-        col[i] = v;
-    }
-}
-// dx[n][h][w][c] = sum over (kh,kw) of dcol[(n,ho,wo)][(kh,kw,c)] with ho*SH-PH+kh == h, wo*SW-PW+kw == w
-__global__ __launch_bounds__(256) void col2im_kernel(const float *__restrict__ dcol, float *__restrict__ dx, int H,
-                                                     int W, int C, int Ho, int Wo, int KH, int KW, int SH, int SW,
-                                                     int PH, int PW, int Kp, long total) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        long p = i / C;
-        const int w = (int)(p % W);
-        p /= W;
-        const int h = (int)(p % H);
-        const long n = p / H;
-        float s = 0.f;
-        for (int kh = 0; kh < KH; ++kh) {
-            const int hh = h + PH - kh;
-            if (hh < 0 || hh % SH) continue;
-            const int ho = hh / SH;
-            if (ho >= Ho) continue;
-            for (int kw = 0; kw < KW; ++kw) {
-                const int ww = w + PW - kw;
-                if (ww < 0 || ww % SW) continue;
-                const int wo = ww / SW;
-                if (wo >= Wo) continue;
-                s += dcol[(((size_t)n * Ho + ho) * Wo + wo) * Kp + (kh * KW + kw) * C + c];
-            }
-        }
-        dx[i] = s;
-    }
-}
 // w [Cout][Cin][KH][KW] <-> wk [Cout][Kp] with k = (kh*KW+kw)*Cin + ci
 __global__ void pack_wk_kernel(const float *__restrict__ w, float *__restrict__ wk, int Cout, int Cin, int KH, int KW,
                                int Kp, int to_packed) {
@@ -298,27 +246,6 @@ __global__ __launch_bounds__(256) void avgpool1d_bwd_kernel(const float *__restr
 
 using namespace adyolo;
 
-extern "C" int adyolo_im2col(const float *x, float *col, int N, int H, int W, int C, int KH, int KW, int SH, int SW,
-                             int PH, int PW, void *stream) {
-    ADYOLO_REQUIRE(x && col && N > 0 && H > 0 && W > 0 && C > 0 && KH > 0 && KW > 0 && SH > 0 && SW > 0, ADYOLO_EINVAL,
-                   "im2col: bad arguments");
-    const int Ho = (H + 2 * PH - KH) / SH + 1, Wo = (W + 2 * PW - KW) / SW + 1;
-    const int Kp = (KH * KW * C + 3) / 4 * 4;
-    const long total = (long)N * Ho * Wo * Kp;
-    hipLaunchKernelGGL(im2col_kernel, dim3(ew_grid_c(total)), dim3(256), 0, as_stream(stream), x, col, H, W, C, Ho, Wo, KH,
-                       KW, SH, SW, PH, PW, Kp, total);
-    return check_launch("im2col");
-}
-extern "C" int adyolo_col2im(const float *dcol, float *dx, int N, int H, int W, int C, int KH, int KW, int SH, int SW,
-                             int PH, int PW, void *stream) {
-    ADYOLO_REQUIRE(dcol && dx && N > 0 && H > 0 && W > 0 && C > 0, ADYOLO_EINVAL, "col2im: bad arguments");
-    const int Ho = (H + 2 * PH - KH) / SH + 1, Wo = (W + 2 * PW - KW) / SW + 1;
-    const int Kp = (KH * KW * C + 3) / 4 * 4;
-    const long total = (long)N * H * W * C;
-    hipLaunchKernelGGL(col2im_kernel, dim3(ew_grid_c(total)), dim3(256), 0, as_stream(stream), dcol, dx, H, W, C, Ho, Wo,
-                       KH, KW, SH, SW, PH, PW, Kp, total);
-    return check_launch("col2im");
-}
 extern "C" int adyolo_pack_wk(float *w, float *wk, int Cout, int Cin, int KH, int KW, int to_packed, void *stream) {
     ADYOLO_REQUIRE(w && wk && Cout > 0 && Cin > 0 && KH > 0 && KW > 0, ADYOLO_EINVAL, "pack_wk: bad arguments");
     const int Kp = (KH * KW * Cin + 3) / 4 * 4;

@@ -15,7 +15,6 @@
 // would buy nothing), loaded one 8-channel group ahead.  Blocks are dealt to XCDs so that an XCD keeps one output-
 // channel slice of U in its L2.  Epilogue: the nu-sum of A^T . A is done in registers, the xi-sum through LDS, then
 // bias / masked addend / ReLU / per-patch BatchNorm sums as in conv.hip, stored as float4 along channels.
-#include <cstdlib>
 #include "common.hpp"
 
 namespace adyolo {
@@ -452,12 +451,6 @@ __global__ __launch_bounds__(256) void wino_pack_many_kernel(const long long *__
 
 using namespace adyolo;
 
-// wino_ws.hip: the wave-specialised persistent kernel for the stage-1 shape (Cin = Cout = 32)
-int adyolo_wino_fwd_ws_full(const float *x, const float *u, const float *bias, const float *addend, const float *addend_mask,
-                            const float *in_scale, const float *in_shift, float *y, float *stats, const float *stat_aux,
-                            const float *stat_mean, const float *stat_invstd, const float *stat_mask, int N, int H, int W,
-                            int relu, int mask_bits, void *stream);
-
 extern "C" int adyolo_wino_tiles(int N, int H, int W) {
     if (N <= 0 || H <= 0 || W <= 0) return ADYOLO_EINVAL;
     return N * cdiv(H, 8) * cdiv(W, 16);
@@ -506,15 +499,6 @@ extern "C" int adyolo_wino_fwd(const float *x, const float *u, const float *bias
     ADYOLO_REQUIRE(!stat_mask || stats, ADYOLO_EINVAL, "wino_fwd: stat_mask needs stats");
     const int tilesW = cdiv(W, 16), tilesH = cdiv(H, 8);
     const int nsp = N * tilesH * tilesW;
-    if (Cin == WKC && Cout == 32 && nsp >= 1024) {       // the stage-1 shape: one 16-step chunk per patch
-        // opt-in (ADYOLO_WINO_WS=1): the wave-specialised persistent kernel of wino_ws.hip.  Its plain form beats this
-        // kernel by 14 % in isolation (0.90 vs 1.05 ms), but with the statistics / fused-gradient epilogues its four producer
-        // waves become the bottleneck (1.21 vs 1.08 ms forward, 2.0 vs 1.6 ms data-gradient inside the training step)
-        static const bool ws_on = getenv("ADYOLO_WINO_WS") && getenv("ADYOLO_WINO_WS")[0] == '1';
-        if (ws_on)
-            return adyolo_wino_fwd_ws_full(x, u, bias, addend, addend_mask, in_scale, in_shift, y, stats, stat_aux, stat_mean,
-                                           stat_invstd, stat_mask, N, H, W, relu, mask_bits, stream);
-    }
     const int nt = Cout % 64 == 0 ? 2 : 1;
     const int ncb = Cout / (32 * nt);
     int xcd_div = 0, blocks = nsp * ncb;

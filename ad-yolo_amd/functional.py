@@ -117,6 +117,13 @@ class GradSink:
         self.done(*[t.data_ptr() for t in tensors if t is not None])
 
 
+def saved(grad_fn):
+    """{name: tensor} of what a StemFn / SEBlockFn node saved for backward -- the supported way for tests to reach e.g. the
+    ReLU output ``a`` (= relu(conv1)), the block output ``e`` or the ReLU-mask bits ``ebits`` of a block (the positional
+    layout of ``saved_tensors`` changes whenever a fusion adds or drops an operand)."""
+    return dict(zip(grad_fn.saved_names, grad_fn.saved_tensors))
+
+
 SINK = GradSink()
 _COUNTER_SCOPE = []           # innermost active bn_counter_scope's list (empty: counters are bumped immediately)
 
@@ -209,6 +216,7 @@ class StemFn(torch.autograd.Function):
         ctx.cin_real = w.shape[1]
         ctx.ptrs = (w.data_ptr(), gamma.data_ptr(), beta.data_ptr())
         ctx.wshape = tuple(w.shape)
+        ctx.saved_names = ["x8", "a", "gamma", "mean", "invstd"]
         ctx.save_for_backward(x8, a, gamma, mean, invstd)
         return out
 
@@ -318,10 +326,15 @@ class SEBlockFn(torch.autograd.Function):
         ctx.wshapes = (tuple(w1.shape), tuple(w2.shape))
         tensors = [p, src, scale1, cc, e, g1, mean1, invstd1, g2, b2, mean2, invstd2, ssum2, pooled, hid, s, fw1, fw2,
                    wpk1d, wpk2d, shift1]
+        names = ["p", "a", "scale1", "cc", "e", "g1", "mean1", "invstd1", "g2", "b2", "mean2", "invstd2", "ssum2", "pooled",
+                 "hid", "s", "fw1", "fw2", "wpk1d", "wpk2d", "shift1"]
         if ebits is not None:
             tensors.append(ebits)
+            names.append("ebits")
         if wd is not None:
             tensors += [q, wd, gd, meand, invstdd]
+            names += ["q", "wd", "gd", "meand", "invstdd"]
+        ctx.saved_names = names                 # (saved(grad_fn) below: tests address saved tensors by NAME, not by position)
         ctx.save_for_backward(*tensors)
         return e
 

@@ -669,21 +669,6 @@ def conv_out_hw(h, w, kh, kw, sh, sw, ph, pw):
     return (h + 2 * ph - kh) // sh + 1, (w + 2 * pw - kw) // sw + 1
 
 
-def im2col(x, kh, kw, sh, sw, ph, pw):
-    _chk(x)
-    n, h, w, c = x.shape
-    ho, wo = conv_out_hw(h, w, kh, kw, sh, sw, ph, pw)
-    col = _new(x, n * ho * wo, _kp(kh, kw, c))
-    _c("adyolo_im2col", _p(x), _p(col), n, h, w, c, kh, kw, sh, sw, ph, pw, _stream())
-    return col, ho, wo
-
-
-def col2im(dcol, n, h, w, c, kh, kw, sh, sw, ph, pw):
-    dx = _new(dcol, n, h, w, c)
-    _c("adyolo_col2im", _p(dcol), _p(dx), n, h, w, c, kh, kw, sh, sw, ph, pw, _stream())
-    return dx
-
-
 def conv_gemm(mode, src, other, n, h, w, cin, cout, kh, kw, sh, sw, ph, pw):
     """General strided convolution as an implicit GEMM (no column buffer), channels-last.
     mode 0: src x [N][H][W][Cin], other wk = pack_wk(w) -> y [N][Ho][Wo][Cout]

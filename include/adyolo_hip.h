@@ -353,9 +353,8 @@ int adyolo_conv_gemm(const float *src, const float *other, float *out, float *sl
 
 /* ------------------------------------------------------------------------------------------------
  * K9  ResNet-Conformer encoder pieces (src/models/backbones/resnet_conformer.py), channels-last fp32
- *   im2col / col2im / pack_wk : general strided convolution = im2col + adyolo_gemm; rows of `col` / `wk` are
- *       (kh, kw, c)-ordered and padded to a multiple of 4 floats (Kp).  Used for the 7x7 s(1,2) stem (:347) and the
- *       torchvision BasicBlock 3x3 / 1x1 s(1,2) convolutions (:353-393).
+ *   pack_wk : filter layout of adyolo_conv_gemm; rows of `wk` are (kh, kw, c)-ordered and padded to a multiple of 4 floats
+ *       (Kp).  Used for the 7x7 s(1,2) stem (:347) and the torchvision BasicBlock 3x3 / 1x1 s(1,2) convolutions (:353-393).
  *   maxpool3 : MaxPool2d(3, stride (1,2), padding 1) (:350); arg = arg-max tap per output (uint8); bwd atomically
  *       adds into a ZEROED dx.
  *   affine_relu, relu_bwd, axpby : BN->ReLU of BasicBlock, residual mixing a*x + b*z (:98)
@@ -363,10 +362,6 @@ int adyolo_conv_gemm(const float *src, const float *other, float *out, float *sl
  *       (flip = 1 gives the data gradient), softmax rows with a pre-scale (:73-76), avgpool1d(k) * fac (:288-294),
  *   ln : LayerNorm(256).
  * ---------------------------------------------------------------------------------------------- */
-int adyolo_im2col(const float *x, float *col, int N, int H, int W, int C, int KH, int KW, int SH, int SW, int PH,
-                  int PW, void *stream);
-int adyolo_col2im(const float *dcol, float *dx, int N, int H, int W, int C, int KH, int KW, int SH, int SW, int PH,
-                  int PW, void *stream);
 int adyolo_pack_wk(float *w, float *wk, int Cout, int Cin, int KH, int KW, int to_packed, void *stream);
 int adyolo_maxpool3_fwd(const float *x, float *y, unsigned char *arg, int N, int H, int W, int C, void *stream);
 int adyolo_maxpool3_bwd(const float *dy, const unsigned char *arg, float *dx_zeroed, int N, int H, int W, int C,

@@ -85,45 +85,6 @@ def test_conv3x3_forward(ops, n, h, w, cin, cout, relu, bias, addend, algo):
     assert_close(nchw(y), ref, 2e-5, "conv3x3 fwd (%s)" % algo)
 
 
-def test_wave_specialised_stage1_kernel_matches_the_default(ops):
-    """The opt-in wave-specialised persistent kernel (ADYOLO_WINO_WS=1, csrc/wino_ws.hip; Cin = Cout = 32, >= 1024 patches) in a
-    child process against the default kernel: bit-equal output and per-patch statistics for the forward form (input affine,
-    bias-free, ReLU, statistics) and the fused data-gradient form (masked addend as bits, BatchNorm-backward statistics with
-    a bit mask), ragged image edges included."""
-    import subprocess
-    import sys
-    code = r"""
-import os, sys, torch
-sys.path.insert(0, %r)
-import adyolo_amd
-from adyolo_amd import ops
-g = torch.Generator(device="cuda:0").manual_seed(11)
-n, h, w, c = 5, 430, 60, 32
-x = torch.randn(n, h, w, c, generator=g, device="cuda:0")
-wt = torch.randn(c, c, 3, 3, generator=g, device="cuda:0") * 0.1
-wpk, wpkd = ops.pack_w3x3(wt, c, algo="winograd")
-aff = (torch.rand(c, generator=g, device="cuda:0") + 0.5, torch.randn(c, generator=g, device="cuda:0"))
-y, st = ops.conv3x3(x, wpk, c, relu=True, in_affine=aff, want_stats=True)
-add = torch.randn(n, h, w, c, generator=g, device="cuda:0")
-e = torch.randn(n, h, w, c, generator=g, device="cuda:0")
-aux = torch.randn(n, h, w, c, generator=g, device="cuda:0")
-mean, inv = torch.randn(c, generator=g, device="cuda:0"), torch.rand(c, generator=g, device="cuda:0") + 0.5
-dx, st2 = ops.conv3x3(x, wpkd, c, addend=add, addend_mask=e, want_stats=True, stat_bn=(aux, mean, inv), stat_mask=e)
-torch.cuda.synchronize()
-torch.save([y.cpu(), st.cpu(), dx.cpu(), st2.cpu()], sys.argv[1])
-""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    import tempfile
-    outs = []
-    with tempfile.TemporaryDirectory() as td:
-        for flag in ("0", "1"):
-            path = os.path.join(td, "o%s.pt" % flag)
-            env = dict(os.environ, ADYOLO_WINO_WS=flag)
-            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=300)
-            outs.append(torch.load(path))
-    for a, b, name in zip(outs[0], outs[1], ("forward", "forward statistics", "data gradient", "gradient statistics")):
-        assert torch.equal(a, b), name
-
-
 @pytest.mark.parametrize("n,h,w,cin,cout", [
     (2, 16, 64, 32, 32), (2, 13, 32, 32, 64), (1, 18, 16, 64, 128), (1, 9, 16, 256, 256), (2, 20, 64, 7, 32),
     (3, 40, 64, 32, 32), (2, 150, 24, 32, 64), (1, 67, 37, 64, 32),

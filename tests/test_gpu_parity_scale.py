@@ -112,15 +112,17 @@ def test_seed100_training_step_matches_reference(ops, monkeypatch, algo):
     target = torch.from_numpy(g["target"])
     captured, bits, hooks = {}, {}, []
 
+    from adyolo_amd import functional as Fn
+
     def grab(site_a, site_e, is_first):
         def hook(mod, inp, out):
-            saved = out.grad_fn.saved_tensors                  # SEBlockFn: [p, src (= relu(conv1)), scale1, cc, e, ...]
-            assert saved[4].data_ptr() == out.data_ptr()
-            captured[site_a], captured[site_e] = saved[1], out
-            if out.grad_fn.has_bits:
-                bits[site_e] = saved[21]                       # (e > 0) as bits, read by the SE-tail backward
+            sv = Fn.saved(out.grad_fn)                         # SEBlockFn's saved tensors by name
+            assert sv["e"].data_ptr() == out.data_ptr()
+            captured[site_a], captured[site_e] = sv["a"], out  # a = relu(conv1(x)), e = the block output
+            if "ebits" in sv:
+                bits[site_e] = sv["ebits"]                     # (e > 0) as bits, read by the SE-tail backward
             if is_first:
-                captured["stem"] = inp[0].grad_fn.saved_tensors[1]     # StemFn: [x8, a (= relu(conv + bias)), ...]
+                captured["stem"] = Fn.saved(inp[0].grad_fn)["a"]      # StemFn: a = relu(conv + bias)
         return hook
     for li in range(1, 5):
         for bi, blk in enumerate(getattr(model.encoder, "layer%d" % li)):

@@ -1,3 +1,8 @@
+// EXPERIMENT (round 2, moved out of the build in round 3): the wave-specialised persistent form of the stage-1 Winograd forward.
+// Plain convolution 1.05 -> 0.90 ms, but with the training epilogues it LOSES (forward + statistics 1.08 -> 1.21 ms, fused
+// data-gradient 1.6 -> 2.0 ms inside the step): see DESIGN.md, "Tried and rejected".  It was an opt-in of libadyolo_hip.so
+// (ADYOLO_WINO_WS=1) with its own test in round 2; to rebuild it, add it back to build.py's SOURCES and restore the dispatch
+// in adyolo_wino_fwd (git history: 033625c).
 // K2w, stage-1 shape (Cin = 32 -> Cout = 32), wave-specialised persistent form of wino_fwd_kernel<1, true> (wino.hip).
 // What-if builds put 22 % of that launch on the exposed first-patch load and 12 % on the epilogue
 // (profiles/r02_whatif_wino_fwd_prologue.txt): one 32-channel chunk is only 16 steps of matrix work per patch, too short
