@@ -237,6 +237,9 @@ EXTRA_CONFIGS = {
                           ref="BASELINE.json configs[0]: bs = 8 x 20 s (the CPU-runnable plumbing case; cpu_baseline's shape)"),
     "eval_bs1x60s": dict(kind="eval", encoder="se-resnet34", batch=1, seconds=60, steps=20,
                          ref="test_epoch: one 60 s clip at a time (src/train.py:130-133, src/test.py:81): K1 + forward + decode"),
+    "eval_bs8x60s": dict(kind="eval", encoder="se-resnet34", batch=8, seconds=60, steps=10,
+                         ref="the same evaluation with eight equal-length clips per forward pass (test.test_epoch_audio(batch_size=8): "
+                             "evaluation-mode outputs do not depend on the batch, same CSV files)"),
     "conformer_bs32x20s": dict(kind="train", encoder="resnet-conformer", batch=32, seconds=20, steps=4,
                                ref="BASELINE.json configs[3]: resnet-conformer + adyolo, bs = 32 x 20 s"),
 }
@@ -352,9 +355,11 @@ def run_extra_config(name, torch, modes="both"):
         ms, outs = timed(graphed, cfg["steps"], 3)
 
         def eager():
+            from adyolo_amd import ops as _ops
             with torch.no_grad():
                 o = model(fx(audio, channels_last8=True), channels_last8=True)
-                return o, post.decode(o)
+                d = _ops.yolo_decode(o.contiguous(), post.nb_classes, post.nb_grids, post.nb_anchors, post.grid_size, post.g_overlap)
+                return o, d.cpu()
         ms_e, outs_e = timed(eager, max(3, cfg["steps"] // 2), 2)
         ent.update({"mode": "hipgraph", "ms_per_step": round(ms, 3), "clips_per_s": round(B / (ms * 1e-3), 1),
                     "audio_s_per_s": round(B * cfg["seconds"] / (ms * 1e-3), 1), "eager_ms_per_step": round(ms_e, 3),

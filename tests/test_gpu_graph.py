@@ -154,3 +154,42 @@ def test_graphed_evaluation_forward_matches_eager(ops):
     assert fg.captures == 2 and fg.replays == 6
     sd = model.state_dict()
     assert int(sd["encoder.bn1.num_batches_tracked"]) == 0                    # eval mode: nothing was updated
+
+
+def test_batched_and_graphed_evaluation_writes_the_same_files(ops, tmp_path):
+    """``test_epoch_audio(batch_size=4, forward=ForwardGraphs(...))`` against the reference's one-clip-per-pass loop
+    (batch_size=1, eager): five clips, four of one length and one longer (its own batch and its own graph) -- identical CSV
+    files (text) and the same mean loss.  Evaluation-mode outputs do not depend on the batch a clip travels in."""
+    import os
+    from scipy.io import wavfile
+    from adyolo_amd import test as atest
+    from adyolo_amd.datasets import FoaDataset
+    from adyolo_amd.features import FeatureExtractor
+    from adyolo_amd.graph import ForwardGraphs
+    from adyolo_amd.postprocess import LabelPostProcessor
+    from adyolo_amd.wrapper import WrapperCriterion, WrapperModel
+    rs = np.random.RandomState(5)
+    wdir, cdir = os.path.join(tmp_path, "foa_dev", "dev-test"), os.path.join(tmp_path, "metadata_dev", "dev-test")
+    os.makedirs(wdir), os.makedirs(cdir)
+    for i, n in enumerate([48000, 48000 + 77, 48000, 72000, 48000 + 401]):
+        wavfile.write(os.path.join(wdir, "t%d.wav" % i), 24000, rs.randint(-8000, 8000, size=(n, 4)).astype(np.int16))
+        with open(os.path.join(cdir, "t%d.csv" % i), "w") as f:
+            for fr in range(i, 20, 3):
+                f.write("%d,%d,0,%d,%d\n" % (fr, (fr + i) % 12, (fr * 53) % 360 - 180, (fr * 9) % 100 - 50))
+    prm = _params()
+    prm["data_config"]["data_pth"] = str(tmp_path)
+    prm["train_config"].update({"conf_thresh": 0.3, "clss_thresh": 0.3})
+    torch.manual_seed(8)
+    model = WrapperModel((1, 7, 80, 64), (), prm).to("cuda:0")
+    crit, post, fx = WrapperCriterion(prm), LabelPostProcessor(prm), FeatureExtractor(None, "cuda:0")
+    ds = FoaDataset(prm, "test", is_valid=True)
+    out_a, out_b = os.path.join(tmp_path, "out_one"), os.path.join(tmp_path, "out_batched")
+    loss_a = atest.test_epoch_audio(ds, model, fx, crit, post, "cuda:0", out_a)
+    fg = ForwardGraphs(model.eval(), fx, None, warm_calls=0)
+    loss_b = atest.test_epoch_audio(ds, model, fx, crit, post, "cuda:0", out_b, batch_size=4, forward=fg)
+    assert fg.captures >= 2 and abs(loss_a - loss_b) <= 1e-6 * abs(loss_a)
+    names = ds.get_filelist()
+    assert len(names) == 5
+    for nm in names:
+        a, b = open(os.path.join(out_a, nm + ".csv")).read(), open(os.path.join(out_b, nm + ".csv")).read()
+        assert a == b and len(a) > 0, nm

@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 out = {}
-for cfg in ("train_bs16x20s", "train_bs8x20s", "eval_bs1x60s", "conformer_bs32x20s"):
+for cfg in ("train_bs16x20s", "train_bs8x20s", "eval_bs1x60s", "eval_bs8x60s", "conformer_bs32x20s"):
     stats = os.path.join(ROOT, "gpurun_out", "%s_%s_kernel_stats.csv" % (tag, cfg))
     log = os.path.join(ROOT, "gpurun_out", "%s_%s_under_rocprof.log" % (tag, cfg))
     if not (os.path.exists(stats) and os.path.exists(log)):
