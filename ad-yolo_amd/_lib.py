@@ -21,6 +21,7 @@ SIGNATURES = {
     "adyolo_last_error": (ctypes.c_char_p, []),
     "adyolo_feat_stft_mel": (I, [P] * 8 + [I, I] + [P] * 4 + [I, I, I, P]),
     "adyolo_feat_finish": (I, [P] * 4 + [I, I, I, P]),
+    "adyolo_feat_gcc_phat": (I, [P] * 6 + [I, I, I, I, P]),
     "adyolo_nchw_to_nhwc8": (I, [P, P, I, I, I, I, P]),
     "adyolo_pack_w3x3": (I, [P, P, P, I, I, I, P]),
     "adyolo_conv3x3_tiles": (I, [I] * 3),

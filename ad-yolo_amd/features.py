@@ -135,6 +135,47 @@ class FeatureExtractor:
         return b * (n_samples * 4 * 4 + 7 * (n_samples // HOP) * N_MELS * 4)
 
 
+class MicFeatureExtractor:
+    """MIC-format feature set of BASELINE config 5 ("DCASE2022 MIC (GCC-PHAT features)"): log-mel of the four microphones
+    (K1 on the MIC audio) + six GCC-PHAT channels (``adyolo_feat_gcc_phat``, csrc/features_mic.hip) -> 10 features.
+    NOT in the reference, which hard-codes FOA (src/datasets.py:36-37,55; src/main.py:40): parity unpinned; the definition
+    is the DCASE2022 SELD baseline's (see include/adyolo_hip.h).
+
+    scaler: {'MEL': {'mean','std'} (1,64,4), 'GCC': {'mean','std'} (1,64,6)} or None.
+    ``__call__(audio (B, n, 4))`` -> (B, T, 64, 32) channels-last float32 (features 0-9, zeros above: the 32-channel pixel the
+    Winograd stem convolution consumes) or, with ``channels_last=False``, (B, 10, T, 64)."""
+
+    N_FEATURES = 10
+
+    def __init__(self, scaler=None, device="cuda:0"):
+        mel_scaler = None
+        mean, std = np.zeros((6, N_MELS)), np.ones((6, N_MELS))
+        if scaler is not None:
+            mel_scaler = {"MEL": scaler["MEL"], "IV": {"mean": np.zeros((1, N_MELS, 3)), "std": np.ones((1, N_MELS, 3))}}
+            mean = np.asarray(scaler["GCC"]["mean"], dtype=np.float64).reshape(N_MELS, 6).T
+            std = np.asarray(scaler["GCC"]["std"], dtype=np.float64).reshape(N_MELS, 6).T
+        self.k1 = FeatureExtractor(mel_scaler, device)
+        dev = self.k1.device
+        self.gcc_mean = torch.tensor(np.asarray(mean, dtype=np.float32), device=dev).contiguous()
+        self.gcc_rstd = torch.tensor(np.asarray(1.0 / std, dtype=np.float32), device=dev).contiguous()
+
+    def __call__(self, audio, channels_last=True):
+        if not audio.is_cuda or audio.dtype != torch.float32 or not audio.is_contiguous():
+            raise _lib.AdyoloHipError("MicFeatureExtractor needs contiguous float32 audio (B, n_samples, 4) on the GPU")
+        b, n, ch = audio.shape
+        if ch != 4 or n % HOP != 0:
+            raise _lib.AdyoloHipError("audio must be (B, n_samples, 4) with n_samples %% 600 == 0")
+        t = n // HOP
+        out = torch.zeros((b, t, N_MELS, 32), dtype=torch.float32, device=audio.device)
+        mel8 = self.k1(audio, channels_last8=True)                    # (B, T, 64, 8): channels 0-3 = log-mel of the four microphones
+        out[..., :4] = mel8[..., :4]                                  # (plumbing copy; the intensity-vector channels are not used)
+        _lib.call("adyolo_feat_gcc_phat", _p(audio), _p(None), _p(self.k1.twiddle), _p(self.gcc_mean), _p(self.gcc_rstd),
+                  _p(out), b, n, 32, 4, _stream())
+        if channels_last:
+            return out
+        return out[..., :10].permute(0, 3, 1, 2).contiguous()
+
+
 def load_scaler_npz(path):
     """Scaler statistics stored as .npz (mel_mean/mel_std (1,64,4), iv_mean/iv_std (1,64,3))."""
     z = np.load(path)

@@ -192,7 +192,7 @@ class StemFn(torch.autograd.Function):
         """holder (a BlockLink-like object) given: the BatchNorm affine is NOT applied here -- the output is relu(conv(x)) and
         holder.affine = (scale, shift) for the consumer (SEBlockFn's ``p_affine``); the incoming gradient is then the
         gradient w.r.t. the affine's output, exactly what the consumer returns for its input."""
-        wpk, _ = ops.pack_w3x3(w, 8, want_dgrad=False)
+        wpk, _ = ops.pack_w3x3(w, x8.shape[-1], want_dgrad=False)      # 8-channel pixels (FOA: 7 features) or 32 (MIC: 10)
         if training and FUSE_STATS:
             a, st = ops.conv3x3(x8, wpk, w.shape[0], bias=b, relu=True, want_stats=True)
             _, mean, invstd, scale, shift = _BNState(bn).stats_tiles(st, a, affine=(gamma, beta))

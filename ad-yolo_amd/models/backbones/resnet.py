@@ -181,7 +181,15 @@ class SEResnet34(nn.Module):
             return self._forward(x, channels_last8)
 
     def _forward(self, x, channels_last8):
-        x8 = x if channels_last8 else ops.nchw_to_nhwc8(x.contiguous().float())
+        if channels_last8:
+            x8 = x                               # (B, T, F, 8) for up to 8 features, (B, T, F, 32) for more (MIC: 10)
+        elif x.shape[1] <= 8:
+            x8 = ops.nchw_to_nhwc8(x.contiguous().float())
+        else:                                    # (plumbing copy) channels-last pixels padded to 32: the Winograd stem's input
+            x8 = torch.nn.functional.pad(x.float().permute(0, 2, 3, 1), (0, 32 - x.shape[1])).contiguous()
+        if x8.shape[-1] < self.in_channels or x8.shape[-1] not in (8, 32):
+            raise RuntimeError("SEResnet34: %d input features need %d-channel pixels (got %d)"
+                               % (self.in_channels, 8 if self.in_channels <= 8 else 32, x8.shape[-1]))
         first = self.layer1[0]
         holder = Fn.BlockLink() if (Fn.FUSE_STEM_AFFINE and not first.pool and first.downsample is None) else None
         y = Fn.StemFn.apply(x8, self.conv1.weight, self.conv1.bias, self.bn1.weight, self.bn1.bias, self.bn1,

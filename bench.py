@@ -240,6 +240,10 @@ EXTRA_CONFIGS = {
     "eval_bs8x60s": dict(kind="eval", encoder="se-resnet34", batch=8, seconds=60, steps=10,
                          ref="the same evaluation with eight equal-length clips per forward pass (test.test_epoch_audio(batch_size=8): "
                              "evaluation-mode outputs do not depend on the batch, same CSV files)"),
+    "config5_mic_adpit_bs64x20s": dict(kind="train", encoder="se-resnet34", batch=64, seconds=20, steps=4, loss="adpit", mic=True,
+                                       ref="BASELINE.json configs[4]: se-resnet34 + multi-ACCDOA (ADPIT) loss, MIC-format audio -> "
+                                           "4 log-mel + 6 GCC-PHAT features (10-channel stem), bs = 64 x 20 s; GCC-PHAT is not in the "
+                                           "reference (parity unpinned)"),
     "conformer_bs32x20s": dict(kind="train", encoder="resnet-conformer", batch=32, seconds=20, steps=4,
                                ref="BASELINE.json configs[3]: resnet-conformer + adyolo, bs = 32 x 20 s"),
 }
@@ -269,10 +273,27 @@ def run_extra_config(name, torch, modes="both"):
     T = n // 600
     prm = params(device)
     prm["args"]["encoder"] = cfg["encoder"]
+    prm["args"]["loss"] = cfg.get("loss", "adyolo")
     prm["train_config"].update(conf_thresh=0.5, clss_thresh=0.5, unify_thresh=15.0, nms="conn-merge")
+    n_feat = 7
     fx = FeatureExtractor(None, device)
     audio = synthetic_audio(B, n, seed=4321).to(device)
     target = synthetic_targets(B, T // 4, 12, seed=4321).to(device)
+    if cfg.get("mic"):                      # MIC feature set: 4 log-mel + 6 GCC-PHAT channels in 32-channel pixels
+        from adyolo_amd.features import MicFeatureExtractor
+        mfx = MicFeatureExtractor(None, device)
+        fx = lambda a, channels_last8=True: mfx(a, channels_last=channels_last8)        # noqa: E731
+        n_feat = 10
+    if cfg.get("loss") == "adpit":          # dense (B, T', 6, 4, C) activity / direction targets
+        import numpy as _np
+        rng = _np.random.default_rng(4321)
+        tgt = _np.zeros((B, T // 4, 6, 4, 12), dtype=_np.float32)
+        act = rng.random((B, T // 4, 12)) < 0.05
+        xyz = rng.normal(size=(B, T // 4, 3, 12)).astype(_np.float32)
+        xyz /= _np.linalg.norm(xyz, axis=2, keepdims=True)
+        tgt[:, :, 0, 0, :] = act
+        tgt[:, :, 0, 1:, :] = xyz * act[:, :, None, :]
+        target = torch.from_numpy(tgt).to(device)
     graphable = cfg["encoder"] == "se-resnet34"
     ent = {"workload": cfg["ref"], "batch": B, "clip_seconds": cfg["seconds"], "steps": cfg["steps"]}
 
@@ -292,7 +313,7 @@ def run_extra_config(name, torch, modes="both"):
         want = ("hipgraph", "eager") if modes == "both" else (modes,)
         for mode in ([m for m in want if graphable or m == "eager"] or ["eager"]):
             torch.manual_seed(100)
-            model = WrapperModel((1, 7, T, 64), (), prm).to(device)
+            model = WrapperModel((1, n_feat, T, 64), (), prm).to(device)
             tr = TrainStep(model, WrapperCriterion(prm), fx, prm, graph=(mode == "hipgraph"))
             ms, loss = timed(lambda: tr.step(audio, target), cfg["steps"], 3)
             res[mode] = (ms, float(loss.reshape(-1)[0]))

@@ -58,6 +58,18 @@ int adyolo_feat_stft_mel(const float *audio, const int64_t *clip_offset, const f
                          int n_samples, int layout, void *stream);
 int adyolo_feat_finish(float *out, const float *chan_max, const float *scaler_mean,
                        const float *scaler_rstd, int B, int T, int layout, void *stream);
+
+/* K1m  GCC-PHAT features of 4-channel MIC-format audio (BASELINE config 5: "DCASE2022 MIC (GCC-PHAT features)").  NOT in
+ *     the reference (FOA is hard-coded: src/datasets.py:36-37,55; the --feature switch is commented out, src/main.py:40):
+ *     PARITY UNPINNED.  Definition: the DCASE2022 SELD baseline's (the repository README.md:156 credits for the metrics):
+ *     per microphone pair m < n, R = conj(X_m) X_n, cc = irfft(exp(i angle(R))), feature = concat(cc[-32:], cc[:32]);
+ *     X = the STFT of K1.  The four log-mel channels of the MIC feature set are adyolo_feat_stft_mel on the same audio.
+ *   audio [B][n_samples][4] float32; out: channels-last pixels of pix_stride floats, [B][T][64 lag bins][pix_stride];
+ *   the six pair channels (0,1) (0,2) (0,3) (1,2) (1,3) (2,3) are written at ch0 .. ch0+5 as (cc - mean) * rstd with
+ *   scaler_mean / scaler_rstd [6][64]. */
+int adyolo_feat_gcc_phat(const float *audio, const int64_t *clip_offset /*or NULL*/, const float *twiddle,
+                         const float *scaler_mean, const float *scaler_rstd, float *out, int B, int n_samples,
+                         int pix_stride, int ch0, void *stream);
 /* [B][C][H][W] (C<=8) -> [B][H][W][8] zero padded; entry of WrapperModel.forward (wrapper.py:52-57) */
 int adyolo_nchw_to_nhwc8(const float *x, float *y, int B, int C, int H, int W, void *stream);
 

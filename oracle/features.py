@@ -170,6 +170,42 @@ def get_feature(audio, scaler=None, mel_wts=None):
     return feat.astype(np.float32), nb_label_frames
 
 
+def gcc_phat(spec, n_lags=N_MELS):
+    """MIC-format GCC-PHAT features, (T, 601, 4) -> (T, n_lags, 6).  NOT part of the reference (FOA is hard-coded there,
+    src/datasets.py:36-37,55): PARITY UNPINNED.  Definition of the DCASE2022 SELD baseline the reference's README credits
+    (README.md:156; cls_feature_class.py::_get_gcc): per microphone pair m < n, R = conj(X_m) X_n,
+    cc = irfft(exp(i angle(R))) over n_fft samples, feature = concat(cc[-n_lags/2:], cc[:n_lags/2])."""
+    t, _, c = spec.shape
+    out = np.zeros((t, n_lags, c * (c - 1) // 2))
+    p = 0
+    for m in range(c):
+        for n in range(m + 1, c):
+            r = np.conj(spec[:, :, m]) * spec[:, :, n]
+            cc = np.fft.irfft(np.exp(1j * np.angle(r)), n=N_FFT, axis=1)
+            out[:, :, p] = np.concatenate([cc[:, -n_lags // 2:], cc[:, :n_lags // 2]], axis=-1)
+            p += 1
+    return out
+
+
+def unit_scaler_mic():
+    return {"MEL": {"mean": np.zeros((1, N_MELS, 4)), "std": np.ones((1, N_MELS, 4))},
+            "GCC": {"mean": np.zeros((1, N_MELS, 6)), "std": np.ones((1, N_MELS, 6))}}
+
+
+def get_feature_mic(audio, scaler=None, mel_wts=None):
+    """MIC feature set of BASELINE config 5: log-mel of the four microphones (datasets.py:260-267 applied to MIC audio) +
+    the six GCC-PHAT channels, z-scored -> float32 (10, T, 64).  Parity unpinned (see ``gcc_phat``)."""
+    if mel_wts is None:
+        mel_wts = mel_filterbank()
+    if scaler is None:
+        scaler = unit_scaler_mic()
+    spec = stft(audio)
+    mel = (logmel(spec, mel_wts) - scaler["MEL"]["mean"]) / scaler["MEL"]["std"]
+    gcc = (gcc_phat(spec) - scaler["GCC"]["mean"]) / scaler["GCC"]["std"]
+    feat = np.concatenate([mel.transpose(2, 0, 1), gcc.transpose(2, 0, 1)], axis=0)
+    return feat.astype(np.float32), int(audio.shape[0] / float(int(SR * 0.1)))
+
+
 def int16_to_audio(pcm):
     """datasets.py:147."""
     return np.asarray(pcm, dtype=np.float64) / 32768.0 + 1e-8

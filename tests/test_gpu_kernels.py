@@ -1104,3 +1104,91 @@ def test_raw_audio_evaluation_writes_the_same_files_as_the_feature_path(ops, tmp
         for la, lb in zip(a, b):
             fa, fb = la.split(","), lb.split(",")
             assert fa[:3] == fb[:3] and np.allclose([float(v) for v in fa[3:]], [float(v) for v in fb[3:]], atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ MIC features (config 5)
+def _mic_audio(b, n, seed):
+    """Four microphones = one noise source seen with small integer delays + independent sensor noise (so the GCC-PHAT has
+    real peaks and no numerically empty bins)."""
+    rng = np.random.default_rng(seed)
+    out = np.zeros((b, n, 4), dtype=np.float64)
+    for i in range(b):
+        base = rng.normal(0.0, 0.1, size=n + 64)
+        delays = rng.integers(-10, 11, size=4)
+        for c in range(4):
+            out[i, :, c] = base[32 - delays[c]:32 - delays[c] + n] + rng.normal(0.0, 0.01, size=n)
+    pcm = np.clip(np.round(out * 32768.0), -32768, 32767)
+    return torch.from_numpy((pcm / 32768.0 + 1e-8).astype(np.float32))
+
+
+def test_mic_gcc_phat_features_match_oracle(ops):
+    """K1m (csrc/features_mic.hip): the MIC-format feature set of BASELINE config 5 -- four log-mel + six GCC-PHAT channels --
+    against the float64 oracle (oracle/features.py::get_feature_mic; PARITY UNPINNED: GCC-PHAT is not in the reference, the
+    oracle restates the DCASE2022 baseline definition and is pinned by its delay property in test_oracle_golden.py)."""
+    from oracle import features as ofeat
+    from adyolo_amd.features import MicFeatureExtractor
+    audio = _mic_audio(2, 24000 * 2, seed=11)
+    rng = np.random.default_rng(3)
+    scaler = {"MEL": {"mean": rng.normal(-40, 5, (1, 64, 4)), "std": rng.uniform(5, 15, (1, 64, 4))},
+              "GCC": {"mean": rng.normal(0, 0.01, (1, 64, 6)), "std": rng.uniform(0.05, 0.2, (1, 64, 6))}}
+    fx = MicFeatureExtractor(scaler, "cuda:0")
+    got32 = fx(dev(audio))
+    got = fx(dev(audio), channels_last=False).cpu()
+    torch.cuda.synchronize()
+    assert got32.shape == (2, 80, 64, 32) and float(got32[..., 10:].abs().max()) == 0.0
+    for b in range(2):
+        ref = torch.from_numpy(ofeat.get_feature_mic(audio[b].double().numpy(), scaler)[0])
+        assert_close(got[b, :4], ref[:4], 1e-3, "log-mel of the microphones (clip %d)" % b)
+        err = float((got[b, 4:] - ref[4:]).abs().max())
+        assert err < 1e-3, "GCC-PHAT abs err %.3e (z-scored values reach %.1f)" % (err, float(ref[4:].abs().max()))
+        assert float(ref[4:].abs().max()) > 3.0                          # the delay peaks are there
+        assert torch.equal(got32[b, :, :, :10].permute(2, 0, 1).cpu(), got[b])
+
+
+def test_config5_mic_model_train_step_matches_oracle(ops):
+    """BASELINE config 5 end to end at test size: MIC audio -> (10, T, 64) features -> SE-ResNet34 with a 10-channel stem
+    (32-channel pixels, Winograd stem convolution) -> ADPIT head + loss, one training step against the oracle on the same
+    features: output 1e-3, loss 1e-3, stem weight gradient (Cin_real = 10 of 32 padded channels) and head gradients."""
+    from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
+    from adyolo_amd.features import MicFeatureExtractor
+    from adyolo_amd.datasets import ClasswiseLabelEncoder
+    from oracle import features as ofeat, seresnet as onet, other_losses as ol
+    prm = _params()
+    prm["args"]["loss"] = "adpit"
+    torch.manual_seed(100)
+    model = WrapperModel((1, 10, 80, 64), (), prm).to("cuda:0")
+    assert model.encoder.conv1.weight.shape == (32, 10, 3, 3)
+    crit = WrapperCriterion(prm)
+    model.train()
+    model.encoder.lstm.dropout = 0.0
+    audio = _mic_audio(3, 24000 * 2, seed=12)
+    enc = ClasswiseLabelEncoder(12)
+    ev = {0: [[3, 0, 10.0, 5.0]], 2: [[3, 0, 10.0, 5.0], [3, 1, -170.0, 40.0]], 5: [[1, 0, 0.0, 0.0], [2, 1, 90.0, 10.0]]}
+    target = torch.stack([enc.get_adpit_label(ev, 20), enc.get_adpit_label({}, 20), enc.get_adpit_label({7: [[4, 0, 1.0, 2.0]]}, 20)])
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    feat = MicFeatureExtractor(None, "cuda:0")(dev(audio))
+    out = model(feat, channels_last8=True)
+    loss = crit(out, target)
+    loss.backward()
+    torch.cuda.synchronize()
+    f_ref = torch.stack([torch.from_numpy(ofeat.get_feature_mic(audio[b].double().numpy())[0]) for b in range(3)])
+    assert float((feat[..., :10].permute(0, 3, 1, 2).cpu() - f_ref).abs().max()) < 1e-3
+    names = ["encoder.conv1.weight", "head.adpit_head.0.weight", "head.adpit_head.1.weight"]
+    for n in names:
+        sd[n].requires_grad_(True)
+    enc_sd, _ = onet.split_state_dict(sd)
+    y = onet.encoder_forward(enc_sd, f_ref, training=True)
+    raw = F.linear(F.linear(y, sd["head.adpit_head.0.weight"], sd["head.adpit_head.0.bias"]),
+                   sd["head.adpit_head.1.weight"], sd["head.adpit_head.1.bias"])
+    out_ref = torch.tanh(raw)
+    loss_ref = ol.adpit_loss(out_ref, target, 12)
+    loss_ref.backward()
+    assert float((out.detach().cpu() - out_ref).abs().max()) <= 1e-3
+    assert abs(float(loss) - float(loss_ref)) <= 1e-3 * abs(float(loss_ref))
+    named = dict(model.named_parameters())
+    for n in names:
+        got, ref = named[n].grad.cpu(), sd[n].grad
+        cos = float(torch.dot(got.reshape(-1).double(), ref.reshape(-1).double()) / (got.double().norm() * ref.double().norm()))
+        lim = 5e-2 if n.startswith("encoder") else 1e-3          # (toy-size encoder gradients: the bound of DESIGN section 7)
+        dev_ = float((got - ref).abs().max()) / float(ref.abs().max())
+        assert cos >= 0.999 and dev_ <= lim, "%s: cosine %.6f, max dev %.2e" % (n, cos, dev_)

@@ -268,6 +268,31 @@ def test_feature_chain_after_the_stft_matches_the_real_reference():
     assert int(g["spec_nb_label_frames"]) == t * 600 // 2400
 
 
+def test_gcc_phat_oracle_finds_the_inter_microphone_delay():
+    """GCC-PHAT (MIC features of BASELINE config 5) has no counterpart in the reference -- parity unpinned -- so the oracle's
+    restatement of the DCASE2022 baseline definition is pinned by its defining PROPERTY: for microphone n = microphone m
+    delayed by d samples, cc of pair (m, n) peaks at lag +d, i.e. at bin 32 + d of concat(cc[-32:], cc[:32]); plus shapes,
+    the irfft normalisation (a zero-delay pair peaks at 1.0 for identical channels) and the pair order."""
+    rng = np.random.default_rng(7)
+    n = 24000
+    base = rng.normal(0.0, 0.1, size=n + 64)
+    delays = [0, 3, 7, 12]
+    audio = np.stack([base[32 - d:32 - d + n] for d in delays], axis=1)           # mic c = base delayed by delays[c]
+    spec = ofeat.stft(audio)
+    g = ofeat.gcc_phat(spec)
+    assert g.shape == (40, 64, 6)
+    pairs = [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
+    for p, (m, k) in enumerate(pairs):
+        want = 32 + (delays[k] - delays[m])
+        assert (np.argmax(g[5:35, :, p], axis=1) == want).all(), (p, want)
+        assert g[5:35, want, p].min() > 0.9                                       # PHAT weighting: a pure delay is a unit impulse
+    same = ofeat.gcc_phat(ofeat.stft(np.stack([base[:n]] * 4, axis=1)))
+    np.testing.assert_allclose(same[:, 32, :], 1.0, atol=1e-12)
+    feat, nb = ofeat.get_feature_mic(audio)
+    assert feat.shape == (10, 40, 64) and feat.dtype == np.float32 and nb == 10
+    np.testing.assert_allclose(feat[:4], ofeat.get_feature(audio)[0][:4], atol=0)    # the log-mel half is the FOA code on MIC audio
+
+
 def test_other_label_encoders_match_reference():
     from oracle import other_losses as ool
     from adyolo_amd.datasets import ClasswiseLabelEncoder
