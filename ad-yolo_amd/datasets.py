@@ -236,9 +236,12 @@ class FoaDataset(torch.utils.data.Dataset):
         self.is_valid, self.is_infer, self.set_type = is_valid, set_type == "infer", set_type
         self.loss_nm = params["args"]["loss"]
         dc = params["data_config"]
+        # audio format: the reference reads ``foa_dev`` only (datasets.py:36-37,55); ``data_config.audio_format: mic`` selects the
+        # DCASE ``mic_dev`` directory of the same layout (4-channel int16 WAVs; BASELINE config 5, features.MicFeatureExtractor)
+        adir = {"foa": "foa_dev", "mic": "mic_dev"}[str(dc.get("audio_format", "foa")).lower()]
         if set_type == "train":
             sub = "dev-train-chunked_{}s_{}s".format(dc["chunk_window_s"], dc["chunk_stride_s"])
-            self.wav_pth, self.csv_pth = opj(dc["data_pth"], "foa_dev", sub), opj(dc["data_pth"], "metadata_dev", sub)
+            self.wav_pth, self.csv_pth = opj(dc["data_pth"], adir, sub), opj(dc["data_pth"], "metadata_dev", sub)
             self.total_filelist = [i.replace(".wav", "") for i in os.listdir(self.wav_pth)]
             self.remaining_file = copy.deepcopy(self.total_filelist)
             self.nb_samples = params["train_config"]["batch_size"] * params["train_config"]["nb_iters"] * self.world
@@ -248,7 +251,7 @@ class FoaDataset(torch.utils.data.Dataset):
             if self.is_infer:
                 self.wav_pth, self.csv_pth = str(params["args"]["infer_pth"]), None
             else:
-                self.wav_pth = opj(dc["data_pth"], "foa_dev", "dev-{}".format(set_type))
+                self.wav_pth = opj(dc["data_pth"], adir, "dev-{}".format(set_type))
                 self.csv_pth = opj(dc["data_pth"], "metadata_dev", "dev-{}".format(set_type))
             self.filelist = [i.replace(".wav", "") for i in os.listdir(self.wav_pth)]
             if self.world > 1:                   # evaluation files are dealt round-robin over the ranks (sorted: listdir order is not a contract)

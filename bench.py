@@ -429,7 +429,12 @@ def main():
         print(json.dumps(run_extra_config(args.only_extra, torch, args.extra_mode)), flush=True)
         return
 
-    rank, world, local_rank = adist.init_from_env("nccl")
+    # ADYOLO_DIST_BACKEND=gloo ADYOLO_BENCH_ONE_DEVICE=1: every rank on cuda:0 over gloo -- a FUNCTIONAL run of the N > 1 path
+    # on a single-GPU box (RCCL refuses two ranks on one device); the numbers of such a run mean nothing
+    one_device = os.environ.get("ADYOLO_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local_rank = adist.init_from_env(os.environ.get("ADYOLO_DIST_BACKEND", "nccl"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
@@ -586,7 +591,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.encoder + " + adyolo loss, synthetic 4ch 24kHz %ds clips, bs=%d per GPU, "
                                    "12 classes, features+fwd+loss+bwd+allreduce+Adam" % (args.seconds, B),
-                       "global_batch": world * B, "clip_seconds": args.seconds, "parallelism": "dp%d" % world},
+                       "global_batch": world * B, "clip_seconds": args.seconds,
+                       "parallelism": "dp%d" % world + (" (functional run: all ranks on one device over gloo)" if one_device else "")},
             # achieved = matrix FLOPs ISSUED per second by the dominant kernel family (what the MFMA pipe executes);
             # algorithmic_tflops = the direct-convolution FLOPs the same launches stand for, 36/16 of it in
             # Winograd form

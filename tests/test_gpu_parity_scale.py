@@ -945,3 +945,28 @@ def test_exact_data_parallel_equals_one_device_on_the_concatenated_batch(ops, tm
     assert cos >= 0.999, "3-step parameter updates: cosine %.6f" % cos
     rel = float((r0["params"] - one["params"]).abs().mean()) / float(one["params"].abs().mean())
     assert rel <= 3e-3, "parameters after 3 steps: mean deviation %.2e of the mean magnitude" % rel
+
+
+def test_bench_two_ranks_functional_run_on_one_device(ops):
+    """``bench.py --gpus 2`` end to end on this single-GPU box: the launcher starts two workers, both on cuda:0 over gloo
+    (ADYOLO_DIST_BACKEND / ADYOLO_BENCH_ONE_DEVICE: RCCL refuses two ranks on one device), barrier + max-over-ranks timing,
+    rank 0 prints ONE JSON line with n_gpus = 2 and the whole-job aggregate.  A functional check of the N > 1 path of the
+    benchmark (launcher, rank env, collectives, JSON contract) -- its numbers mean nothing."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ADYOLO_DIST_BACKEND="gloo", ADYOLO_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "ADYOLO_FORCE_DP_HOOKS"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--seconds", "4", "--no-cpu-baseline", "--no-stages", "--no-extra"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["config"]["global_batch"] == 4 and "dp2" in d["config"]["parallelism"]
+    assert abs(d["value"] - 2 * 2 * 4 / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]     # whole-job audio-seconds per second
+    assert np.isfinite(d["final_loss"]) and d["roofline"]["launches"] > 0 and "cpu_baseline" not in d
