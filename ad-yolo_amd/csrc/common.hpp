@@ -108,24 +108,4 @@ __device__ __forceinline__ double block_colsum32(const float *__restrict__ parti
     return s;
 }
 
-// "Last workgroup finishes": true in exactly ONE of the `n` workgroups that call it with the same counter -- the last to
-// arrive, which may then read what the others wrote before arriving (their stores are fenced, the reader's loads are of
-// addresses this launch has not read before).  The counter must be zero before the first arrival and is reset by the last,
-// so one statically zero-initialised word serves launch after launch on a stream.  Used to fold the tiny finishing kernels
-// (5 us launches that sit between two convolutions) into the reduction that feeds them, without losing the reduction's
-// parallelism; the finishing arithmetic and its summation order are unchanged (bit-identical results).
-__device__ __forceinline__ bool last_arrival(unsigned *counter, unsigned n) {
-    __shared__ bool last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned prev = atomicAdd(counter, 1u);
-        last = prev == n - 1;
-        if (last) atomicExch(counter, 0u);
-    }
-    __syncthreads();
-    if (last) __threadfence();
-    return last;
-}
-
 }  // namespace adyolo

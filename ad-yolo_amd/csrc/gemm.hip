@@ -241,13 +241,9 @@ __global__ void gemm_slab_reduce_kernel(const float *__restrict__ slabs, const f
 
 // column sums: stage 1 partial[blk][c] over a strip of rows (64 columns x 4 row-lanes per workgroup, LDS
 // combine), stage 2 sums the partials in double (32 columns x 8 part-groups per workgroup).
-// one launch (round 3): the last of a 64-column block's strip-workgroups to arrive sums the partials of its columns
-__device__ unsigned g_colsum_arrival[1024];
-__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ A, float *__restrict__ partial,
-                                                     float *__restrict__ out, long R, int C, int lda, long rows_per_block,
-                                                     int accumulate) {
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ A, float *__restrict__ partial,
+                                                             long R, int C, int lda, long rows_per_block) {
     __shared__ float red[256];
-    __shared__ double dred[256];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cx;
     const long rbeg = (long)blockIdx.x * rows_per_block;
@@ -258,14 +254,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ A
     red[threadIdx.x] = s;
     __syncthreads();
     if (ry == 0 && c < C) partial[(size_t)blockIdx.x * C + c] = red[cx] + red[64 + cx] + red[128 + cx] + red[192 + cx];
-    if (!last_arrival(&g_colsum_arrival[blockIdx.y], gridDim.x)) return;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int c0 = blockIdx.y * 64 + half * 32;
-        const double t = block_colsum32(partial, (int)gridDim.x, (size_t)C, c0, C, dred);
-        const int cc = c0 + (threadIdx.x & 31);
-        if ((threadIdx.x >> 5) == 0 && cc < C) out[cc] = (accumulate ? out[cc] : 0.f) + (float)t;
-    }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ partial, float *__restrict__ out,
+                                                           int nblk, int C, int accumulate) {
+    __shared__ double red[256];
+    const double s = block_colsum32(partial, nblk, (size_t)C, blockIdx.x * 32, C, red);
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    if ((threadIdx.x >> 5) == 0 && c < C) out[c] = (accumulate ? out[c] : 0.f) + (float)s;
 }
 
 __global__ void add_kernel(const float4 *__restrict__ a, const float4 *__restrict__ b, float4 *__restrict__ y,
@@ -430,9 +425,11 @@ extern "C" int adyolo_colsum(const float *A, float *out, float *partial, int R, 
     if (nblk > 1024) nblk = 1024;
     const long rpb = ((long)R + nblk - 1) / nblk;
     nblk = cdiv(R, rpb);
-    ADYOLO_REQUIRE(cdiv(C, 64) <= 1024, ADYOLO_ENOSUP, "colsum: C=%d exceeds the arrival counters", C);
-    hipLaunchKernelGGL(colsum_kernel, dim3(nblk, cdiv(C, 64)), dim3(256), 0, st, A, partial, out, (long)R, C, lda, rpb, accumulate);
-    return check_launch("colsum");
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, cdiv(C, 64)), dim3(256), 0, st, A, partial, (long)R, C, lda, rpb);
+    int rc = check_launch("colsum_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, partial, out, nblk, C, accumulate);
+    return check_launch("colsum_final");
 }
 
 extern "C" int adyolo_add(const float *a, const float *b, float *y, long n, void *stream) {

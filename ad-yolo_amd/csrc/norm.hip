@@ -106,33 +106,6 @@ __global__ __launch_bounds__(256) void persample_reduce_kernel(const float *__re
     }
 }
 
-// two-stage sum of per-patch sums in ONE launch: stage 1 on the (ceil(C/32), groups) grid writes per-group sums, the last
-// of a channel block's `groups` workgroups to arrive adds them up (same order as the separate second launch of round 2)
-__device__ unsigned g_tiles_arrival[64];
-__global__ __launch_bounds__(256) void twostage_reduce_kernel(const float *__restrict__ tiles, float *__restrict__ partial,
-                                                              float *__restrict__ out0, float *__restrict__ out1,
-                                                              int groups, int per_group, int C) {
-    __shared__ double red[256];
-    const int gI = blockIdx.y, c0 = blockIdx.x * 32;
-    const size_t half = (size_t)groups * per_group * C;
-    const float *base = tiles + (size_t)gI * per_group * C;
-    const double s0 = block_colsum32(base, per_group, (size_t)C, c0, C, red);
-    const double s1 = block_colsum32(base + half, per_group, (size_t)C, c0, C, red);
-    const int c = c0 + (threadIdx.x & 31);
-    float *p0 = partial, *p1 = partial + (size_t)groups * C;
-    if ((threadIdx.x >> 5) == 0 && c < C) {
-        p0[(size_t)gI * C + c] = (float)s0;
-        p1[(size_t)gI * C + c] = (float)s1;
-    }
-    if (!last_arrival(&g_tiles_arrival[blockIdx.x], gridDim.y)) return;
-    const double t0 = block_colsum32(p0, groups, (size_t)C, c0, C, red);
-    const double t1 = block_colsum32(p1, groups, (size_t)C, c0, C, red);
-    if ((threadIdx.x >> 5) == 0 && c < C) {
-        out0[c] = (float)t0;
-        out1[c] = (float)t1;
-    }
-}
-
 // stage 3 (BatchNorm forward): batch mean / invstd from the per-sample sums, running statistics update
 __global__ void bn_stats_final_kernel(const float *__restrict__ ps0, const float *__restrict__ ps1,
                                       float *__restrict__ mean, float *__restrict__ invstd,
@@ -158,14 +131,16 @@ __global__ void bn_stats_final_kernel(const float *__restrict__ ps0, const float
 }
 
 // stage 3, parallel form: 32 channels x 8 sample-groups per workgroup (double), then mean / invstd, the running
-// statistics update and -- when gamma / beta are given -- the affine (scale, shift) the consumers apply; the work of ONE
-// workgroup for channels c0 .. c0 + 31
-__device__ __forceinline__ void bn_finish_block(const float *__restrict__ ps0, const float *__restrict__ ps1,
-                                                float *__restrict__ mean, float *__restrict__ invstd,
-                                                float *__restrict__ rmean, float *__restrict__ rvar,
-                                                const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                float *__restrict__ scale, float *__restrict__ shift, int N, int C, int c0,
-                                                double R, float momentum, float eps, double *red) {
+// statistics update and -- when gamma / beta are given -- the affine (scale, shift) the consumers apply, in ONE launch
+// grid ceil(C/32)
+__global__ __launch_bounds__(256) void bn_finish_kernel(const float *__restrict__ ps0, const float *__restrict__ ps1,
+                                                        float *__restrict__ mean, float *__restrict__ invstd,
+                                                        float *__restrict__ rmean, float *__restrict__ rvar,
+                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                        float *__restrict__ scale, float *__restrict__ shift, int N, int C,
+                                                        double R, float momentum, float eps) {
+    __shared__ double red[256];
+    const int c0 = blockIdx.x * 32;
     const double t0 = block_colsum32(ps0, N, (size_t)C, c0, C, red);
     const double t1 = block_colsum32(ps1, N, (size_t)C, c0, C, red);
     const int c = c0 + (threadIdx.x & 31);
@@ -186,43 +161,6 @@ __device__ __forceinline__ void bn_finish_block(const float *__restrict__ ps0, c
         scale[c] = sc;
         shift[c] = beta[c] - mf * sc;
     }
-}
-
-// grid ceil(C/32)
-__global__ __launch_bounds__(256) void bn_finish_kernel(const float *__restrict__ ps0, const float *__restrict__ ps1,
-                                                        float *__restrict__ mean, float *__restrict__ invstd,
-                                                        float *__restrict__ rmean, float *__restrict__ rvar,
-                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                        float *__restrict__ scale, float *__restrict__ shift, int N, int C,
-                                                        double R, float momentum, float eps) {
-    __shared__ double red[256];
-    bn_finish_block(ps0, ps1, mean, invstd, rmean, rvar, gamma, beta, scale, shift, N, C, blockIdx.x * 32, R, momentum, eps, red);
-}
-
-// stages 2 + 3 in ONE launch (round 3): per-sample sums on the (ceil(C/32), N) grid of persample_reduce_kernel; the last of
-// the N workgroups of a channel block to arrive runs that block's finishing step (36 launches per train step fewer; same
-// arithmetic, same order)
-__device__ unsigned g_bn_arrival[64];
-__global__ __launch_bounds__(256) void persample_finish_kernel(const float *__restrict__ partial, float *__restrict__ ps0,
-                                                               float *__restrict__ ps1, float *__restrict__ mean,
-                                                               float *__restrict__ invstd, float *__restrict__ rmean,
-                                                               float *__restrict__ rvar, const float *__restrict__ gamma,
-                                                               const float *__restrict__ beta, float *__restrict__ scale,
-                                                               float *__restrict__ shift, int N, int G, int C, double R,
-                                                               float momentum, float eps) {
-    __shared__ double red[256];
-    const int n = blockIdx.y, c0 = blockIdx.x * 32;
-    const size_t half = (size_t)N * G * C;
-    const float *base = partial + (size_t)n * G * C;
-    const double s0 = block_colsum32(base, G, (size_t)C, c0, C, red);
-    const double s1 = block_colsum32(base + half, G, (size_t)C, c0, C, red);
-    const int c = c0 + (threadIdx.x & 31);
-    if ((threadIdx.x >> 5) == 0 && c < C) {
-        ps0[(size_t)n * C + c] = (float)s0;
-        ps1[(size_t)n * C + c] = (float)s1;
-    }
-    if (!last_arrival(&g_bn_arrival[blockIdx.x], gridDim.y)) return;
-    bn_finish_block(ps0, ps1, mean, invstd, rmean, rvar, gamma, beta, scale, shift, N, C, c0, R, momentum, eps, red);
 }
 
 __global__ void bn_eval_stats_kernel(const float *rm, const float *rv, float *mean, float *invstd, int C, float eps) {
@@ -648,11 +586,13 @@ extern "C" int adyolo_bn_stats(const float *x, float *ssum, float *mean, float *
     if (rc) return rc;
     float *ps0 = ssum ? ssum : partial + (size_t)2 * 1024 * C;
     float *ps1 = partial + (size_t)3 * 1024 * C;
-    ADYOLO_REQUIRE(C <= 64 * 32, ADYOLO_ENOSUP, "bn_stats: C=%d exceeds the arrival counters", C);
-    hipLaunchKernelGGL(persample_finish_kernel, dim3(cdiv(C, 32), N), dim3(256), 0, st, partial, ps0, ps1, mean, invstd,
-                       running_mean, running_var, (const float *)nullptr, (const float *)nullptr, (float *)nullptr,
-                       (float *)nullptr, N, G, C, (double)N * (double)HW, momentum, eps);
-    return check_launch("bn_stats_persample_finish");
+    hipLaunchKernelGGL(persample_reduce_kernel, dim3(cdiv(C, 32), N), dim3(256), 0, st, partial, ps0, ps1, N, G, C);
+    rc = check_launch("bn_stats_persample");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_finish_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, ps0, ps1, mean, invstd, running_mean,
+                       running_var, (const float *)nullptr, (const float *)nullptr, (float *)nullptr, (float *)nullptr, N, C,
+                       (double)N * (double)HW, momentum, eps);
+    return check_launch("bn_stats_final");
 }
 
 extern "C" int adyolo_bn_stats_tiles(const float *tile_stats, float *ssum, float *mean, float *invstd,
@@ -665,10 +605,12 @@ extern "C" int adyolo_bn_stats_tiles(const float *tile_stats, float *ssum, float
     hipStream_t st = as_stream(stream);
     float *ps0 = ssum ? ssum : partial;
     float *ps1 = partial + (size_t)1024 * C;
-    ADYOLO_REQUIRE(C <= 64 * 32, ADYOLO_ENOSUP, "bn_stats_tiles: C=%d exceeds the arrival counters", C);
-    hipLaunchKernelGGL(persample_finish_kernel, dim3(cdiv(C, 32), N), dim3(256), 0, st, tile_stats, ps0, ps1, mean, invstd,
-                       running_mean, running_var, gamma, beta, scale, shift, N, G, C, (double)N * (double)HW, momentum, eps);
-    return check_launch("bn_stats_tiles_persample_finish");
+    hipLaunchKernelGGL(persample_reduce_kernel, dim3(cdiv(C, 32), N), dim3(256), 0, st, tile_stats, ps0, ps1, N, G, C);
+    int rc = check_launch("bn_stats_tiles_persample");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_finish_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, ps0, ps1, mean, invstd, running_mean,
+                       running_var, gamma, beta, scale, shift, N, C, (double)N * (double)HW, momentum, eps);
+    return check_launch("bn_stats_tiles_final");
 }
 
 // the two halves of adyolo_bn_stats_tiles as separate calls: under exact data parallelism the per-sample sums of all ranks
@@ -746,9 +688,11 @@ extern "C" int adyolo_bn_bwd_tiles(const float *tile_stats, float *sdy, float *s
         hipLaunchKernelGGL(persample_reduce_kernel, dim3(cdiv(C, 32), 1), dim3(256), 0, st, tile_stats, sdy, sdyx, 1, tiles, C);
         return check_launch("bn_bwd_tiles");
     }
-    ADYOLO_REQUIRE(C <= 64 * 32, ADYOLO_ENOSUP, "bn_bwd_tiles: C=%d exceeds the arrival counters", C);
-    hipLaunchKernelGGL(twostage_reduce_kernel, dim3(cdiv(C, 32), groups), dim3(256), 0, st, tile_stats, partial, sdy, sdyx, groups,
-                       tiles / groups, C);
+    hipLaunchKernelGGL(persample_reduce_kernel, dim3(cdiv(C, 32), groups), dim3(256), 0, st, tile_stats, partial,
+                       partial + (size_t)groups * C, groups, tiles / groups, C);
+    int rc = check_launch("bn_bwd_tiles_groups");
+    if (rc) return rc;
+    hipLaunchKernelGGL(persample_reduce_kernel, dim3(cdiv(C, 32), 1), dim3(256), 0, st, partial, sdy, sdyx, 1, groups, C);
     return check_launch("bn_bwd_tiles");
 }
 

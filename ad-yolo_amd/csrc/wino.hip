@@ -796,9 +796,20 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
     }
 }
 
-// dw[co][ci][3][3] = G^T dU[.][ci][co] G for one (ci, co)
-__device__ __forceinline__ void wino_wgrad_finish_one(const float *__restrict__ du, float *__restrict__ dw, int Cin,
-                                                      int Cin_real, int Cout, int idx) {
+// slabs [nslab][total] -> du [total] (fixed order, partial sums in double)
+__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ du,
+                                                                int nslab, int total) {
+    __shared__ double red[256];
+    const double sum = block_colsum32(slabs, nslab, (size_t)total, blockIdx.x * 32, total, red);
+    const int idx = blockIdx.x * 32 + (threadIdx.x & 31);
+    if ((threadIdx.x >> 5) == 0 && idx < total) du[idx] = (float)sum;
+}
+
+// dw[co][ci][3][3] = G^T dU[.][ci][co] G
+__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float *__restrict__ du, float *__restrict__ dw,
+                                                                int Cin, int Cin_real, int Cout) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // over [Cin][Cout], co fastest
+    if (idx >= Cin * Cout) return;
     const int co = idx % Cout, ci = idx / Cout;
     if (ci >= Cin_real) return;
     float d[4][4];
@@ -818,23 +829,6 @@ __device__ __forceinline__ void wino_wgrad_finish_one(const float *__restrict__ 
         o[a * 3 + 1] = 0.5f * (t[a][1] - t[a][2]);
         o[a * 3 + 2] = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
     }
-}
-
-// slabs [nslab][16 Cin Cout] -> dU (fixed order, partial sums in double), and -- by the last of the 16 position-workgroups
-// of a 32-pair chunk to arrive -- dw = G^T dU G for those 32 (ci, co) pairs: the separate finishing launch of round 2 folded
-// in (32 launches per train step fewer, same arithmetic and order).  grid = 16 Cin Cout / 32
-__device__ unsigned g_wgrad_arrival[2048];
-__global__ __launch_bounds__(256) void wino_wgrad_reduce_finish_kernel(const float *__restrict__ slabs, float *__restrict__ du,
-                                                                       float *__restrict__ dw, int nslab, int Cin,
-                                                                       int Cin_real, int Cout) {
-    __shared__ double red[256];
-    const int total = 16 * Cin * Cout, per_pos = Cin * Cout;
-    const double sum = block_colsum32(slabs, nslab, (size_t)total, blockIdx.x * 32, total, red);
-    const int idx = blockIdx.x * 32 + (threadIdx.x & 31);
-    if ((threadIdx.x >> 5) == 0 && idx < total) du[idx] = (float)sum;
-    const int chunk = (blockIdx.x * 32 % per_pos) / 32;               // per_pos is a multiple of 32: a workgroup never straddles positions
-    if (!last_arrival(&g_wgrad_arrival[chunk], 16u)) return;
-    if (threadIdx.x < 32) wino_wgrad_finish_one(du, dw, Cin, Cin_real, Cout, chunk * 32 + threadIdx.x);
 }
 
 // Work items = (sample, 16-pixel column strip, segment of seg_rows tile rows), dealt STATICALLY to the nsplit workgroups of
@@ -907,8 +901,9 @@ extern "C" int adyolo_wino_wgrad(const float *x, const float *dy, const float *i
     int rc = check_launch("wino_wgrad");
     if (rc) return rc;
     const int total = 16 * Cin * Cout;
-    ADYOLO_REQUIRE(Cin * Cout / 32 <= 2048, ADYOLO_ENOSUP, "wino_wgrad: Cin * Cout = %d exceeds the arrival counters", Cin * Cout);
-    hipLaunchKernelGGL(wino_wgrad_reduce_finish_kernel, dim3(total / 32), dim3(256), 0, st, slabs, du, dw, nsplit, Cin, Cin_real,
-                       Cout);
-    return check_launch("wino_wgrad_reduce_finish");
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, slabs, du, nsplit, total);
+    rc = check_launch("wino_wgrad_reduce");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(cdiv(Cin * Cout, 256)), dim3(256), 0, st, du, dw, Cin, Cin_real, Cout);
+    return check_launch("wino_wgrad_finish");
 }
