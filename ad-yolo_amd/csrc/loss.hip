@@ -162,9 +162,11 @@ __global__ __launch_bounds__(256) void loss_assign_kernel(const float *__restric
         cnt_partial[blockIdx.x * 4 + threadIdx.x] = (unsigned)(red_cnt[0][threadIdx.x] + red_cnt[1][threadIdx.x] +
                                                                 red_cnt[2][threadIdx.x] + red_cnt[3][threadIdx.x]);
     if (threadIdx.x == 0) ang_partial[blockIdx.x] = red_sum[0] + red_sum[1] + red_sum[2] + red_sum[3];
-    __threadfence();
     __syncthreads();
-    if (threadIdx.x == 0) is_last = atomicAdd(&hdr[4], 1u) == gridDim.x - 1;
+    if (threadIdx.x == 0) {        // ONE device-scope fence per workgroup (a fence costs 5-20 ns per wave on this multi-XCD part;
+        __threadfence();           // release is cumulative over the barrier: it also covers the stores of threads 1-3)
+        is_last = atomicAdd(&hdr[4], 1u) == gridDim.x - 1;
+    }
     __syncthreads();
     if (is_last) {
         __threadfence();
