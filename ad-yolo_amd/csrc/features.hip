@@ -23,7 +23,10 @@
 
 namespace adyolo {
 
-constexpr int NMEL = 64, FR = 8;
+#ifndef K1_FR
+#define K1_FR 8
+#endif
+constexpr int NMEL = 64, FR = K1_FR;
 
 __device__ __forceinline__ void atomic_max_float(float *addr, float val) {
     if (val >= 0.f) atomicMax(reinterpret_cast<int *>(addr), __float_as_int(val));
@@ -37,6 +40,10 @@ constexpr int MAX_MELW = 1200, SPS8 = 8, MAX_CHUNKS = 224;     // LDS total 34.7
 // bin k = k1 + 10 k2 + 100 k3 then sits at position k1*120 + k2*12 + k3.  Pass 1 takes its input straight from global
 // memory (lane = n mod 120: consecutive samples), the Hann window is folded in as
 // 0.5 - 0.5 cos(2 pi (t + 120 n1) / 1200) = 0.5 - 0.5 (cos a cos b - sin a sin b) with a fixed per thread.
+#ifndef K1_SKIP
+#define K1_SKIP 0      // timing-only what-if builds (tools/build_variant.sh ... -DK1_SKIP=mask; results invalid): bit 0 global loads,
+#endif                 // 1 pass 1, 2 pass 2, 3 pass 3, 4 untangling, 5 mel contraction, 6 combine + log + store, 7 all audio loads hit
+                       // one cache line, 8 no window, 9 no pass-1 table loads, 10 one pass-1 LDS store instead of ten
 __global__ __launch_bounds__(256, 4) void feat_stft_mel_kernel(
     const float *__restrict__ audio, const long *__restrict__ clip_offset, const float *__restrict__ twiddle,
     const int *__restrict__ chunk_mel, const int *__restrict__ chunk_start, const int *__restrict__ chunk_len,
@@ -66,18 +73,22 @@ __global__ __launch_bounds__(256, 4) void feat_stft_mel_kernel(
     // pass-1 role: signal sf (0: W + iY, 1: Z + iX), residue st = n mod 120
     const int sf = tid >= 120 ? 1 : 0, st = tid - 120 * sf;
     const bool p1 = tid < 240;
+    // hop = 600 = 5 x 120: thread (sf, st)'s samples 5..9 of frame t ARE its samples 0..4 of frame t + 1 -- only the first
+    // frame of a workgroup loads all ten, every later one shifts five registers and loads five (half the global loads)
     float2 av[10];
-    auto load_frame = [&](int t) {
-        if (p1) {
+    auto load_frame = [&](int t, int first) {
+        if (p1 && !(K1_SKIP & 1)) {
 #pragma unroll
             for (int i = 0; i < 10; ++i) {
+                if (i < first) continue;
                 int s = t * FHOP - FHOP + st + 120 * i;
                 if (s < 0) s = -s;                   // np.pad(..., mode='reflect') at the start of the (virtual) clip
+                if (K1_SKIP & 128) s = st;
                 av[i] = aud[2 * (size_t)s + sf];
             }
         }
     };
-    if (t0 < T) load_frame(t0);
+    if (t0 < T) load_frame(t0, 0);
     __syncthreads();
     for (int fr = 0; fr < FR; ++fr) {
         const int t = t0 + fr;
@@ -90,32 +101,33 @@ __global__ __launch_bounds__(256, 4) void feat_stft_mel_kernel(
         const int sfo = ti >= 120 ? 1 : 0, sto = ti - 120 * sfo;
         const bool p1o = ti < 240;
         // ---- pass 1 (from registers): window, ten-point DFT over n1, twiddle, store at (k1, st)
-        if (p1o) {
+        if (p1o && !(K1_SKIP & 2)) {
             const float wc = tw[sto].x, ws = -tw[sto].y;      // cos / sin of 2 pi st / 1200 (the table holds exp(-i .))
             float2 v[10];
 #pragma unroll
             for (int i = 0; i < 10; ++i) {
-                const float w = 0.5f - 0.5f * (wc * RC10[i] + ws * RS10[i]);      // RS10 = -sin
+                const float w = (K1_SKIP & 256) ? 1.f : 0.5f - 0.5f * (wc * RC10[i] + ws * RS10[i]);      // RS10 = -sin
                 v[i] = make_float2(av[i].x * w, av[i].y * w);
             }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) av[i] = av[i + 5];
             butterfly<10>(v);
             float2 *dst = buf + sfo * FSIG + sto + 2 * (sto / 12);
             dst[0] = v[0];
-            // twiddle index (st * k) mod 1200, stepped; `sto` is opaque to the optimiser once per frame, otherwise the 18
-            // table loads of passes 1-2 (and their addresses) are hoisted out of the frame loop into ~50 live registers
+            // twiddles W^{st k} from the lane-ordered copy of the table; `sto` is opaque to the optimiser once per frame,
+            // otherwise the 18 table loads of passes 1-2 (and their addresses) are hoisted out of the frame loop into ~50 live
+            // registers
             __builtin_amdgcn_sched_barrier(0);
-            int idx = 0;
+            const float2 *t1 = tw + FTW1 + sto;
 #pragma unroll
             for (int k = 1; k < 10; ++k) {
-                idx += sto;
-                if (idx >= FN) idx -= FN;
-                dst[k * (10 * FROW)] = cmul(v[k], tw[idx]);
+                if (!(K1_SKIP & 1024) || k == 1) dst[k * (10 * FROW)] = cmul(v[k], (K1_SKIP & 512) ? make_float2(0.6f, 0.8f) : t1[(k - 1) * 120]);
                 if (k % 3 == 0) __builtin_amdgcn_sched_barrier(0);      // three table loads in flight at a time
             }
         }
         __syncthreads();
         // ---- pass 2: ten-point DFT over n2 for (k1, n3), twiddle W_120^{n3 k2}
-        if (p1o) {
+        if (p1o && !(K1_SKIP & 4)) {
             const int k1 = sto / 12, n3 = sto - 12 * k1;
             float2 *base = buf + sfo * FSIG + k1 * (10 * FROW) + n3;
             float2 v[10];
@@ -126,13 +138,13 @@ __global__ __launch_bounds__(256, 4) void feat_stft_mel_kernel(
             base[0] = v[0];
 #pragma unroll
             for (int k = 1; k < 10; ++k) {
-                base[k * FROW] = cmul(v[k], tw[n3 * (k * 10)]);      // n3 k 10 <= 1080 < 1200
+                base[k * FROW] = cmul(v[k], tw[FTW2 + (k - 1) * 12 + n3]);
                 if (k % 3 == 0) __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
         // ---- pass 3: twelve-point DFT over n3 for the row (k1, k2)
-        if (ti < 200) {
+        if (ti < 200 && !(K1_SKIP & 8)) {
             const int f = ti >= 100 ? 1 : 0, r = ti - 100 * f;
             float4 *row = reinterpret_cast<float4 *>(buf + f * FSIG + r * FROW);
             float2 v[12];
@@ -153,7 +165,7 @@ __global__ __launch_bounds__(256, 4) void feat_stft_mel_kernel(
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int k = tid + 256 * i;              // (tid, not ti: these six LDS addresses are worth keeping in registers)
-            if (k < FBINS) {
+            if (k < FBINS && !(K1_SKIP & 16)) {
                 const int pk = fpos(k), pn = fpos(k == 0 ? 0 : FN - k);
                 const float2 z1 = buf[pk], z2 = buf[FSIG + pk];
                 const float2 n1 = make_float2(buf[pn].x, -buf[pn].y), n2 = make_float2(buf[FSIG + pn].x, -buf[FSIG + pn].y);
@@ -179,10 +191,10 @@ __global__ __launch_bounds__(256, 4) void feat_stft_mel_kernel(
             }
         }
         __syncthreads();
-        if (fr + 1 < FR && t + 1 < T) load_frame(t + 1);      // the next frame's samples travel under the mel contraction
+        if (fr + 1 < FR && t + 1 < T) load_frame(t + 1, 5);      // the next frame's samples travel under the mel contraction
         // sparse mel contraction: work item = a piece of <= 8 consecutive bins of one filter, all 7 quantities at once
         // (two ds_read_b128 + one weight per bin feed 8 FMAs)
-        for (int ck = ti; ck < n_chunks; ck += 256) {
+        for (int ck = ti; ck < ((K1_SKIP & 32) ? 0 : n_chunks); ck += 256) {
             const int st_ = chunk_start[ck], ln = chunk_len[ck], of = chunk_off[ck];
             float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
             const float4 *sp = reinterpret_cast<const float4 *>(spec) + 2 * st_;
@@ -202,7 +214,7 @@ __global__ __launch_bounds__(256, 4) void feat_stft_mel_kernel(
             mp[1] = a1;
         }
         __syncthreads();
-        for (int o = ti; o < 512; o += 256) {
+        for (int o = ti; o < ((K1_SKIP & 64) ? 0 : 512); o += 256) {
             const int m = o >> 3, c = o & 7;
             float acc = 0.f;
             if (c < 7)

@@ -47,7 +47,7 @@ __device__ __forceinline__ void fft_passes_2_3(float2 *buf, const float2 *__rest
         butterfly<10>(v);
         base[0] = v[0];
 #pragma unroll
-        for (int k = 1; k < 10; ++k) base[k * FROW] = cmul(v[k], tw[n3 * (k * 10)]);
+        for (int k = 1; k < 10; ++k) base[k * FROW] = cmul(v[k], tw[FTW2 + (k - 1) * 12 + n3]);
     }
     __syncthreads();
     if (ti < 200) {
@@ -74,13 +74,9 @@ __device__ __forceinline__ void fft_pass_1(float2 *buf, const float2 *__restrict
     butterfly<10>(v);
     float2 *dst = buf + sfo * FSIG + sto + 2 * (sto / 12);
     dst[0] = v[0];
-    int idx = 0;
+    const float2 *t1 = tw + FTW1 + sto;
 #pragma unroll
-    for (int k = 1; k < 10; ++k) {
-        idx += sto;
-        if (idx >= FN) idx -= FN;
-        dst[k * (10 * FROW)] = cmul(v[k], tw[idx]);
-    }
+    for (int k = 1; k < 10; ++k) dst[k * (10 * FROW)] = cmul(v[k], t1[(k - 1) * 120]);
 }
 
 __global__ __launch_bounds__(256, 3) void feat_gcc_kernel(const float *__restrict__ audio, const long *__restrict__ clip_offset,

@@ -7,6 +7,11 @@
 namespace adyolo {
 
 constexpr int FN = 1200, FBINS = 601, FHOP = 600;
+// the twiddle table handed in by the caller: [0, 1200) exp(-2 pi i n / 1200); then the entries of passes 1 and 2 in the order
+// their lanes read them -- FTW1 + (k-1) 120 + st = W^{st k} (k = 1..9, st < 120) and FTW2 + (k-1) 12 + n3 = W^{10 n3 k}: a
+// wave's load of one k touches 4 cache lines instead of up to 36 (the gather tw[(st k) mod 1200] kept the CU's address unit busy
+// for a third of the kernel)
+constexpr int FTW1 = FN, FTW2 = FN + 9 * 120, FTW_LEN = FN + 9 * 120 + 9 * 12;
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);

@@ -59,6 +59,11 @@ class FeatureExtractor:
         self.device = torch.device(device)
         n = np.arange(N_FFT, dtype=np.float64)
         tw = np.stack([np.cos(2.0 * np.pi * n / N_FFT), -np.sin(2.0 * np.pi * n / N_FFT)], axis=1)
+        # the same table entries once more in the order passes 1 and 2 of the transform read them (adyolo_hip.h, K1):
+        # [k-1][st] = tw[(st k) mod 1200] and [k-1][n3] = tw[10 n3 k] -- neighbouring lanes read neighbouring entries
+        k = np.arange(1, 10)[:, None]
+        tw = np.concatenate([tw, tw[(k * np.arange(120)[None, :]) % N_FFT].reshape(-1, 2),
+                             tw[(10 * k * np.arange(12)[None, :])].reshape(-1, 2)], axis=0)
         mel = slaney_mel_matrix()
         # non-zero weights filter after filter, each (contiguous, triangular) filter cut into pieces of <= 8 bins so
         # that the kernel's work items are balanced (filters span 2 .. ~70 bins)

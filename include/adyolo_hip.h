@@ -39,7 +39,9 @@ const char *adyolo_last_error(void);
  *           at clip_offset[b] -- the 20 s / 1 s-stride training chunks of src/preprocess.py:13-84 (chunking), computed
  *           from the whole recording in place; every virtual clip gets its own reflect padding (np.pad at the chunk
  *           start, preprocess.py writes the chunk as its own file) and its own top_db reference (chan_max row b)
- *   twiddle [1200][2]  exp(-2 pi i n/1200) (re,im) (the periodic Hann window is generated in the kernel)
+ *   twiddle [2388][2]  rows 0..1199: tw[n] = exp(-2 pi i n/1200) (re,im) (the periodic Hann window is generated in the
+ *           kernel); rows 1200 + (k-1) 120 + s = tw[(s k) mod 1200] and rows 2280 + (k-1) 12 + j = tw[10 j k] for k = 1..9,
+ *           s < 120, j < 12: the same entries in the order the lanes of transform passes 1 and 2 read them
  *   mel_w   [n_mel_w <= 1200] float32 non-zero weights of the 64 (contiguous, triangular) mel filters, filter
  *           after filter; the filters are cut into n_chunks (<= 224) pieces of a few bins for load balance:
  *           chunk_mel[i] = filter index (non-decreasing, every filter 0..63 present), chunk_start[i] = first FFT bin, chunk_len[i], chunk_off[i] = offset in mel_w
