@@ -30,6 +30,8 @@ SIGNATURES = {
     "adyolo_wino_pack_many": (I, [P, I, I, I, P]),
     "adyolo_wino_tiles": (I, [I] * 3),
     "adyolo_wino_fwd": (I, [P] * 13 + [I] * 7 + [P]),
+    "adyolo_wino_pack_w_b3": (I, [P, P, P, I, I, I, P]),
+    "adyolo_wino_fwd_b3": (I, [P] * 13 + [I] * 7 + [P]),
     "adyolo_wino_wgrad_slabs": (I, [I] * 5),
     "adyolo_wino_wgrad": (I, [P] * 7 + [I] * 6 + [P]),
     "adyolo_conv3x3_wgrad_slabs": (I, [I] * 5),

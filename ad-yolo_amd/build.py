@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libadyolo_hip.so")
-SOURCES = ["conv.hip", "wino.hip", "gemm.hip", "norm.hip", "seq.hip", "loss.hip", "losses.hip", "features.hip", "features_mic.hip", "conformer.hip", "attention.hip", "aug.hip", "optim.hip"]
+SOURCES = ["conv.hip", "wino.hip", "wino_b3.hip", "gemm.hip", "norm.hip", "seq.hip", "loss.hip", "losses.hip", "features.hip", "features_mic.hip", "conformer.hip", "attention.hip", "aug.hip", "optim.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
@@ -29,7 +29,7 @@ def build(force=False, verbose=True):
     hipcc = _hipcc()
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    common = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "fft1200.hpp"), os.path.join(HERE, "..", "include", "adyolo_hip.h")]
+    common = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join(HERE, "..", "include", "adyolo_hip.h")]
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

@@ -15,33 +15,10 @@
 // would buy nothing), loaded one 8-channel group ahead.  Blocks are dealt to XCDs so that an XCD keeps one output-
 // channel slice of U in its L2.  Epilogue: the nu-sum of A^T . A is done in registers, the xi-sum through LDS, then
 // bias / masked addend / ReLU / per-patch BatchNorm sums as in conv.hip, stored as float4 along channels.
-#include "common.hpp"
+#include "wino_common.hpp"
 
 namespace adyolo {
 
-constexpr int WKC = 32;                    // input channels per chunk
-constexpr int WAS = 36;                    // floats per staged pixel (144 B)
-constexpr int WHALF = 10;                  // slots per (row, parity) half row (9 used)
-constexpr int WPATCH = 10 * 2 * WHALF * WAS;   // floats per staged patch (28.8 KB)
-
-// ONE = the whole Cin fits one chunk (Cin == 32: stage 1): a single patch buffer, 44 KB of LDS and <= 168 VGPRs, so THREE
-// workgroups per CU cover each other's prologue / epilogue (one 32-channel chunk is only 16 steps of matrix work)
-template <int NT, bool ONE>
-struct WinoCfg {
-    static constexpr int CB = 32 * NT;
-    static constexpr int CBP = CB + 8;                       // epilogue exchange row (conflict-free b32 writes)
-    static constexpr int PBUF = 8 * 32 * CBP;                // [wave][b][tile][CBP]
-    static constexpr int NBUF = ONE ? 1 : 2;
-    static constexpr int LDS_FLOATS = (NBUF * WPATCH > PBUF) ? NBUF * WPATCH : PBUF;
-    static constexpr int WG_PER_CU = (ONE && NT == 1) ? 3 : 2;
-};
-constexpr int WMAXC = 512;                 // largest Cin of the Winograd forward kernel (affine table in LDS)
-
-__device__ __forceinline__ float4 f4_fma(float4 a, float s, float4 b) {      // b + s * a
-    return make_float4(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z), fmaf(s, a.w, b.w));
-}
-__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 f4_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
 template <int NT, bool ONE>
 __global__ __launch_bounds__(256, (WinoCfg<NT, ONE>::WG_PER_CU)) void wino_fwd_kernel(
@@ -274,110 +251,8 @@ __global__ __launch_bounds__(256, (WinoCfg<NT, ONE>::WG_PER_CU)) void wino_fwd_k
         __syncthreads();
     }
 
-    // ---- output transform.  nu-sum in registers: P[b] = sum_nu A^T[b][nu] M[w][nu];  xi-sum through LDS
-    float *Pb = lds;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mfma_row(r, lane);
-            const float p0 = acc[0][nt][r] + acc[1][nt][r] + acc[2][nt][r];
-            const float p1 = acc[1][nt][r] - acc[2][nt][r] - acc[3][nt][r];
-            Pb[((wave * 2 + 0) * 32 + m) * CBP + nt * 32 + li] = p0;
-            Pb[((wave * 2 + 1) * 32 + m) * CBP + nt * 32 + li] = p1;
-        }
-    __syncthreads();
-
-    constexpr int C4 = CB / 4;                  // float4 pieces per pixel
-    constexpr int MPT = 32 * C4 / 256;          // tiles per thread (1 or 2)
-    const int c4 = tid % C4, m0 = tid / C4;
-    const int co = co0 + c4 * 4;
-    float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = ssum;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), smean = bv, sinv = bv;
-    if (bias) bv = *reinterpret_cast<const float4 *>(bias + co);
-    if (stat_aux) {
-        smean = *reinterpret_cast<const float4 *>(stat_mean + co);
-        sinv = *reinterpret_cast<const float4 *>(stat_invstd + co);
-    }
-#pragma unroll
-    for (int it = 0; it < MPT; ++it) {
-        const int m = m0 + it * (256 / C4);
-        float4 P[4][2];
-#pragma unroll
-        for (int w = 0; w < 4; ++w)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-                P[w][b] = *reinterpret_cast<const float4 *>(&Pb[((w * 2 + b) * 32 + m) * CBP + c4 * 4]);
-        const int mr = m >> 3, mc = m & 7;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                float4 v = a == 0 ? f4_add(f4_add(P[0][b], P[1][b]), P[2][b]) : f4_sub(f4_sub(P[1][b], P[2][b]), P[3][b]);
-                const int gy = ty0 + 2 * mr + a, gx = tx0 + 2 * mc + b;
-                if (gy < H && gx < W) {
-                    const size_t o = (((size_t)n * H + gy) * W + gx) * Cout + co;
-                    v = f4_add(v, bv);
-                    if (addend) {
-                        float4 ad = *reinterpret_cast<const float4 *>(addend + o);
-                        if (addend_mask) {
-                            bool kx, ky, kz, kw;
-                            if (mask_bits & 1) {
-                                mask_bits4(reinterpret_cast<const unsigned long long *>(addend_mask), o >> 2, kx, ky, kz, kw);
-                            } else {
-                                const float4 mk = *reinterpret_cast<const float4 *>(addend_mask + o);
-                                kx = mk.x > 0.f; ky = mk.y > 0.f; kz = mk.z > 0.f; kw = mk.w > 0.f;
-                            }
-                            ad = make_float4(kx ? ad.x : 0.f, ky ? ad.y : 0.f, kz ? ad.z : 0.f, kw ? ad.w : 0.f);
-                        }
-                        v = f4_add(v, ad);
-                    }
-                    if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-                    *reinterpret_cast<float4 *>(y + o) = v;      // (non-temporal loads/stores here: measured 1 % slower)
-                    if (stats) {
-                        if (stat_mask) {        // statistics of v * (mask > 0): the SE / BN2 backward sums of the block below
-                            bool kx, ky, kz, kw;
-                            if (mask_bits & 2) {
-                                mask_bits4(reinterpret_cast<const unsigned long long *>(stat_mask), o >> 2, kx, ky, kz, kw);
-                            } else {
-                                const float4 mk = *reinterpret_cast<const float4 *>(stat_mask + o);
-                                kx = mk.x > 0.f; ky = mk.y > 0.f; kz = mk.z > 0.f; kw = mk.w > 0.f;
-                            }
-                            v = make_float4(kx ? v.x : 0.f, ky ? v.y : 0.f, kz ? v.z : 0.f, kw ? v.w : 0.f);
-                        }
-                        ssum = f4_add(ssum, v);
-                        if (stat_aux) {
-                            const float4 ax = *reinterpret_cast<const float4 *>(stat_aux + o);
-                            ssq.x += v.x * (ax.x - smean.x) * sinv.x;
-                            ssq.y += v.y * (ax.y - smean.y) * sinv.y;
-                            ssq.z += v.z * (ax.z - smean.z) * sinv.z;
-                            ssq.w += v.w * (ax.w - smean.w) * sinv.w;
-                        } else {
-                            ssq.x += v.x * v.x;
-                            ssq.y += v.y * v.y;
-                            ssq.z += v.z * v.z;
-                            ssq.w += v.w * v.w;
-                        }
-                    }
-                }
-            }
-    }
-    if (stats) {
-        // per-patch, per-channel sums of the stored output, layout [2][patches][Cout] (see conv.hip)
-        __syncthreads();
-        constexpr int G = 256 / C4;             // thread groups sharing a channel piece
-        float *red = lds;                       // [2][G][CB]
-        *reinterpret_cast<float4 *>(&red[(0 * G + m0) * CB + c4 * 4]) = ssum;
-        *reinterpret_cast<float4 *>(&red[(1 * G + m0) * CB + c4 * 4]) = ssq;
-        __syncthreads();
-        if (tid < CB * 2) {
-            const int c = tid % CB, which = tid / CB;
-            float s = 0.f;
-#pragma unroll 8
-            for (int gI = 0; gI < G; ++gI) s += red[(which * G + gI) * CB + c];
-            stats[(size_t)which * nsp * Cout + (size_t)sp * Cout + co0 + c] = s;
-        }
-    }
+    wino_epilogue<NT, ONE>(acc, lds, tid, lane, wave, li, bias, addend, addend_mask, y, stats, stat_aux, stat_mean, stat_invstd,
+                           stat_mask, n, H, W, Cout, co0, ty0, tx0, nsp, sp, relu, mask_bits);
 }
 
 // U = G g G^T in fragment order [16 pos][Cout/32][Cin/8][64 lanes][4]: lane (n, h) element j = U_pos[cin 8g+4h+j][cout 32cb+n].
@@ -433,18 +308,25 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float *__restrict_
 }
 
 // Every 3x3 filter of a model in ONE launch (64 pack launches per train step of SE-ResNet34 otherwise: the packed filters
-// change once per optimizer step, not per layer call).  table: [n][6] int64 = {w, u_fwd, u_dgrad (or 0), Cout, Cin_real, Cin};
+// change once per optimizer step, not per layer call).  table: [n][8] int64 = {w, u_fwd, u_dgrad (or 0), Cout, Cin_real, Cin,
+// fwd_b3, dgrad_b3}; a non-zero *_b3 flag selects the pre-split bf16x3 form of wino_b3.hip for that direction.
 // grid (ceil(largest total / 256), n)
 __global__ __launch_bounds__(256) void wino_pack_many_kernel(const long long *__restrict__ table) {
-    const long long *d = table + 6 * blockIdx.y;
+    const long long *d = table + 8 * blockIdx.y;
     const float *w = reinterpret_cast<const float *>(d[0]);
     float *uf = reinterpret_cast<float *>(d[1]), *ud = reinterpret_cast<float *>(d[2]);
     const int Cout = (int)d[3], Cin_real = (int)d[4], Cin = (int)d[5];
-    const long total = (long)(Cout / 32) * (Cin / 8) * 256;       // same count for both packings
+    const long total = (long)(Cout / 32) * (Cin / 8) * 256;       // = Cout * Cin: one element per thread in every form
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    if (uf) wino_pack_one(w, uf, Cin_real, Cin, Cout, 0, idx, total);
-    if (ud) wino_pack_one(w, ud, Cin_real, Cout, Cin, 1, idx, total);
+    if (uf) {
+        if (d[6]) wino_pack_b3_one(w, reinterpret_cast<unsigned short *>(uf), Cin_real, Cin, Cout, 0, idx);
+        else wino_pack_one(w, uf, Cin_real, Cin, Cout, 0, idx, total);
+    }
+    if (ud) {
+        if (d[7]) wino_pack_b3_one(w, reinterpret_cast<unsigned short *>(ud), Cin_real, Cout, Cin, 1, idx);
+        else wino_pack_one(w, ud, Cin_real, Cout, Cin, 1, idx, total);
+    }
 }
 
 }  // namespace adyolo

@@ -1,0 +1,208 @@
+// Shared by the Winograd forward kernels (wino.hip: exact-fp32 MFMA; wino_b3.hip: three-term bf16 operands on the bf16 MFMA):
+// patch geometry constants, the per-template configuration and the epilogue (output transform, bias / masked addend / ReLU,
+// per-patch BatchNorm sums).
+#pragma once
+#include "common.hpp"
+
+namespace adyolo {
+
+constexpr int WKC = 32;                    // input channels per chunk
+constexpr int WAS = 36;                    // floats per staged pixel (144 B)
+constexpr int WHALF = 10;                  // slots per (row, parity) half row (9 used)
+constexpr int WPATCH = 10 * 2 * WHALF * WAS;   // floats per staged patch (28.8 KB)
+
+// ONE = the whole Cin fits one chunk (Cin == 32: stage 1): a single patch buffer, 44 KB of LDS and <= 168 VGPRs, so THREE
+// workgroups per CU cover each other's prologue / epilogue (one 32-channel chunk is only 16 steps of matrix work)
+template <int NT, bool ONE>
+struct WinoCfg {
+    static constexpr int CB = 32 * NT;
+    static constexpr int CBP = CB + 8;                       // epilogue exchange row (conflict-free b32 writes)
+    static constexpr int PBUF = 8 * 32 * CBP;                // [wave][b][tile][CBP]
+    static constexpr int NBUF = ONE ? 1 : 2;
+    static constexpr int LDS_FLOATS = (NBUF * WPATCH > PBUF) ? NBUF * WPATCH : PBUF;
+    static constexpr int WG_PER_CU = (ONE && NT == 1) ? 3 : 2;
+};
+constexpr int WMAXC = 512;                 // largest Cin of the Winograd forward kernel (affine table in LDS)
+
+__device__ __forceinline__ float4 f4_fma(float4 a, float s, float4 b) {      // b + s * a
+    return make_float4(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z), fmaf(s, a.w, b.w));
+}
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+// Epilogue of a forward workgroup: acc[v][nt] = M[pos = 4 wave + v][32 tiles][32 nt + cout] in MFMA accumulator layout.
+// The nu-sum of A^T . A is done in registers, the xi-sum through LDS (which the caller has finished reading), then
+// bias / masked addend / ReLU / per-patch BatchNorm sums as in conv.hip, stored as float4 along channels.
+template <int NT, bool ONE>
+__device__ __forceinline__ void wino_epilogue(f32x16 (&acc)[4][NT], float *lds, int tid, int lane, int wave, int li,
+                                              const float *__restrict__ bias, const float *__restrict__ addend,
+                                              const float *__restrict__ addend_mask, float *__restrict__ y,
+                                              float *__restrict__ stats, const float *__restrict__ stat_aux,
+                                              const float *__restrict__ stat_mean, const float *__restrict__ stat_invstd,
+                                              const float *__restrict__ stat_mask, int n, int H, int W, int Cout, int co0,
+                                              int ty0, int tx0, int nsp, int sp, int relu, int mask_bits) {
+    using Cfg = WinoCfg<NT, ONE>;
+    constexpr int CB = Cfg::CB, CBP = Cfg::CBP;
+    // ---- output transform.  nu-sum in registers: P[b] = sum_nu A^T[b][nu] M[w][nu];  xi-sum through LDS
+    float *Pb = lds;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mfma_row(r, lane);
+            const float p0 = acc[0][nt][r] + acc[1][nt][r] + acc[2][nt][r];
+            const float p1 = acc[1][nt][r] - acc[2][nt][r] - acc[3][nt][r];
+            Pb[((wave * 2 + 0) * 32 + m) * CBP + nt * 32 + li] = p0;
+            Pb[((wave * 2 + 1) * 32 + m) * CBP + nt * 32 + li] = p1;
+        }
+    __syncthreads();
+
+    constexpr int C4 = CB / 4;                  // float4 pieces per pixel
+    constexpr int MPT = 32 * C4 / 256;          // tiles per thread (1 or 2)
+    const int c4 = tid % C4, m0 = tid / C4;
+    const int co = co0 + c4 * 4;
+    float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = ssum;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), smean = bv, sinv = bv;
+    if (bias) bv = *reinterpret_cast<const float4 *>(bias + co);
+    if (stat_aux) {
+        smean = *reinterpret_cast<const float4 *>(stat_mean + co);
+        sinv = *reinterpret_cast<const float4 *>(stat_invstd + co);
+    }
+#pragma unroll
+    for (int it = 0; it < MPT; ++it) {
+        const int m = m0 + it * (256 / C4);
+        float4 P[4][2];
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                P[w][b] = *reinterpret_cast<const float4 *>(&Pb[((w * 2 + b) * 32 + m) * CBP + c4 * 4]);
+        const int mr = m >> 3, mc = m & 7;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float4 v = a == 0 ? f4_add(f4_add(P[0][b], P[1][b]), P[2][b]) : f4_sub(f4_sub(P[1][b], P[2][b]), P[3][b]);
+                const int gy = ty0 + 2 * mr + a, gx = tx0 + 2 * mc + b;
+                if (gy < H && gx < W) {
+                    const size_t o = (((size_t)n * H + gy) * W + gx) * Cout + co;
+                    v = f4_add(v, bv);
+                    if (addend) {
+                        float4 ad = *reinterpret_cast<const float4 *>(addend + o);
+                        if (addend_mask) {
+                            bool kx, ky, kz, kw;
+                            if (mask_bits & 1) {
+                                mask_bits4(reinterpret_cast<const unsigned long long *>(addend_mask), o >> 2, kx, ky, kz, kw);
+                            } else {
+                                const float4 mk = *reinterpret_cast<const float4 *>(addend_mask + o);
+                                kx = mk.x > 0.f; ky = mk.y > 0.f; kz = mk.z > 0.f; kw = mk.w > 0.f;
+                            }
+                            ad = make_float4(kx ? ad.x : 0.f, ky ? ad.y : 0.f, kz ? ad.z : 0.f, kw ? ad.w : 0.f);
+                        }
+                        v = f4_add(v, ad);
+                    }
+                    if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                    *reinterpret_cast<float4 *>(y + o) = v;      // (non-temporal loads/stores here: measured 1 % slower)
+                    if (stats) {
+                        if (stat_mask) {        // statistics of v * (mask > 0): the SE / BN2 backward sums of the block below
+                            bool kx, ky, kz, kw;
+                            if (mask_bits & 2) {
+                                mask_bits4(reinterpret_cast<const unsigned long long *>(stat_mask), o >> 2, kx, ky, kz, kw);
+                            } else {
+                                const float4 mk = *reinterpret_cast<const float4 *>(stat_mask + o);
+                                kx = mk.x > 0.f; ky = mk.y > 0.f; kz = mk.z > 0.f; kw = mk.w > 0.f;
+                            }
+                            v = make_float4(kx ? v.x : 0.f, ky ? v.y : 0.f, kz ? v.z : 0.f, kw ? v.w : 0.f);
+                        }
+                        ssum = f4_add(ssum, v);
+                        if (stat_aux) {
+                            const float4 ax = *reinterpret_cast<const float4 *>(stat_aux + o);
+                            ssq.x += v.x * (ax.x - smean.x) * sinv.x;
+                            ssq.y += v.y * (ax.y - smean.y) * sinv.y;
+                            ssq.z += v.z * (ax.z - smean.z) * sinv.z;
+                            ssq.w += v.w * (ax.w - smean.w) * sinv.w;
+                        } else {
+                            ssq.x += v.x * v.x;
+                            ssq.y += v.y * v.y;
+                            ssq.z += v.z * v.z;
+                            ssq.w += v.w * v.w;
+                        }
+                    }
+                }
+            }
+    }
+    if (stats) {
+        // per-patch, per-channel sums of the stored output, layout [2][patches][Cout] (see conv.hip)
+        __syncthreads();
+        constexpr int G = 256 / C4;             // thread groups sharing a channel piece
+        float *red = lds;                       // [2][G][CB]
+        *reinterpret_cast<float4 *>(&red[(0 * G + m0) * CB + c4 * 4]) = ssum;
+        *reinterpret_cast<float4 *>(&red[(1 * G + m0) * CB + c4 * 4]) = ssq;
+        __syncthreads();
+        if (tid < CB * 2) {
+            const int c = tid % CB, which = tid / CB;
+            float s = 0.f;
+#pragma unroll 8
+            for (int gI = 0; gI < G; ++gI) s += red[(which * G + gI) * CB + c];
+            stats[(size_t)which * nsp * Cout + (size_t)sp * Cout + co0 + c] = s;
+        }
+    }
+}
+
+// U = G g G^T, split into three bf16 terms, in fragment order [16 pos][Nn/32][K/16][3][64 lanes][8]: lane (n, h) k slot i =
+// U_pos[cin 16 G + 8 (i >> 2) + 4 h + (i & 3)][cout 32 nb + n].  mode 0: forward filter, mode 1: data-gradient filter (see
+// wino_pack_one in wino.hip; same arithmetic for U)
+__device__ __forceinline__ void wino_pack_b3_one(const float *__restrict__ w, unsigned short *__restrict__ u, int Cin_real,
+                                                 int K, int Nn, int mode, long idx) {
+    const int i = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    const long rest = idx >> 9;
+    const int nG = K / 16;
+    const int G = (int)(rest % nG), nb = (int)(rest / nG);
+    const int k = G * 16 + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3), nn = nb * 32 + (lane & 31);
+    float f[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            float v = 0.f;
+            if (mode == 0) {
+                if (k < Cin_real) v = w[((size_t)nn * Cin_real + k) * 9 + a * 3 + b];
+            } else {
+                if (nn < Cin_real) v = w[((size_t)k * Cin_real + nn) * 9 + (2 - a) * 3 + (2 - b)];
+            }
+            f[a][b] = v;
+        }
+    float tt[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        tt[0][b] = f[0][b];
+        tt[1][b] = 0.5f * (f[0][b] + f[1][b] + f[2][b]);
+        tt[2][b] = 0.5f * (f[0][b] - f[1][b] + f[2][b]);
+        tt[3][b] = f[2][b];
+    }
+    const size_t pos_stride = (size_t)(Nn / 32) * nG * 3 * 512;           // bf16 elements per transform position
+    const size_t base = (((size_t)nb * nG + G) * 3) * 512 + (size_t)lane * 8 + i;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float uu[4];
+        uu[0] = tt[a][0];
+        uu[1] = 0.5f * (tt[a][0] + tt[a][1] + tt[a][2]);
+        uu[2] = 0.5f * (tt[a][0] - tt[a][1] + tt[a][2]);
+        uu[3] = tt[a][2];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const __bf16 h = (__bf16)uu[b];
+            const float r1 = uu[b] - (float)h;
+            const __bf16 m = (__bf16)r1;
+            const float r2 = r1 - (float)m;
+            const __bf16 l = (__bf16)r2;
+            const size_t o = (size_t)(a * 4 + b) * pos_stride + base;
+            u[o] = __builtin_bit_cast(unsigned short, h);
+            u[o + 512] = __builtin_bit_cast(unsigned short, m);
+            u[o + 1024] = __builtin_bit_cast(unsigned short, l);
+        }
+    }
+}
+
+
+}  // namespace adyolo

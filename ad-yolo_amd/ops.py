@@ -98,19 +98,44 @@ def conv_algo():
     return a
 
 
-def pack_w3x3(w, cin_pad, want_dgrad=True, algo=None):
+def math_mode():
+    """'f32' (default: every matrix product on the exact-fp32 MFMA) or 'bf16x3' (OPT-IN, ADYOLO_MATH=bf16x3): the Winograd
+    forward / data-gradient GEMMs with more than one 32-channel chunk run on the bf16 MFMA with every fp32 operand split
+    exactly into three bf16 terms and six products per multiply (csrc/wino_b3.hip; fp32 accumulation, error of the order
+    of the fp32 MFMA's own rounding).  Read per call of ``pack_w3x3`` / ``WinoPackSet.refresh``."""
+    m = os.environ.get("ADYOLO_MATH", "f32").lower()
+    if m not in ("f32", "bf16x3"):
+        raise _lib.AdyoloHipError("ADYOLO_MATH must be 'f32' or 'bf16x3' (got %r)" % m)
+    return m
+
+
+def _b3_eligible(k_gemm, math):
+    """the bf16x3 kernel is the multi-chunk form: one-chunk (32-channel) contractions stay on the fp32 kernel"""
+    return math == "bf16x3" and k_gemm > 32
+
+
+def pack_w3x3(w, cin_pad, want_dgrad=True, algo=None, math=None):
     """w [Cout][Cin][3][3] -> (fwd pack, dgrad pack or None).
 
     direct:   wpk_fwd [Cout][9][cin_pad], wpk_dgrad [cin_pad][9][Cout]
     winograd: u_fwd [16][Cout/32][cin_pad/8][256], u_dgrad [16][cin_pad/32][Cout/8][256]  (needs both channel
-              counts to be multiples of 32; the 8-channel stem stays direct).  ``conv3x3`` tells them apart by rank."""
+              counts to be multiples of 32; the 8-channel stem stays direct).  ``conv3x3`` tells them apart by rank.
+    winograd, math 'bf16x3': a direction whose contraction has more than 32 channels is packed pre-split,
+              [16][Cout/32][cin_pad/16][768] (resp. [16][cin_pad/32][Cout/16][768]); ``conv3x3`` tells by the last axis."""
     _chk(w)
     cout, cin = w.shape[0], w.shape[1]
     algo = algo or conv_algo()
     if algo == "winograd" and cin_pad % 32 == 0 and cout % 32 == 0:
-        uf = _new(w, 16, cout // 32, cin_pad // 8, 256)
-        ud = _new(w, 16, cin_pad // 32, cout // 8, 256) if want_dgrad else None
-        _c("adyolo_wino_pack_w", _p(w), _p(uf), _p(ud), cout, cin, cin_pad, _stream())
+        math = math or math_mode()
+        fb, db = _b3_eligible(cin_pad, math), _b3_eligible(cout, math) and want_dgrad
+        uf = _new(w, 16, cout // 32, cin_pad // 16, 768) if fb else _new(w, 16, cout // 32, cin_pad // 8, 256)
+        ud = None
+        if want_dgrad:
+            ud = _new(w, 16, cin_pad // 32, cout // 16, 768) if db else _new(w, 16, cin_pad // 32, cout // 8, 256)
+        if fb or db:
+            _c("adyolo_wino_pack_w_b3", _p(w), _p(uf if fb else None), _p(ud if db else None), cout, cin, cin_pad, _stream())
+        if not fb or (want_dgrad and not db):
+            _c("adyolo_wino_pack_w", _p(w), _p(None if fb else uf), _p(None if db else ud), cout, cin, cin_pad, _stream())
         return uf, ud
     wf = _new(w, cout, 9, cin_pad)
     wd = _new(w, cin_pad, 9, cout) if want_dgrad else None
@@ -128,7 +153,8 @@ class WinoPackSet:
         self.key = None
 
     def refresh(self, weights):
-        key = tuple(w.data_ptr() for w in weights)
+        math = math_mode()
+        key = (math,) + tuple(w.data_ptr() for w in weights)
         if key != self.key:
             dev = weights[0].device
             self.packs, rows = [], []
@@ -137,9 +163,11 @@ class WinoPackSet:
                 cout, cin = w.shape[0], w.shape[1]
                 if cout % 32 or cin % 32:
                     raise _lib.AdyoloHipError("WinoPackSet: channel counts must be multiples of 32")
-                uf, ud = _new(w, 16, cout // 32, cin // 8, 256), _new(w, 16, cin // 32, cout // 8, 256)
+                fb, db = _b3_eligible(cin, math), _b3_eligible(cout, math)
+                uf = _new(w, 16, cout // 32, cin // 16, 768) if fb else _new(w, 16, cout // 32, cin // 8, 256)
+                ud = _new(w, 16, cin // 32, cout // 16, 768) if db else _new(w, 16, cin // 32, cout // 8, 256)
                 self.packs.append((uf, ud))
-                rows.append([w.data_ptr(), uf.data_ptr(), ud.data_ptr(), cout, cin, cin])
+                rows.append([w.data_ptr(), uf.data_ptr(), ud.data_ptr(), cout, cin, cin, int(fb), int(db)])
             self.table = torch.tensor(rows, dtype=torch.int64, device=dev)
             self.max_cout = max(w.shape[0] for w in weights)
             self.max_cin = max(w.shape[1] for w in weights)
@@ -176,7 +204,8 @@ def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, 
         stats = _new(x, 2, tiles, cout)
     sc, sh = in_affine if in_affine is not None else (None, None)
     sa, sm, si = stat_bn if stat_bn is not None else (None, None, None)
-    _c("adyolo_wino_fwd" if wino else "adyolo_conv3x3_fwd", _p(x), _p(wpk), _p(bias), _p(addend), _p(addend_mask),
+    fn = ("adyolo_wino_fwd_b3" if wpk.shape[-1] == 768 else "adyolo_wino_fwd") if wino else "adyolo_conv3x3_fwd"
+    _c(fn, _p(x), _p(wpk), _p(bias), _p(addend), _p(addend_mask),
        _p(sc), _p(sh), _p(y), _p(stats), _p(sa), _p(sm), _p(si), _p(stat_mask), n, h, w, cin, cout, int(relu), mbits,
        _stream())
     return (y, stats) if want_stats else y

@@ -246,6 +246,10 @@ EXTRA_CONFIGS = {
                                            "reference (parity unpinned)"),
     "conformer_bs32x20s": dict(kind="train", encoder="resnet-conformer", batch=32, seconds=20, steps=4,
                                ref="BASELINE.json configs[3]: resnet-conformer + adyolo, bs = 32 x 20 s"),
+    "headline_b64x60s_math_bf16x3": dict(kind="train", encoder="se-resnet34", batch=64, seconds=60, steps=4, math="bf16x3",
+                                         ref="the headline workload with the OPT-IN math mode ADYOLO_MATH=bf16x3: multi-chunk Winograd "
+                                             "forward / data-gradient GEMMs on the bf16 MFMA with fp32 operands split exactly into three "
+                                             "bf16 terms (six products, fp32 accumulation; csrc/wino_b3.hip); NOT the headline's arithmetic"),
 }
 
 
@@ -260,6 +264,23 @@ def _small_shape_kernel_ms(name):
 
 
 def run_extra_config(name, torch, modes="both"):
+    cfg = EXTRA_CONFIGS[name]
+    if cfg.get("math"):                     # opt-in math mode for this configuration only
+        prev = os.environ.get("ADYOLO_MATH")
+        os.environ["ADYOLO_MATH"] = cfg["math"]
+        try:
+            ent = _run_extra_config(name, cfg, torch, modes)
+        finally:
+            if prev is None:
+                os.environ.pop("ADYOLO_MATH", None)
+            else:
+                os.environ["ADYOLO_MATH"] = prev
+        ent["math"] = cfg["math"]
+        return ent
+    return _run_extra_config(name, cfg, torch, modes)
+
+
+def _run_extra_config(name, cfg, torch, modes):
     import adyolo_amd  # noqa: F401
     from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
     from adyolo_amd.features import FeatureExtractor
@@ -267,7 +288,6 @@ def run_extra_config(name, torch, modes="both"):
     from adyolo_amd.train import TrainStep
     from adyolo_amd.graph import ForwardGraphs
     from adyolo_amd.postprocess import LabelPostProcessor
-    cfg = EXTRA_CONFIGS[name]
     device = "cuda:%d" % torch.cuda.current_device()
     B, n = cfg["batch"], 24000 * cfg["seconds"]
     T = n // 600
