@@ -110,8 +110,10 @@ def math_mode():
 
 
 def _b3_eligible(k_gemm, math):
-    """the bf16x3 kernel is the multi-chunk form: one-chunk (32-channel) contractions stay on the fp32 kernel"""
-    return math == "bf16x3" and k_gemm > 32
+    """the bf16x3 kernel takes the multi-chunk contractions; one-chunk (32-channel) ones stay on the fp32 kernel, whose
+    single-buffer form keeps three workgroups per CU (ADYOLO_B3_MIN_K=32 sends them over as well: 3-40 % faster launch by
+    launch in isolation, but the whole step goes 143.3 -> 145.9 ms; DESIGN "bf16x3, round 3")"""
+    return math == "bf16x3" and k_gemm >= int(os.environ.get("ADYOLO_B3_MIN_K", "64"))
 
 
 def pack_w3x3(w, cin_pad, want_dgrad=True, algo=None, math=None):

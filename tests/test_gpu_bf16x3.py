@@ -42,8 +42,10 @@ def _err(got, ref64):
     (3, 7, 50, 64, 96, False, True, True),        # 3 channel blocks of 32 (NT = 1 kernel), odd sizes
     (5, 8, 16, 512, 64, True, False, False),      # deepest reduction
     (2, 13, 37, 96, 64, False, True, False),      # three chunks, ragged both ways
+    (2, 16, 64, 32, 32, False, False, True),      # stage 1: one chunk, one channel tile
+    (7, 24, 16, 32, 128, False, False, False),    # one chunk, 21 patches on two channel blocks
 ])
-def test_b3_forward_matches_float64_like_the_fp32_kernel(ops, n, h, w, cin, cout, relu, bias, addend):
+def test_b3_forward_matches_float64_like_the_fp32_kernel(ops, monkeypatch, n, h, w, cin, cout, relu, bias, addend):
     g = torch.Generator().manual_seed(n * 1000 + h * 10 + cin)
     x = torch.randn(n, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
@@ -55,6 +57,8 @@ def test_b3_forward_matches_float64_like_the_fp32_kernel(ops, n, h, w, cin, cout
     if relu:
         ref = F.relu(ref)
     errs = {}
+    if cin == 32:
+        monkeypatch.setenv("ADYOLO_B3_MIN_K", "32")           # one-chunk contractions: not the default, still a supported shape
     for math in ("f32", "bf16x3"):
         wpk, _ = ops.pack_w3x3(dev(wt), cin, want_dgrad=False, algo="winograd", math=math)
         assert (wpk.shape[-1] == 768) == (math == "bf16x3")
@@ -75,7 +79,7 @@ def test_b3_data_gradient(ops, n, h, w, cin, cout):
     F.conv2d(x, wt.double(), None, padding=1).backward(dy.double())
     uf, ud = ops.pack_w3x3(dev(wt), cin, want_dgrad=True, algo="winograd", math="bf16x3")
     assert ud.shape[-1] == 768                       # the data-gradient contracts over Cout >= 64
-    assert (uf.shape[-1] == 768) == (cin > 32)       # one-chunk forward stays on the fp32 kernel
+    assert (uf.shape[-1] == 768) == (cin > 32)       # one-chunk forward stays on the fp32 kernel by default
     dx = ops.conv3x3(dev(nhwc(dy)), ud, cin)
     torch.cuda.synchronize()
     assert _err(nchw(dx), x.grad) <= 2e-5

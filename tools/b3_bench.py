@@ -10,7 +10,7 @@ import adyolo_amd  # noqa: E402,F401
 from adyolo_amd import ops  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-SHAPES = [("stage2 64->64", 1200, 32, 64, 64), ("stage3 128->128", 600, 16, 128, 128), ("stage4 256->256", 600, 16, 256, 256),
+SHAPES = [("stage1 32->32", 2400, 64, 32, 32), ("stage2.0 32->64", 1200, 32, 32, 64), ("stage2 64->64", 1200, 32, 64, 64), ("stage3 128->128", 600, 16, 128, 128), ("stage4 256->256", 600, 16, 256, 256),
           ("stage3.0 64->128", 600, 16, 64, 128), ("stage4.0 128->256", 600, 16, 128, 256)]
 
 
