@@ -18,6 +18,12 @@ import torch
 import torch.distributed as dist
 
 
+def _params_changed():
+    """parameters / buffers were written in place by a collective: evaluation-mode caches keyed on ops.PARAMS_EPOCH expire"""
+    from . import ops
+    ops.params_changed()
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract). Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -68,6 +74,7 @@ class FlatParameters:
             dist.broadcast(self.flat, src, group=group)
             for b in self.buffers:
                 dist.broadcast(b, src, group=group)
+            _params_changed()
 
     def average_buffers(self, group=None):
         """BatchNorm running statistics are per-rank under DDP-conventional semantics; average them over the ranks (e.g.
@@ -77,6 +84,7 @@ class FlatParameters:
             for b in self.buffers:
                 dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
                 b.div_(w)
+            _params_changed()
 
     def zero_grad(self):
         self.flat_grad.zero_()

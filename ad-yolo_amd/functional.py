@@ -165,10 +165,27 @@ class _BNState:
         if training:
             ssum, mean, invstd = ops.bn_stats(x, m.running_mean, m.running_var, m.momentum, m.eps)
             _bump_counter(m.num_batches_tracked)
+            ops.params_changed()                 # the running buffers moved (kernels write them without a version bump)
         else:
             ssum = None
             mean, invstd = ops.bn_eval_stats(m.running_mean, m.running_var, m.eps)
         return ssum, mean, invstd
+
+    def eval_affine(self, gamma, beta):
+        """Evaluation mode: (mean, invstd, scale, shift) from the running buffers, computed once and kept on the module until a
+        parameter or buffer changes (72 four-microsecond launches per SE-ResNet34 forward otherwise: 9 % of a one-clip pass).
+        Validity: ``ops.PARAMS_EPOCH`` (bumped by every kernel that writes parameters or buffers in place: Adam, the
+        training-mode statistics) and the tensors' own version counters (``load_state_dict`` / ``copy_``)."""
+        m = self.mod
+        key = (ops.PARAMS_EPOCH[0], m.running_mean.data_ptr(), m.running_mean._version, m.running_var._version,
+               gamma.data_ptr(), gamma._version, beta.data_ptr(), beta._version)
+        c = m.__dict__.get("_adyolo_eval_affine")
+        if c is None or c[0] != key:
+            mean, invstd = ops.bn_eval_stats(m.running_mean, m.running_var, m.eps)
+            scale, shift = ops.bn_scale_shift(gamma, beta, mean, invstd)
+            c = (key, mean, invstd, scale, shift)
+            m.__dict__["_adyolo_eval_affine"] = c
+        return c[1:]
 
     def stats_tiles(self, tile_stats, x, update=True, affine=None):
         """Training-mode statistics from the per-patch sums a conv epilogue produced (no extra read pass).
@@ -178,6 +195,7 @@ class _BNState:
         hw = x.numel() // (n * c)
         g, b = affine if affine is not None else (None, None)
         if update:
+            ops.params_changed()
             out = ops.bn_stats_tiles(tile_stats, n, hw, m.running_mean, m.running_var, m.momentum, m.eps, g, b)
             _bump_counter(m.num_batches_tracked)
             return out
@@ -198,8 +216,11 @@ class StemFn(torch.autograd.Function):
             _, mean, invstd, scale, shift = _BNState(bn).stats_tiles(st, a, affine=(gamma, beta))
         else:
             a = ops.conv3x3(x8, wpk, w.shape[0], bias=b, relu=True)
-            _, mean, invstd = _BNState(bn).stats(a, False)
-            scale, shift = ops.bn_scale_shift(gamma, beta, mean, invstd)
+            if training:
+                _, mean, invstd = _BNState(bn).stats(a, True)
+                scale, shift = ops.bn_scale_shift(gamma, beta, mean, invstd)
+            else:
+                mean, invstd, scale, shift = _BNState(bn).eval_affine(gamma, beta)
         ctx.holder = None
         if holder is not None:
             holder.affine = (scale, shift)
@@ -269,8 +290,11 @@ class SEBlockFn(torch.autograd.Function):
             _, mean1, invstd1, scale1, shift1 = _BNState(bn1).stats_tiles(st1, a, affine=(g1, b1))
         else:
             a = ops.conv3x3(p, wpk1, c, relu=True, in_affine=p_aff)
-            _, mean1, invstd1 = _BNState(bn1).stats(a, training)
-            scale1, shift1 = ops.bn_scale_shift(g1, b1, mean1, invstd1)
+            if training:
+                _, mean1, invstd1 = _BNState(bn1).stats(a, True)
+                scale1, shift1 = ops.bn_scale_shift(g1, b1, mean1, invstd1)
+            else:
+                mean1, invstd1, scale1, shift1 = _BNState(bn1).eval_affine(g1, b1)
         if FUSE_AFFINE:
             # BN1's affine is applied while conv2 stages its input: bn1(a) is never written to HBM
             src, aff = a, (scale1, shift1)
@@ -283,7 +307,7 @@ class SEBlockFn(torch.autograd.Function):
                 ssum2, mean2, invstd2, scale2, shift2 = _BNState(bn2).stats_tiles(st2, cc, affine=(g2, b2))
             else:
                 ssum2, _, _ = _BNState(bn2).stats_tiles(st2, cc, update=False)
-                _, mean2, invstd2 = _BNState(bn2).stats(cc, False)
+                mean2, invstd2, scale2, shift2 = _BNState(bn2).eval_affine(g2, b2)
         else:
             scale2 = None
             cc = ops.conv3x3(src, wpk2, c, in_affine=aff)
@@ -291,7 +315,7 @@ class SEBlockFn(torch.autograd.Function):
                 ssum2, mean2, invstd2 = _BNState(bn2).stats(cc, True)
             else:
                 ssum2, _, _ = ops.bn_stats(cc, None, None)
-                _, mean2, invstd2 = _BNState(bn2).stats(cc, False)
+                mean2, invstd2, scale2, shift2 = _BNState(bn2).eval_affine(g2, b2)
         if scale2 is None:
             scale2, shift2 = ops.bn_scale_shift(g2, b2, mean2, invstd2)
         pooled, hid, s = ops.se_fc_fwd(ssum2, scale2, shift2, fw1, fb1, fw2, fb2, h * w_)
@@ -299,8 +323,11 @@ class SEBlockFn(torch.autograd.Function):
         meand = invstdd = None
         if wd is not None:
             q = ops.gemm(p, wd, n * h * w_, c, cin, cin, cin).view(n, h, w_, c)
-            _, meand, invstdd = _BNState(bnd).stats(q, training)
-            scaled, shiftd = ops.bn_scale_shift(gd, bd, meand, invstdd)
+            if training:
+                _, meand, invstdd = _BNState(bnd).stats(q, True)
+                scaled, shiftd = ops.bn_scale_shift(gd, bd, meand, invstdd)
+            else:
+                meand, invstdd, scaled, shiftd = _BNState(bnd).eval_affine(gd, bd)
             r, raff = q, (scaled, shiftd)            # the downsample BatchNorm is applied while the tail reads q
         else:
             r, raff = p, p_aff
@@ -693,8 +720,11 @@ class BatchNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, bn, training, relu, residual=None):
-        _, mean, invstd = _BNState(bn).stats(x, training)
-        scale, shift = ops.bn_scale_shift(gamma, beta, mean, invstd)
+        if training:
+            _, mean, invstd = _BNState(bn).stats(x, True)
+            scale, shift = ops.bn_scale_shift(gamma, beta, mean, invstd)
+        else:
+            mean, invstd, scale, shift = _BNState(bn).eval_affine(gamma, beta)
         if residual is not None:
             n, c = x.shape[0], x.shape[-1]
             ones = torch.ones(n, c, dtype=torch.float32, device=x.device)

@@ -142,6 +142,7 @@ class ForwardGraphs:
         self.warm_calls = warm_calls
         self.entries, self.seen = {}, {}
         self.captures = self.replays = 0
+        self.epoch = ops.PARAMS_EPOCH[0]
 
     def _run(self, audio):
         out = self.model(self.features(audio, channels_last8=True), channels_last8=True)
@@ -154,6 +155,10 @@ class ForwardGraphs:
     def __call__(self, audio):
         if self.model.training:
             raise RuntimeError("ForwardGraphs records the evaluation forward: call model.eval() first")
+        if self.epoch != ops.PARAMS_EPOCH[0]:          # parameters / buffers were written since the graphs were recorded: the
+            self.entries.clear()                      # evaluation-mode BatchNorm affines inside them are stale -- record again
+            self.seen.clear()
+            self.epoch = ops.PARAMS_EPOCH[0]
         key = tuple(audio.shape)
         ent = self.entries.get(key)
         with torch.no_grad():

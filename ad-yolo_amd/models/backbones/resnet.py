@@ -199,7 +199,8 @@ class SEResnet34(nn.Module):
         blocks = [blk for li in range(1, 5) for blk in getattr(self, "layer%d" % li)]
         packs = None
         if ops.conv_algo() == "winograd":        # every block filter packed by ONE launch (64 otherwise)
-            packs = self._packs.refresh([w for blk in blocks for w in (blk.conv1.weight, blk.conv2.weight)])
+            packs = self._packs.refresh([w for blk in blocks for w in (blk.conv1.weight, blk.conv2.weight)],
+                                        frozen=not self.training)
         for bi, blk in enumerate(blocks):
             nxt = Fn.BlockLink()
             pk = (packs.get(2 * bi) + packs.get(2 * bi + 1)) if packs is not None else None

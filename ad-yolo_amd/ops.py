@@ -88,6 +88,16 @@ class ExactDP:
 EXACT = ExactDP()
 
 
+# Parameter / buffer epoch: bumped by everything that writes parameters or BatchNorm buffers IN PLACE through a kernel (no
+# torch version bump): the optimizer step, the training-mode BatchNorm statistics, the start-up broadcast.  Evaluation-mode
+# caches (BatchNorm affines, ``functional._BNState.eval_affine``; recorded forward graphs, ``graph.ForwardGraphs``) are keyed on it.
+PARAMS_EPOCH = [0]
+
+
+def params_changed():
+    PARAMS_EPOCH[0] += 1
+
+
 # ---------------------------------------------------------------------------------------------- conv
 def conv_algo():
     """'winograd' (default: F(2x2,3x3) on the fp32 MFMA, 2.25x fewer matrix FLOPs) or 'direct' (implicit GEMM);
@@ -152,11 +162,17 @@ class WinoPackSet:
     storage moves (``.to()``, re-homing into a flat parameter buffer)."""
 
     def __init__(self):
-        self.key = None
+        self.key = self.stamp = None
 
-    def refresh(self, weights):
+    def refresh(self, weights, frozen=False):
+        """frozen (evaluation mode): skip the launch when nothing was written to the filters since the last one
+        (``PARAMS_EPOCH`` for in-place kernels, the tensors' version counters for ``copy_`` / ``load_state_dict``)."""
         math = math_mode()
         key = (math,) + tuple(w.data_ptr() for w in weights)
+        stamp = (PARAMS_EPOCH[0],) + tuple(w._version for w in weights)
+        if frozen and key == self.key and stamp == self.stamp:
+            return self
+        self.stamp = stamp
         if key != self.key:
             dev = weights[0].device
             self.packs, rows = [], []

@@ -48,6 +48,7 @@ class FusedAdam:
         """A captured step (graph.py) was replayed: the Adam launch inside it advanced the device counter."""
         self._step_count += 1
         self._dev_step_value = self._step_count
+        ops.params_changed()
 
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()
@@ -58,6 +59,7 @@ class FusedAdam:
                           self.lr, self.betas, self.eps, self.weight_decay, grad_scale)
         self._step_count += 1
         self._dev_step_value = self._step_count
+        ops.params_changed()
 
     def state_dict(self):
         """torch.optim.Adam's layout with parameter indices in ``model.parameters()`` order -- the ONE format this build

@@ -5,6 +5,8 @@ Both encoders (``se-resnet34``, ``resnet-conformer``) and every ``--loss`` of th
 accdoa, seddoa, masked-seddoa) run on the gfx950 kernels; there is no CPU / eager fallback."""
 import torch.nn as nn
 
+from . import ops
+
 from .models.backbones.resnet import SEResnet34
 from .models.backbones.resnet_conformer import ResnetConformer
 from .models.linearheads import ADYOLOhead, ACCDOAhead, ADPIThead, SEDDOAhead
@@ -36,6 +38,9 @@ class WrapperModel(nn.Module):
             self.head = ADYOLOhead(d, d, self.nb_classes, self.grid_size, self.nb_anchors)
         else:
             raise NotImplementedError("head: {}".format(self.loss_nm))
+        # evaluation-mode caches (BatchNorm affines, packed filters, recorded forward graphs) expire on a state load; code that
+        # writes parameters by hand in evaluation mode calls ops.params_changed() itself
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: ops.params_changed())
 
     def forward(self, x, channels_last8=False):
         """x : (B, C, T, F)  ->  (B, T//4, K)"""

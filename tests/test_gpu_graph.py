@@ -193,3 +193,64 @@ def test_batched_and_graphed_evaluation_writes_the_same_files(ops, tmp_path):
     for nm in names:
         a, b = open(os.path.join(out_a, nm + ".csv")).read(), open(os.path.join(out_b, nm + ".csv")).read()
         assert a == b and len(a) > 0, nm
+
+
+def test_evaluation_caches_expire_when_parameters_change(ops):
+    """Evaluation-mode BatchNorm affines are computed once and kept (``_BNState.eval_affine``), and ``ForwardGraphs`` records
+    them into its graphs; both must expire when parameters or running statistics change -- through a train step (kernels
+    write in place, no torch version bump) or through ``load_state_dict``.  Reference behaviour: evaluation after every
+    epoch sees the weights of that epoch (src/train.py:178-215)."""
+    from adyolo_amd import functional as Fn
+    from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
+    from adyolo_amd.features import FeatureExtractor
+    from adyolo_amd.graph import ForwardGraphs
+    from adyolo_amd.datasets import synthetic_audio, synthetic_targets
+    from adyolo_amd.train import TrainStep
+    torch.manual_seed(100)
+    prm = _params()
+    n = 24000 * 2
+    model = WrapperModel((1, 7, n // 600, 64), (), prm).to("cuda:0")
+    fx = FeatureExtractor(None, "cuda:0")
+    tr = TrainStep(model, WrapperCriterion(prm), fx, prm, graph=False)
+    audio = synthetic_audio(2, n, seed=5).to("cuda:0")
+    target = synthetic_targets(2, n // 2400, 12, seed=5).to("cuda:0")
+    clip = synthetic_audio(1, n, seed=6).to("cuda:0")
+
+    def uncached():
+        """the evaluation forward with every cache dropped first"""
+        for m in model.modules():
+            m.__dict__.pop("_adyolo_eval_affine", None)
+        with torch.no_grad():
+            return model(fx(clip, channels_last8=True), channels_last8=True).clone()
+
+    model.eval()
+    fg = ForwardGraphs(model, fx, None, warm_calls=1)
+    outs = [fg(clip)[0].clone() for _ in range(3)]              # warm call, recorded call, replay
+    assert fg.captures == 1 and torch.equal(outs[0], outs[2]) and torch.equal(outs[2], uncached())
+    launches = []
+    real = ops.bn_eval_stats
+    ops.bn_eval_stats = lambda *a, **k: (launches.append(1), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            again = model(fx(clip, channels_last8=True), channels_last8=True)
+        assert not launches and torch.equal(again, outs[2])     # served from the cache: no BatchNorm launch at all
+        model.train()
+        tr.step(audio, target)                                  # parameters and running statistics move (in place, by kernels)
+        model.eval()
+        after_step = fg(clip)[0].clone()                        # must NOT be the stale graph
+        assert len(launches) == 36                              # every BatchNorm recomputed its affine once
+        assert torch.equal(after_step, uncached()) and not torch.equal(after_step, outs[2])
+        for _ in range(2):
+            assert torch.equal(fg(clip)[0], after_step)         # recorded again, replayed
+        caps = fg.captures
+        # load_state_dict (copy_ into the same storage) expires the eager caches through the tensors' version counters and the
+        # recorded graphs through WrapperModel's post-load hook
+        sd = {k: (v * 0.5 if k.endswith("bn1.weight") else v) for k, v in model.state_dict().items()}
+        model.load_state_dict(sd)
+        for _ in range(3):
+            loaded = fg(clip)[0].clone()
+            assert torch.equal(loaded, uncached()) and not torch.equal(loaded, after_step)
+        assert fg.captures == caps + 1
+    finally:
+        ops.bn_eval_stats = real
+    assert Fn is not None
