@@ -147,3 +147,30 @@ def test_b3_training_trajectory_matches_the_fp32_mode(ops, monkeypatch):
     rel = {k: float((gf - runs[k][1]).norm() / gf.norm()) for k in ("bf16x3", "direct")}
     print("first-step gradient, relative L2 difference to the fp32 Winograd run:", rel)
     assert rel["bf16x3"] <= 1.5 * rel["direct"] + 1e-5 and rel["bf16x3"] <= 5e-3, rel
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(64, 64, 1200, 32), (128, 128, 600, 16), (256, 256, 600, 16), (64, 128, 600, 16)])
+def test_b3_at_bench_shape_slices(ops, cin, cout, h, w):
+    """Forward and data-gradient on the bf16x3 kernel launched at the FULL benchmark shape (64 clips x 60 s: stages 2-4), compared
+    on two clips x 64 rows with a float64 convolution of the slice -- same windows and the same 2e-5 bound as
+    test_conv3x3_at_bench_shape_slices uses for the fp32 kernels."""
+    n = 64
+    gen = torch.Generator(device="cuda:0").manual_seed(cin * 7 + cout)
+    x = torch.randn(n, h, w, cin, generator=gen, device="cuda:0")
+    dy = torch.randn(n, h, w, cout, generator=gen, device="cuda:0")
+    wt = (torch.randn(cout, cin, 3, 3, generator=gen, device="cuda:0") / np.sqrt(9 * cin)).contiguous()
+    wf, wd = ops.pack_w3x3(wt, cin, algo="winograd", math="bf16x3")
+    assert wf.shape[-1] == 768 and wd.shape[-1] == 768
+    y = ops.conv3x3(x, wf, cout)
+    dx = ops.conv3x3(dy, wd, cin)
+    torch.cuda.synchronize()
+    wc = wt.cpu()
+    wflip = wc.flip(2, 3).permute(1, 0, 2, 3).contiguous()
+    for clip, r0 in ((0, 0), (n - 1, h // 2 - 29)):
+        lo, hi = max(r0 - 1, 0), min(r0 + 65, h)
+        for src, kern, out, what in ((x, wc, y, "forward"), (dy, wflip, dx, "data-gradient")):
+            xin = src[clip, lo:hi].cpu().permute(2, 0, 1)[None]
+            ref = F.conv2d(xin.double(), kern.double(), padding=1)[0].permute(1, 2, 0)
+            top = r0 - lo
+            e = _err(out[clip, r0:r0 + 64], ref[top:top + 64])
+            assert e <= 2e-5, "%s clip %d rows %d..%d: %.2e of absmax" % (what, clip, r0, r0 + 64, e)
