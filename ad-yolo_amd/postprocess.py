@@ -126,21 +126,23 @@ class LabelPostProcessor:
         self.conf_thresh = thresh
         self.clss_thresh = thresh
 
-    def decode(self, output):
-        """GPU half of ``postprocess`` (threshold-free): logits (1, T', K) -> decoded predictions as a host array."""
+    def decode(self, output, borrow=False):
+        """GPU half of ``postprocess`` (threshold-free): logits (1, T', K) -> decoded predictions as a host array.
+        borrow: return a view of the page-locked staging buffer (valid until the next decode of that shape) instead of a copy."""
         from . import ops
         if output.shape[0] != 1:
             raise ValueError("postprocess handles one clip at a time (B = 1), like the reference (datasets.py:752-753)")
         dec = ops.yolo_decode(output.contiguous(), self.nb_classes, self.nb_grids, self.nb_anchors, self.grid_size,
                               self.g_overlap)
-        return dec.cpu().numpy()
+        host = ops.to_host(dec).numpy()
+        return host if borrow else host.copy()
 
     def select(self, decoded):
         """Host half: confidence / class thresholds + conn-merge NMS on a ``decode`` result."""
         return nms_decoded(decoded, self.nb_classes, self.conf_thresh, self.clss_thresh, self.unify_thresh, self.nms)
 
     def postprocess(self, output):
-        return self.select(self.decode(output))
+        return self.select(self.decode(output, borrow=True))       # consumed at once: no second host copy
 
 
 def write_seld_output_file(file_pth, output: dict):

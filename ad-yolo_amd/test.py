@@ -95,8 +95,11 @@ def test_epoch_audio(dataset, model, features, criterion, postprocessor, device,
             t = items[0][1]
             pcm_b = torch.from_numpy(__import__("numpy").stack([it[0][:t] for it in items])).to(device).contiguous()
             audio = ops.pcm16_to_f32(pcm_b).view(len(items), t, 4)
+            decoded = None
             if forward is not None:
-                output = forward(audio)[0]
+                output, dec = forward(audio)
+                if dec is not None:                           # the graph decoded the whole batch: ONE page-locked copy to the host
+                    decoded = ops.to_host(dec).numpy()
             else:
                 output = model(features(audio, channels_last8=True), channels_last8=True)
             for b, (pcm, _, rows) in enumerate(items):
@@ -106,7 +109,9 @@ def test_epoch_audio(dataset, model, features, criterion, postprocessor, device,
                     loss = criterion(out_b, target)
                     total = loss.reshape(-1)[:1].clone() if total is None else total + loss.reshape(-1)[:1]
                     n += 1
-                write_seld_output_file(os.path.join(output_pth, names[i + b] + ".csv"), postprocessor.postprocess(out_b))
+                tp = output.shape[1]                          # decoded: [B * T'][Gaz][Gel][A][C+3], clip after clip
+                rows_out = postprocessor.select(decoded[b * tp:(b + 1) * tp]) if decoded is not None else postprocessor.postprocess(out_b)
+                write_seld_output_file(os.path.join(output_pth, names[i + b] + ".csv"), rows_out)
             i += len(items)
     return float(total) / max(n, 1) if total is not None else 0.0
 
