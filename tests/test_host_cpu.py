@@ -385,3 +385,33 @@ def test_raw_audio_dataset_shards_by_rank(tmp_path):
     assert whole[0::2] == shards[0] and whole[1::2] == shards[1]
     te = [FoaDataset(params, "test", is_valid=True, rank=r, world=2).get_filelist() for r in range(2)]
     assert te == [["t0", "t2"], ["t1"]]
+
+
+def test_math_mode_switch_and_parameter_epoch(monkeypatch):
+    """Host logic of round 3 that needs no GPU: the opt-in math mode is validated and only takes multi-chunk contractions by
+    default; the parameter epoch that evaluation-mode caches are keyed on moves when asked to; a state load on the wrapper
+    moves it too (the hook ``WrapperModel`` registers)."""
+    import adyolo_amd  # noqa: F401
+    from adyolo_amd import ops, _lib
+    monkeypatch.delenv("ADYOLO_MATH", raising=False)
+    monkeypatch.delenv("ADYOLO_B3_MIN_K", raising=False)
+    assert ops.math_mode() == "f32" and not ops._b3_eligible(256, ops.math_mode())
+    monkeypatch.setenv("ADYOLO_MATH", "bf16x3")
+    assert ops.math_mode() == "bf16x3"
+    assert ops._b3_eligible(64, "bf16x3") and not ops._b3_eligible(32, "bf16x3")     # one-chunk contractions stay fp32
+    monkeypatch.setenv("ADYOLO_B3_MIN_K", "32")
+    assert ops._b3_eligible(32, "bf16x3")
+    monkeypatch.setenv("ADYOLO_MATH", "tf32")
+    with pytest.raises(_lib.AdyoloHipError):
+        ops.math_mode()
+    e0 = ops.PARAMS_EPOCH[0]
+    ops.params_changed()
+    assert ops.PARAMS_EPOCH[0] == e0 + 1
+    from adyolo_amd.wrapper import WrapperModel
+    torch.manual_seed(0)
+    prm = {"args": {"encoder": "se-resnet34", "loss": "adyolo"}, "data_config": {"nb_classes": 12},
+           "train_config": {"grid_size": [45, 45], "nb_anchors": 5}}
+    model = WrapperModel((1, 7, 80, 64), (), prm)
+    e1 = ops.PARAMS_EPOCH[0]
+    model.load_state_dict(model.state_dict())
+    assert ops.PARAMS_EPOCH[0] == e1 + 1
