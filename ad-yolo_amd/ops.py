@@ -98,6 +98,8 @@ def to_host(t):
     key = (tuple(t.shape), t.dtype)
     buf = _PINNED.get(key)
     if buf is None:
+        if len(_PINNED) >= 16:                       # clips of many different lengths: keep the page-locked pool bounded
+            _PINNED.pop(next(iter(_PINNED)))
         buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
         _PINNED[key] = buf
     buf.copy_(t, non_blocking=True)
