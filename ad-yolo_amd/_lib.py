@@ -87,6 +87,7 @@ SIGNATURES = {
     "adyolo_affine_relu_nhwc": (I, [P] * 4 + [L, I, P]),
     "adyolo_relu_bwd": (I, [P, P, P, L, P]),
     "adyolo_axpby": (I, [P, P, P, F, F, L, P]),
+    "adyolo_dropout_axpby": (I, [P, P, P, L, F, U64, U64, P, F, F, P]),
     "adyolo_swish_fwd": (I, [P, P, L, P]),
     "adyolo_swish_bwd": (I, [P, P, P, L, P]),
     "adyolo_glu_fwd": (I, [P, P, L, I, P]),

@@ -453,9 +453,47 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const float4 *__rest
     }
 }
 
+// out = a * dropout(x) + b * z with the mask of dropout_apply_kernel (z may be null: out = a * dropout(x), the gradient form):
+// the residual mix of a Conformer sub-module whose last operation is a Dropout (resnet_conformer.py:98 on top of :209, :280)
+// in one pass instead of two.  The rounding sequence is that of dropout_apply followed by axpby.
+__global__ __launch_bounds__(256) void dropout_axpby_kernel(const float4 *__restrict__ x, const float4 *__restrict__ z,
+                                                            float4 *__restrict__ y, long n4, float p, float keep_scale,
+                                                            uint64_t seed, uint64_t offset,
+                                                            const uint64_t *__restrict__ offset_dev, float a, float b) {
+    if (offset_dev) offset += *offset_dev;
+    const uint64_t s0 = splitmix64(seed);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = x[i];
+        const uint64_t q = offset + (uint64_t)i * 4;
+        const float u0 = (float)(splitmix64(s0 ^ q) >> 40) * (1.0f / 16777216.0f);
+        const float u1 = (float)(splitmix64(s0 ^ (q + 1)) >> 40) * (1.0f / 16777216.0f);
+        const float u2 = (float)(splitmix64(s0 ^ (q + 2)) >> 40) * (1.0f / 16777216.0f);
+        const float u3 = (float)(splitmix64(s0 ^ (q + 3)) >> 40) * (1.0f / 16777216.0f);
+        const float d0 = v.x * (u0 >= p ? keep_scale : 0.f), d1 = v.y * (u1 >= p ? keep_scale : 0.f);
+        const float d2 = v.z * (u2 >= p ? keep_scale : 0.f), d3 = v.w * (u3 >= p ? keep_scale : 0.f);
+        if (z) {
+            const float4 w = z[i];
+            y[i] = make_float4(a * d0 + b * w.x, a * d1 + b * w.y, a * d2 + b * w.z, a * d3 + b * w.w);
+        } else {
+            y[i] = make_float4(a * d0, a * d1, a * d2, a * d3);
+        }
+    }
+}
+
 }  // namespace adyolo
 
 using namespace adyolo;
+
+extern "C" int adyolo_dropout_axpby(const float *x, const float *z, float *y, long n, float p, uint64_t seed, uint64_t offset,
+                                    const uint64_t *offset_dev, float a, float b, void *stream) {
+    ADYOLO_REQUIRE(x && y && n > 0 && n % 4 == 0 && p >= 0.f && p < 1.f, ADYOLO_EINVAL,
+                   "dropout_axpby: n must be a positive multiple of 4, 0 <= p < 1");
+    const long n4 = n / 4, g = (n4 + 255) / 256;
+    hipLaunchKernelGGL(dropout_axpby_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(z), reinterpret_cast<float4 *>(y),
+                       n4, p, 1.0f / (1.0f - p), seed, offset, offset_dev, a, b);
+    return check_launch("dropout_axpby");
+}
 
 extern "C" int adyolo_sap_fwd(const float *x, const float *w, const float *b, float *y, float *attn, int R, int F,
                               int C, void *stream) {

@@ -867,7 +867,27 @@ class AxpbyFn(torch.autograd.Function):
     def backward(ctx, dy):
         a, b = ctx.ab
         dy = _c(dy)
-        return ops.axpby(dy, dy, a, 0.0), ops.axpby(dy, dy, b, 0.0), None, None
+        # a factor of exactly 1 hands the incoming gradient on (no copy launch: autograd does not write into it)
+        return (dy if a == 1.0 else ops.axpby(dy, dy, a, 0.0)), (dy if b == 1.0 else ops.axpby(dy, dy, b, 0.0)), None, None
+
+
+class DropoutAxpbyFn(torch.autograd.Function):
+    """a * dropout(x) + b * z in ONE pass, mask regenerated from (seed, offset) like ``DropoutHashFn``: the residual mix of a
+    Conformer sub-module that ends in nn.Dropout (reference resnet_conformer.py:98 over :178 / :209 / :272-274).  Same
+    values as ``AxpbyFn(DropoutHashFn(x), z, a, b)``; backward: a * dropout-mask * dy and b * dy."""
+
+    @staticmethod
+    def forward(ctx, x, z, a, b, p, seed, offset, offset_dev=None):
+        ctx.key = (a, b, p, seed, offset, offset_dev)
+        return ops.dropout_axpby(_c(x), _c(z), a, b, p, seed, offset, offset_dev)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b, p, seed, offset, offset_dev = ctx.key
+        dy = _c(dy)
+        dx = ops.dropout_axpby(dy, None, a, 0.0, p, seed, offset, offset_dev)
+        dz = dy if b == 1.0 else ops.axpby(dy, dy, b, 0.0)
+        return dx, dz, None, None, None, None, None, None
 
 
 class AvgPool1dFn(torch.autograd.Function):

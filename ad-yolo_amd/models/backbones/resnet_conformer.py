@@ -31,6 +31,14 @@ def _dropout(x, p, training, rng):
     return Fn.DropoutHashFn.apply(x, p, *rng.draw(x.numel()))
 
 
+def _dropout_residual(y, z, a, p, training, rng):
+    """a * dropout(y) + z: fused into one pass when the stateless mask applies (training, p > 0, element count a multiple
+    of 4); the stream is drawn exactly as ``_dropout`` would draw it."""
+    if training and p > 0.0 and y.numel() % 4 == 0:
+        return Fn.DropoutAxpbyFn.apply(y, z, a, 1.0, p, *rng.draw(y.numel()))
+    return Fn.AxpbyFn.apply(_dropout(y, p, training, rng), z, a, 1.0)
+
+
 def _conv3x3_s1(x, w):
     """Stride-1 3x3 convolution.  Winograd kernels on wide maps; the deep stages of this ResNet have strided the
     frequency axis down to 4, 2 and 1 bins, where an 8 x 16-pixel Winograd patch would be 75-94 % padding, so those run on
@@ -107,12 +115,15 @@ class FeedForwardModule(nn.Module):
         self.sequential = nn.ModuleDict({"0": LayerNormParams(dim), "1": LinearParams(dim, dim * expansion),
                                          "4": LinearParams(dim * expansion, dim)})
 
-    def forward(self, x, rng):
+    def forward(self, x, rng, residual=None):
+        """residual=(z, a): returns a * module(x) + z with the final Dropout fused into the mix"""
         s = self.sequential
         y = Fn.LNFn.apply(x, s["0"].weight, s["0"].bias, s["0"].eps)
         y = Fn.LinearFn.apply(y, s["1"].weight, s["1"].bias)
         y = _dropout(Fn.SwishFn.apply(y), self.p, self.training, rng)
         y = Fn.LinearFn.apply(y, s["4"].weight, s["4"].bias)
+        if residual is not None:
+            return _dropout_residual(y, residual[0], residual[1], self.p, self.training, rng)
         return _dropout(y, self.p, self.training, rng)
 
 
@@ -149,7 +160,7 @@ class ConformerConvModule(nn.Module):
                                    "3": BatchNormParams(2 * dim), "5": Conv1dParams(dim, dim, 3, groups=dim),
                                    "6": BatchNormParams(dim), "8": Conv1dParams(dim, dim, 1)})
 
-    def forward(self, x, rng):
+    def forward(self, x, rng, residual=None):
         c = self.conv
         y = Fn.LNFn.apply(x, c["0"].weight, c["0"].bias, c["0"].eps)
         y = Fn.LinearFn.apply(y, c["2"].weight.view(c["2"].weight.shape[0], -1), c["2"].bias)
@@ -159,6 +170,8 @@ class ConformerConvModule(nn.Module):
         y = Fn.BatchNormFn.apply(y, c["6"].weight, c["6"].bias, c["6"], self.training, False, None)
         y = Fn.SwishFn.apply(y)
         y = Fn.LinearFn.apply(y, c["8"].weight.view(c["8"].weight.shape[0], -1), c["8"].bias)
+        if residual is not None:
+            return _dropout_residual(y, residual[0], residual[1], self.p, self.training, rng)
         return _dropout(y, self.p, self.training, rng)
 
 
@@ -189,13 +202,12 @@ class ConformerBlock(nn.Module):
 
     def forward(self, x, rng):
         s = self.sequential
-        x = Fn.AxpbyFn.apply(s[0].module(x, rng), x, s[0].factor, 1.0)
+        x = s[0].module(x, rng, residual=(x, s[0].factor))          # x + 0.5 * FFN(x), final Dropout fused into the mix
         a = s[1].module
         y = Fn.LNFn.apply(x, a["0"].weight, a["0"].bias, a["0"].eps)
-        y = _dropout(a["1"](y, rng), self.p2, self.training, rng)
-        x = Fn.AxpbyFn.apply(y, x, s[1].factor, 1.0)
-        x = Fn.AxpbyFn.apply(s[2].module(x, rng), x, s[2].factor, 1.0)
-        x = Fn.AxpbyFn.apply(s[3].module(x, rng), x, s[3].factor, 1.0)
+        x = _dropout_residual(a["1"](y, rng), x, s[1].factor, self.p2, self.training, rng)
+        x = s[2].module(x, rng, residual=(x, s[2].factor))
+        x = s[3].module(x, rng, residual=(x, s[3].factor))
         return Fn.LNFn.apply(x, s[4].weight, s[4].bias, s[4].eps)
 
 

@@ -806,6 +806,15 @@ def relu_bwd(dy, y):
     return dx
 
 
+def dropout_axpby(x, z, a, b, p, seed, offset, offset_dev=None):
+    """a * dropout(x) + b * z in one pass (z None: a * dropout(x)); the mask of ``dropout_apply(x, p, seed, offset, offset_dev)``."""
+    _chk(x, z)
+    y = torch.empty_like(x)
+    _c("adyolo_dropout_axpby", _p(x), _p(z), _p(y), x.numel(), float(p), ctypes.c_uint64(seed),
+       ctypes.c_uint64(offset & 0xFFFFFFFFFFFFFFFF), _p(offset_dev), float(a), float(b), _stream())
+    return y
+
+
 def axpby(x, z, a, b):
     _chk(x, z)
     y = torch.empty_like(x)

@@ -396,6 +396,11 @@ int adyolo_affine_relu_nhwc(const float *x, const float *scale, const float *shi
                             void *stream);
 int adyolo_relu_bwd(const float *dy, const float *y, float *dx, long n, void *stream);
 int adyolo_axpby(const float *x, const float *z, float *y, float a, float b, long n, void *stream);
+/* y = a * dropout(x) + b * z in one pass (z NULL: y = a * dropout(x), the gradient w.r.t. x); mask = the stateless stream of
+ * adyolo_dropout_apply(_dev) -- ResidualConnectionModule (resnet_conformer.py:98) on a sub-module that ends in nn.Dropout
+ * (:209 FeedForwardModule, :178 ConformerConvModule, :272-274 attention branch); same rounding as the two separate calls. */
+int adyolo_dropout_axpby(const float *x, const float *z /*or NULL*/, float *y, long n, float p, uint64_t seed, uint64_t offset,
+                         const uint64_t *offset_dev /*or NULL*/, float a, float b, void *stream);
 int adyolo_swish_fwd(const float *x, float *y, long n, void *stream);
 int adyolo_swish_bwd(const float *dy, const float *x, float *dx, long n, void *stream);
 int adyolo_glu_fwd(const float *x, float *y, long rows, int C, void *stream);

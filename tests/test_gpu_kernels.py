@@ -1192,3 +1192,29 @@ def test_config5_mic_model_train_step_matches_oracle(ops):
         lim = 5e-2 if n.startswith("encoder") else 1e-3          # (toy-size encoder gradients: the bound of DESIGN section 7)
         dev_ = float((got - ref).abs().max()) / float(ref.abs().max())
         assert cos >= 0.999 and dev_ <= lim, "%s: cosine %.6f, max dev %.2e" % (n, cos, dev_)
+
+
+def test_fused_dropout_residual_equals_the_two_separate_ops(ops):
+    """DropoutAxpbyFn (a * dropout(x) + z in one pass; Conformer residual branches, reference resnet_conformer.py:98 over a
+    sub-module ending in nn.Dropout) against AxpbyFn(DropoutHashFn(x), z, a, 1): same mask stream, bit-equal forward and
+    gradients; a unit factor hands the incoming gradient on without a copy."""
+    from adyolo_amd import functional as Fn
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(3, 50, 256, generator=g)
+    z0 = torch.randn(3, 50, 256, generator=g)
+    dy = dev(torch.randn(3, 50, 256, generator=g))
+    for a, p in ((0.5, 0.1), (1.0, 0.2)):
+        outs = []
+        for fused in (True, False):
+            x, z = dev(x0).requires_grad_(True), dev(z0).requires_grad_(True)
+            if fused:
+                y = Fn.DropoutAxpbyFn.apply(x, z, a, 1.0, p, 1234, 96)
+            else:
+                y = Fn.AxpbyFn.apply(Fn.DropoutHashFn.apply(x, p, 1234, 96), z, a, 1.0)
+            y.backward(dy)
+            outs.append((y.detach(), x.grad, z.grad))
+        for got, ref, what in zip(outs[0], outs[1], ("forward", "dx", "dz")):
+            assert torch.equal(got, ref), (a, p, what)
+        keep = (outs[0][1] != 0).float().mean().item()
+        assert abs(keep - (1.0 - p)) < 0.02                      # the mask really is a dropout mask
+        assert torch.equal(outs[0][2], dy)                        # b = 1: the residual gradient is the incoming one
