@@ -95,6 +95,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ 
         kh_run = tap0 / cg.KW;
         kw_run = tap0 - kh_run * cg.KW;
     }
+    // gathered B (G == 2): pixel (n, y, x) of this thread's two K rows; with the map width dividing the K tile a tile step
+    // moves y by GBK / Wm with at most one carry into n (Hm >= GBK / Wm is checked), instead of three divisions per row and fetch
+    const bool fastp = G == 2 && cg.Wm > 0 && (GBK % cg.Wm) == 0 && cg.Hm >= GBK / cg.Wm;
+    int px[2] = {0, 0}, py[2] = {0, 0}, pn[2] = {0, 0};
+    if (fastp) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = kbeg + ((tid + i * 256) >> 4);
+            px[i] = k % cg.Wm;
+            const int t_ = k / cg.Wm;
+            py[i] = t_ % cg.Hm;
+            pn[i] = t_ / cg.Hm;
+        }
+    }
     // software pipeline: the next K tile is fetched into registers while the current one feeds the matrix cores
     float4 ra[4], rb[2];
     auto fetch = [&](int k0) {
@@ -161,8 +175,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ 
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int k = k0 + ((tid + i * 256) >> 4);
-                const int x_ = k % cg.Wm, t_ = k / cg.Wm;
-                const int y_ = t_ % cg.Hm, n_ = t_ / cg.Hm;
+                int x_, y_, n_;
+                if (fastp) {                     // the pixel of this thread's K row, advanced by one K tile per fetch
+                    x_ = px[i]; y_ = py[i]; n_ = pn[i];
+                    py[i] += GBK / cg.Wm;
+                    if (py[i] >= cg.Hm) {
+                        py[i] -= cg.Hm;
+                        ++pn[i];
+                    }
+                } else {
+                    x_ = k % cg.Wm;
+                    const int t_ = k / cg.Wm;
+                    y_ = t_ % cg.Hm;
+                    n_ = t_ / cg.Hm;
+                }
                 const int sy = y_ * cg.SH - cg.PH + bkh, sx = x_ * cg.SW - cg.PW + bkw;
                 rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (k < kend && bc >= 0 && sy >= 0 && sy < cg.Hs && sx >= 0 && sx < cg.Ws)
