@@ -30,6 +30,10 @@ SIGNATURES = {
     "adyolo_wino_pack_many": (I, [P, I, I, I, P]),
     "adyolo_wino_tiles": (I, [I] * 3),
     "adyolo_wino_fwd": (I, [P] * 13 + [I] * 7 + [P]),
+    "adyolo_wino4_pack_w": (I, [P, P, P, I, I, I, P]),
+    "adyolo_wino4_pack_many": (I, [P, I, I, I, P]),
+    "adyolo_wino4_tiles": (I, [I] * 3),
+    "adyolo_wino4_fwd": (I, [P] * 13 + [I] * 7 + [P]),
     "adyolo_wino_pack_w_b3": (I, [P, P, P, I, I, I, P]),
     "adyolo_wino_fwd_b3": (I, [P] * 13 + [I] * 7 + [P]),
     "adyolo_wino_wgrad_slabs": (I, [I] * 5),

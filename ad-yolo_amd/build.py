@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libadyolo_hip.so")
-SOURCES = ["conv.hip", "wino.hip", "wino_b3.hip", "gemm.hip", "norm.hip", "seq.hip", "loss.hip", "losses.hip", "features.hip", "features_mic.hip", "conformer.hip", "attention.hip", "aug.hip", "optim.hip"]
+SOURCES = ["conv.hip", "wino.hip", "wino4.hip", "wino_b3.hip", "gemm.hip", "norm.hip", "seq.hip", "loss.hip", "losses.hip", "features.hip", "features_mic.hip", "conformer.hip", "attention.hip", "aug.hip", "optim.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 

@@ -119,12 +119,18 @@ def params_changed():
 
 # ---------------------------------------------------------------------------------------------- conv
 def conv_algo():
-    """'winograd' (default: F(2x2,3x3) on the fp32 MFMA, 2.25x fewer matrix FLOPs) or 'direct' (implicit GEMM);
-    chosen per call of ``pack_w3x3`` from ADYOLO_CONV_ALGO."""
+    """'winograd4' (F(4x4,3x3) on the fp32 MFMA where the shape allows it -- 4x fewer matrix FLOPs than the direct form --
+    and F(2x2,3x3) elsewhere), 'winograd' (F(2x2,3x3) everywhere, 2.25x fewer) or 'direct' (implicit GEMM); chosen per call
+    of ``pack_w3x3`` / ``WinoPackSet.refresh`` from ADYOLO_CONV_ALGO."""
     a = os.environ.get("ADYOLO_CONV_ALGO", "winograd").lower()
-    if a not in ("winograd", "direct"):
-        raise _lib.AdyoloHipError("ADYOLO_CONV_ALGO must be 'winograd' or 'direct' (got %r)" % a)
+    if a not in ("winograd4", "winograd", "direct"):
+        raise _lib.AdyoloHipError("ADYOLO_CONV_ALGO must be 'winograd4', 'winograd' or 'direct' (got %r)" % a)
     return a
+
+
+def _w4_eligible(k_gemm, n_gemm):
+    """F(4x4,3x3) kernel (csrc/wino4.hip): 64 output channels per workgroup, 16-channel pairs of the contraction."""
+    return n_gemm % 64 == 0 and k_gemm % 32 == 0 and k_gemm <= 512
 
 
 def math_mode():
@@ -156,6 +162,17 @@ def pack_w3x3(w, cin_pad, want_dgrad=True, algo=None, math=None):
     _chk(w)
     cout, cin = w.shape[0], w.shape[1]
     algo = algo or conv_algo()
+    if algo == "winograd4" and cin_pad % 32 == 0 and cout % 32 == 0:
+        # per direction: the F(4x4) form [36][N/32][K/8][256] where it applies, else the F(2x2) form
+        f4, d4 = _w4_eligible(cin_pad, cout), want_dgrad and _w4_eligible(cout, cin_pad)
+        uf = _new(w, 36 if f4 else 16, cout // 32, cin_pad // 8, 256)
+        ud = _new(w, 36 if d4 else 16, cin_pad // 32, cout // 8, 256) if want_dgrad else None
+        if f4 or d4:
+            _c("adyolo_wino4_pack_w", _p(w), _p(uf if f4 else None), _p(ud if d4 else None), cout, cin, cin_pad, _stream())
+        if not f4 or (want_dgrad and not d4):
+            _c("adyolo_wino_pack_w", _p(w), _p(None if f4 else uf), _p(None if (d4 or not want_dgrad) else ud), cout, cin,
+               cin_pad, _stream())
+        return uf, ud
     if algo == "winograd" and cin_pad % 32 == 0 and cout % 32 == 0:
         math = math or math_mode()
         fb, db = _b3_eligible(cin_pad, math), _b3_eligible(cout, math) and want_dgrad
@@ -234,14 +251,19 @@ def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, 
     _chk(x, wpk, bias, addend, None if mbits & 1 else addend_mask, None if mbits & 2 else stat_mask)
     n, h, w, cin = x.shape
     wino = wpk.dim() == 4
+    wino4 = wino and wpk.shape[0] == 36
     y = _new(x, n, h, w, cout)
     stats = None
     if want_stats:
-        tiles = (_lib.load().adyolo_wino_tiles if wino else _lib.load().adyolo_conv3x3_tiles)(n, h, w)
+        lib = _lib.load()
+        tiles = (lib.adyolo_wino4_tiles if wino4 else lib.adyolo_wino_tiles if wino else lib.adyolo_conv3x3_tiles)(n, h, w)
         stats = _new(x, 2, tiles, cout)
     sc, sh = in_affine if in_affine is not None else (None, None)
     sa, sm, si = stat_bn if stat_bn is not None else (None, None, None)
-    fn = ("adyolo_wino_fwd_b3" if wpk.shape[-1] == 768 else "adyolo_wino_fwd") if wino else "adyolo_conv3x3_fwd"
+    if wino4:
+        fn = "adyolo_wino4_fwd"
+    else:
+        fn = ("adyolo_wino_fwd_b3" if wpk.shape[-1] == 768 else "adyolo_wino_fwd") if wino else "adyolo_conv3x3_fwd"
     _c(fn, _p(x), _p(wpk), _p(bias), _p(addend), _p(addend_mask),
        _p(sc), _p(sh), _p(y), _p(stats), _p(sa), _p(sm), _p(si), _p(stat_mask), n, h, w, cin, cout, int(relu), mbits,
        _stream())

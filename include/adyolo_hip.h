@@ -123,6 +123,23 @@ int adyolo_wino_fwd(const float *x, const float *u, const float *bias, const flo
                     const float *addend_mask, const float *in_scale, const float *in_shift, float *y, float *stats,
                     const float *stat_aux, const float *stat_mean, const float *stat_invstd, const float *stat_mask,
                     int N, int H, int W, int Cin, int Cout, int relu, int mask_bits, void *stream);
+/* K2w4  the same operator as Winograd F(4x4,3x3) (csrc/wino4.hip; round 4): 36 multiplies per 4x4 output tile and channel pair,
+ *      1.78x fewer matrix instructions than K2w, still on the exact-fp32 MFMA.  Interpolation points 0, +-3/4, +-3/2, infinity;
+ *      error against a float64 convolution ~1e-6 of the output's absmax (K2w: 2e-7).  Replaces nn.Conv2d forward / data-gradient
+ *      at src/models/backbones/resnet.py:16,18 for Cout a multiple of 64 and Cin a multiple of 32 (<= 512).
+ *      u_fwd / u_dgrad: G g G^T in MFMA-fragment order [36][Cout/32][Cin/8][64][4] (forward) / [36][Cin/32][Cout/8][64][4]
+ *      (data-gradient, taps flipped, channels transposed); position order: see csrc/wino4.hip.  adyolo_wino4_fwd takes the
+ *      arguments of adyolo_conv3x3_fwd with `u` in place of `wpk`; its `stats` rows are 32x16-pixel (maps narrower than 32
+ *      pixels) or 16x32-pixel patches: adyolo_wino4_tiles(N,H,W) of them.  adyolo_wino4_pack_many: the table of
+ *      adyolo_wino_pack_many (columns 6, 7 unused). */
+int adyolo_wino4_pack_w(const float *w /*[Cout][Cin_real][3][3]*/, float *u_fwd /*or NULL*/, float *u_dgrad /*or NULL*/,
+                        int Cout, int Cin_real, int Cin, void *stream);
+int adyolo_wino4_pack_many(const int64_t *table, int n, int max_cout, int max_cin, void *stream);
+int adyolo_wino4_tiles(int N, int H, int W);
+int adyolo_wino4_fwd(const float *x, const float *u, const float *bias, const float *addend, const float *addend_mask,
+                     const float *in_scale, const float *in_shift, float *y, float *stats, const float *stat_aux,
+                     const float *stat_mean, const float *stat_invstd, const float *stat_mask, int N, int H, int W, int Cin,
+                     int Cout, int relu, int mask_bits, void *stream);
 /* K2w-b3 (OPT-IN, ADYOLO_MATH=bf16x3; csrc/wino_b3.hip): adyolo_wino_fwd with its GEMMs on the bf16 MFMA and every fp32 operand
  *      split exactly into three bf16 terms (six products per multiply, fp32 accumulation; error of the order of the fp32
  *      MFMA's own rounding).  Same operator, arguments and statistics rows as adyolo_wino_fwd; `u` comes from
