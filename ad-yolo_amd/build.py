@@ -9,6 +9,9 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libadyolo_hip.so")
 SOURCES = ["conv.hip", "wino.hip", "wino4.hip", "wino_b3.hip", "gemm.hip", "norm.hip", "seq.hip", "loss.hip", "losses.hip", "features.hip", "features_mic.hip", "conformer.hip", "attention.hip", "aug.hip", "optim.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# per-file additions.  wino4.hip: no SLP pairing of its transform arithmetic into v_pk_*_f32 -- a packed fp32 instruction beside
+# MFMAs costs more issue time than the two plain ones it replaces (MI355X_MICROARCH.md, cycle constants: "an anti-lever")
+EXTRA_FLAGS = {"wino4.hip": ["-fno-slp-vectorize", "-DW4_BRING=9"]}
 
 
 def _hipcc():
@@ -39,7 +42,7 @@ def build(force=False, verbose=True):
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (s, r.stdout, r.stderr))

@@ -44,7 +44,7 @@ struct Cfg {
     static constexpr int RS = 256 / (4 * TC);           // patch rows per full staging round (16 channels = 4 quads per pixel)
     static constexpr int CBP = 72;                      // epilogue exchange row (64 channels + pad)
     static constexpr int EXCH = 8 * 32 * CBP;
-    static constexpr int LDS_FLOATS = 4 * CBUF > EXCH ? 4 * CBUF : EXCH;
+    static constexpr int LDS_FLOATS = 4 * CBUF > 2 * EXCH ? 4 * CBUF : 2 * EXCH;   // the epilogue exchanges two output rows per round
 };
 
 
@@ -53,13 +53,16 @@ struct Cfg {
     {                                                                                     \
         const float e12 = fmaf(-B2, c[2].F, c[4].F), o12 = fmaf(-B2, c[1].F, c[3].F);      \
         const float e34 = fmaf(-A2, c[2].F, c[4].F), o34 = fmaf(-A2, c[1].F, c[3].F);      \
-        t[0].F = fmaf(P2, c[0].F, fmaf(-S2, c[2].F, c[4].F));                             \
+        const float t0 = fmaf(P2, c[0].F, fmaf(-S2, c[2].F, c[4].F));                     \
+        const float t5 = fmaf(P2, c[1].F, fmaf(-S2, c[3].F, c[5].F));                     \
+        t[0].F = t0;                                                                      \
         t[1].F = fmaf(PA, o12, e12);                                                      \
         t[2].F = fmaf(-PA, o12, e12);                                                     \
         t[3].F = fmaf(PB, o34, e34);                                                      \
         t[4].F = fmaf(-PB, o34, e34);                                                     \
-        t[5].F = fmaf(P2, c[1].F, fmaf(-S2, c[3].F, c[5].F));                             \
+        t[5].F = t5;                                                                      \
     }
+// (t may alias c)
 __device__ __forceinline__ void bt6(const float4 (&c)[6], float4 (&t)[6]) {
     ADYOLO_W4_BT(x) ADYOLO_W4_BT(y) ADYOLO_W4_BT(z) ADYOLO_W4_BT(w)
 }
@@ -74,23 +77,20 @@ __device__ __forceinline__ void bt6s(const float (&c)[6], float (&t)[6]) {      
     t[5] = fmaf(P2, c[1], fmaf(-S2, c[3], c[5]));
 }
 #undef ADYOLO_W4_BT
-// half of it: rows xi = 0, 1, 2 from c0..c4 (hh = 0) or xi = 3, 4, 5 from c1..c5 (hh = 1); r[k] = c[hh + k]
+// half of it for a half column: xi = 0, 1, 2 (hh = 0) or xi = 5, 3, 4 (hh = 1), in that order.  The pair terms use rows 1..4 in
+// both cases (K2 = B2, KP = PA or A2, PB: wave-uniform scalars), the single term rows z = (0, 2, 4) or (1, 3, 5): the caller
+// reads z through wave-uniform addresses, so there is no select and no branch here (two of the seven rows are read twice)
+__device__ __forceinline__ void bt3(const float4 (&c)[4], const float4 (&z)[3], float4 (&t)[3], float K2, float KP) {
 #define ADYOLO_W4_BT3(F)                                                                  \
-    if (hh == 0) {                                                                        \
-        const float e12 = fmaf(-B2, r[2].F, r[4].F), o12 = fmaf(-B2, r[1].F, r[3].F);      \
-        t[0].F = fmaf(P2, r[0].F, fmaf(-S2, r[2].F, r[4].F));                             \
-        t[1].F = fmaf(PA, o12, e12);                                                      \
-        t[2].F = fmaf(-PA, o12, e12);                                                     \
-    } else {                                                                              \
-        const float e34 = fmaf(-A2, r[1].F, r[3].F), o34 = fmaf(-A2, r[0].F, r[2].F);      \
-        t[0].F = fmaf(PB, o34, e34);                                                      \
-        t[1].F = fmaf(-PB, o34, e34);                                                     \
-        t[2].F = fmaf(P2, r[0].F, fmaf(-S2, r[2].F, r[4].F));                             \
+    {                                                                                     \
+        const float e = fmaf(-K2, c[1].F, c[3].F), o = fmaf(-K2, c[0].F, c[2].F);          \
+        t[0].F = fmaf(P2, z[0].F, fmaf(-S2, z[1].F, z[2].F));                             \
+        t[1].F = fmaf(KP, o, e);                                                          \
+        t[2].F = fmaf(-KP, o, e);                                                         \
     }
-__device__ __forceinline__ void bt3(const float4 (&r)[5], float4 (&t)[3], int hh) {
     ADYOLO_W4_BT3(x) ADYOLO_W4_BT3(y) ADYOLO_W4_BT3(z) ADYOLO_W4_BT3(w)
-}
 #undef ADYOLO_W4_BT3
+}
 
 // output transform A^T along one direction: y[p] = sum_k AT[p][k] m[k]
 __device__ __forceinline__ void at4(float m0, float m1, float m2, float m3, float m4, float m5, float &y0, float &y1,
@@ -102,7 +102,33 @@ __device__ __forceinline__ void at4(float m0, float m1, float m2, float m3, floa
     y3 = fmaf(A3, d12, fmaf(B3, d34, m5));
 }
 
-template <int TC>
+#ifndef W4_BRING
+#define W4_BRING 18      // B fragments in flight per wave (9: 2304 matrix cycles ahead, 18: 4608)
+#endif
+#ifndef W4_WHATIF
+#define W4_WHATIF 0       // timing-only builds (results invalid): bit 0 no staging in the loop, 1 no B refills, 2 no A reads / transforms,
+                          // 3 no epilogue (one store per lane), 4 no MFMAs, 5 no staging loads, 6 no staging transforms, 7 no staging writes,
+                          // 8 no leftover-row round, 9 epilogue without its register->LDS half, 10 epilogue without its stores
+#endif
+
+// Four chained MFMAs on an accumulator tile that lives in ARCHITECTURAL registers.  A wave owns 18 tiles = 288 registers, the
+// accumulator half of the file holds 256: hipcc keeps the other two tiles in VGPRs but issues every MFMA in the AccVGPR form,
+// copying the tile in and out around each use (32 v_accvgpr moves per use, each read waiting for the MFMA to drain).  The "+v"
+// constraint pins the VGPR form.  s_nop 1: a just-written VGPR operand needs two wait states before an MFMA reads it, and hipcc
+// pads nothing inside an asm statement (cdna_hip_programming.md 5.7 item 2); the chain on one accumulator needs none, and
+// the tile's next reader is the epilogue, thousands of cycles later.
+__device__ __forceinline__ void mfma32x4_vgpr(f32x16 &c, const float4 &a, const float4 &b) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %1, %5, %0\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %2, %6, %0\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %3, %7, %0\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %4, %8, %0"
+        : "+v"(c)
+        : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
+}
+
+template <int TC, bool AFF>
 __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
     const float *__restrict__ x, const float *__restrict__ u, const float *__restrict__ bias,
     const float *__restrict__ addend, const float *__restrict__ addend_mask, const float *__restrict__ in_scale,
@@ -112,14 +138,13 @@ __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
     int xcd_div, int relu, int mask_bits) {
     using C = Cfg<TC>;
     constexpr int PS = C::PS, CBUF = C::CBUF, RS = C::RS, PR = C::PR, CBP = C::CBP;
-    __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS + 2 * WMAXC];     // (one array: see cdna_hip_programming.md 5, trap 4a)
-    float *aff = lds + C::LDS_FLOATS;                     // producer BatchNorm scale | shift (1 | 0 if none)
+    __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS + 2 * WMAXC];     // (one array: cdna_hip_programming.md 5, trap 4a)
+    float *aff = lds + C::LDS_FLOATS;                     // producer BatchNorm scale | shift
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    const bool has_aff = in_scale != nullptr;
-    if (has_aff)
+    if (AFF)
         for (int c = tid; c < Cin; c += 256) {
             aff[c] = in_scale[c];
             aff[WMAXC + c] = in_shift[c];
@@ -144,106 +169,140 @@ __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
     const int co0 = cb * 64;
     const int ty0 = ph * (4 * C::TR), tx0 = pw * (4 * TC);
 
-    // ---- GEMM-side constants.  Wave w: full column nuF (xi = 0..5 -> acc 0..5) and half column nuH (xi = 3 hh + 0..2 -> acc 6..8)
+    // ---- GEMM-side constants.  Wave w: full column nuF (xi = 0..5 -> acc 0..5) and half column nuH (acc 6..8 = xi 0, 1, 2 for
+    // hh = 0, xi 5, 3, 4 for hh = 1)
     const int nuF = wave == 0 ? 0 : wave == 1 ? 2 : wave == 2 ? 3 : 5;
     const int nuH = wave < 2 ? 1 : 4;
     const int hh = wave & 1;
-    const int tr = li >> C::LOG_TC, tc = li & (TC - 1);
-    // read offsets (bytes) of patch rows 4 tr + j (j = 0..3) of plane (nu 0, quad lh); rows 4, 5 = rows 0, 1 of the next block,
-    // whose rotation is one more: row 4 tr + 4 sits at o[1] + 4 rows, row 4 tr + 5 at o[2] + 4 rows
-    int o_[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o_[j] = ((lh * PS + (4 * tr + ((tr + j) & 3)) * TC + tc) * 16);
+    const float K2 = hh ? A2 : B2, KP = hh ? PB : PA;
     constexpr int ROW4 = 4 * TC * 16;
-    const int planeF = nuF * 2 * PS * 16, planeH = nuH * 2 * PS * 16;      // wave-uniform byte offsets
+    // Everything below that is a per-lane constant of the whole kernel is computed ONCE and kept in registers (the 512-register
+    // budget has room): on the fp32 MFMA a VALU instruction is not hidden under the matrix work, it takes ~5 cycles of the same
+    // pipe (tools/micro/mfma32_coissue.hip), so address arithmetic in the loop is paid in full.
+    // read offsets (bytes) of patch rows 4 tr + j (j = 0..3) of quad lh in the planes of nuF / nuH; rows 4, 5 = rows 0, 1 of the
+    // next block, whose rotation is one more: row 4 tr + 4 sits at row 1's offset + 4 rows, row 4 tr + 5 at row 2's + 4 rows
+    int oF[4], oH[3], oZ[3];
+    {
+        const int tr = li >> C::LOG_TC, tc = li & (TC - 1);
+        int o_[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o_[j] = ((lh * PS + (4 * tr + ((tr + j) & 3)) * TC + tc) * 16);
+        const int planeF = nuF * 2 * PS * 16, planeH = nuH * 2 * PS * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) oF[j] = planeF + o_[j];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) oH[j] = planeH + o_[j + 1];
+        // rows hh, hh + 2, hh + 4 of the half column (the single term's operands)
+        oZ[0] = planeH + (hh ? o_[1] : o_[0]);
+        oZ[1] = planeH + (hh ? o_[3] : o_[2]);
+        oZ[2] = planeH + (hh ? o_[2] : o_[1]) + ROW4;
+    }
 
-    // ---- staging.  Item = (patch row y, tile column stc, channel quad sq4 of the 16-channel pair): six pixels -> six nu
+    // ---- staging.  Item = (patch row y, tile column stc, channel quad sq4 of the 16-channel pair): six pixels -> six nu.
+    // Full rounds: thread tid takes row (tid >> (2 + LOG_TC)) [+ RS in round 1]; leftover rows 2 RS ..: lanes of ONE wave.
+    // Byte offsets of the six pixels inside the sample: out-of-image COLUMNS get 0x80000000 (added to any row offset of a sample
+    // smaller than 2 GiB - 2 rows it stays beyond num_records: the buffer load returns 0); out-of-image ROWS need nothing: a
+    // negative offset or one beyond the sample fails the range check by itself.
     const int rowb = W * Cin * 4, pixb = Cin * 4;
+    const unsigned nrec = (unsigned)H * (unsigned)rowb;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(x + (size_t)n * H * W * Cin), 0, H * W * Cin * 4, 0x00020000);
-    auto opaque_zero = [&]() {
-        int z;
-        asm volatile("v_mov_b32 %0, 0" : "=v"(z));
-        return z;
-    };
-    // idx = tid (full rounds: rows ybase + (tid >> (2 + LOG_TC))) or lane (the leftover rows, one wave)
-    auto st_load = [&](float4 (&p)[6], int idx, int ybase, int pr) {
-        const int i = idx + opaque_zero();
-        const int sq4 = i & 3, stc = (i >> 2) & (TC - 1), yy = ybase + (i >> (2 + C::LOG_TC));
-        const int gy = ty0 + yy - 1, gx0 = tx0 + 4 * stc - 1;
-        const bool rowok = (unsigned)gy < (unsigned)H && yy < PR;
-        const int vo = gy * rowb + gx0 * pixb + sq4 * 16;
+        const_cast<float *>(x + (size_t)n * H * W * Cin), 0, (int)nrec, 0x00020000);
+    int offF[6], offL[6], wbF0, wbF1, wbL;
+    {
+        auto item = [&](int i, int ybase, int (&off)[6], int &wb) {
+            const int sq4 = i & 3, stc = (i >> 2) & (TC - 1), yy = ybase + (i >> (2 + C::LOG_TC));
+            const int gy = ty0 + yy - 1, gx0 = tx0 + 4 * stc - 1;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                off[j] = (yy < PR && (unsigned)(gx0 + j) < (unsigned)W) ? gy * rowb + (gx0 + j) * pixb + sq4 * 16 : (int)0x80000000;
+            const int q = yy >> 2;
+            const int brow = 4 * q + (((yy & 3) + q) & 3);       // storage row: rotation inside 4-row blocks
+            // buffer (sq4 >> 1) of the pair, plane (nu, sq4 & 1); -1: no such row
+            wb = yy < PR ? (sq4 >> 1) * (CBUF * 4) + ((sq4 & 1) * PS + brow * TC + stc) * 16 : -1;
+        };
+        int dummy[6];
+        item(tid, 0, offF, wbF0);
+        item(tid, RS, dummy, wbF1);
+        item(lane, 2 * RS, offL, wbL);
+    }
+    // round: 0, 1 (full rounds), 2 (leftover rows; `on`: this wave's turn, else every lane is sent out of range)
+    auto st_load = [&](float4 (&p)[6], int round, int pr, bool on) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const bool ok = rowok && (unsigned)(gx0 + j) < (unsigned)W;
-            // (whole-vector bit cast: __builtin_bit_cast(float, v[i]) of one element makes hipcc narrow the load to one dword)
-            // (the pixel's whole offset in the VGPR: the range check looks at it alone, and vo itself is negative at the image's
-            //  first row / column)
-            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                          xrs, ok ? vo + j * pixb : (int)0x80000000, pr * 64, 0));
+            const int vo = round == 0 ? offF[j] : round == 1 ? offF[j] + RS * rowb : (on ? offL[j] : (int)0x80000000);
+            // whole-vector bit cast (a bit cast of ONE element makes hipcc narrow the load to a dword)
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, pr * 64, 0));
             p[j] = make_float4(v[0], v[1], v[2], v[3]);
         }
     };
-    auto st_store = [&](const float4 (&p)[6], int idx, int ybase, float *Cn, int pr) {
-        const int i = idx + opaque_zero();
-        const int sq4 = i & 3, stc = (i >> 2) & (TC - 1), yy = ybase + (i >> (2 + C::LOG_TC));
-        float4 tt[6];
-        bt6(p, tt);
-        if (has_aff) {
-            // affine after the transform: scale * T(x) + shift * T(m), m = 1 on in-image pixels
-            const int gy = ty0 + yy - 1, gx0 = tx0 + 4 * stc - 1;
-            const bool rowok = (unsigned)gy < (unsigned)H;
-            float m[6], tm[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) m[j] = (rowok && (unsigned)(gx0 + j) < (unsigned)W) ? 1.f : 0.f;
-            bt6s(m, tm);
+    // second half of a staging round, in two parts so that the caller can place them under different MFMA steps:
+    // st_xform: (producer affine on the in-image pixels,) six-point transform, in place;  st_write: six ds_write_b128
+    auto st_xform = [&](float4 (&p)[6], int round, int pr) {
+        if (AFF) {
+            // x' = scale * x + shift on in-image pixels; out-of-image pixels were read as 0 and must stay 0
+            const int sq4 = (round == 2 ? lane : tid) & 3;
             const float4 isc = *reinterpret_cast<const float4 *>(&aff[pr * 16 + sq4 * 4]);
             const float4 ish = *reinterpret_cast<const float4 *>(&aff[WMAXC + pr * 16 + sq4 * 4]);
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                tt[j].x = fmaf(tt[j].x, isc.x, ish.x * tm[j]);
-                tt[j].y = fmaf(tt[j].y, isc.y, ish.y * tm[j]);
-                tt[j].z = fmaf(tt[j].z, isc.z, ish.z * tm[j]);
-                tt[j].w = fmaf(tt[j].w, isc.w, ish.w * tm[j]);
+                const int vo = round == 0 ? offF[j] : round == 1 ? offF[j] + RS * rowb : offL[j];
+                const bool ok = (unsigned)vo < nrec;
+                p[j].x = fmaf(p[j].x, isc.x, ok ? ish.x : 0.f);
+                p[j].y = fmaf(p[j].y, isc.y, ok ? ish.y : 0.f);
+                p[j].z = fmaf(p[j].z, isc.z, ok ? ish.z : 0.f);
+                p[j].w = fmaf(p[j].w, isc.w, ok ? ish.w : 0.f);
             }
         }
-        if (yy < PR) {
-            const int q = yy >> 2;
-            const int brow = 4 * q + (((yy & 3) + q) & 3);       // storage row: rotation inside 4-row blocks
-            // buffer (sq4 >> 1) of the pair, plane (nu, sq4 & 1)
-            char *dst = reinterpret_cast<char *>(Cn) + (sq4 >> 1) * (CBUF * 4) + ((sq4 & 1) * PS + brow * TC + stc) * 16;
+        bt6(p, p);
+    };
+    auto st_write = [&](const float4 (&tt)[6], int round, float *Cn) {
+        const int wb = round == 0 ? wbF0 : round == 1 ? wbF1 : wbL;
+        if (round < 2 || wb >= 0) {
+            char *dst = reinterpret_cast<char *>(Cn) + wb;
 #pragma unroll
             for (int j = 0; j < 6; ++j) *reinterpret_cast<float4 *>(dst + j * 2 * PS * 16) = tt[j];
         }
     };
+    auto st_store = [&](float4 (&p)[6], int round, float *Cn, int pr) {
+        st_xform(p, round, pr);
+        st_write(p, round, Cn);
+    };
 
     const int nkg = Cin / 8, npairs = Cin / 16;
     const size_t ustride_pos = (size_t)(Cout / 32) * nkg * 256;               // floats per transform position
-    const char *ubase = reinterpret_cast<const char *>(u + ((size_t)(wave * 9) * (Cout / 32) + (size_t)cb * 2) * nkg * 256);
-    const unsigned ulane = lane * 16u;
+    // B fragments through a buffer descriptor: the lane's 16 bytes are the VGPR offset (one register for every load), the
+    // fragment's position the SGPR offset -- no vector instruction per load (a global_load costs a v_or or a 64-bit vector add)
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(u), 0, (int)(36 * ustride_pos * 4), 0x00020000);
+    const int ulane = lane * 16;
+    const int uwave = (int)((((size_t)(wave * 9) * (Cout / 32) + (size_t)cb * 2) * nkg * 256) * 4);
     // B fragment of use uu = 2 s + nt of group kg
     auto bload = [&](int uu, int kg) {
         const int s = uu >> 1, nt = uu & 1;
-        return *reinterpret_cast<const float4 *>(
-            ubase + ((unsigned)((s * ustride_pos + ((size_t)nt * nkg + kg) * 256) * 4) + ulane));
+        const int so = uwave + (int)((s * ustride_pos + ((size_t)nt * nkg + kg) * 256) * 4);
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, ulane, so, 0));
+        return make_float4(v[0], v[1], v[2], v[3]);
     };
-    // nine-slot ring: use uu of a group sits in slot uu % 9 (18 uses per group: the slot of a use is the same in every group)
-    float4 bq[9];
+    // register ring of BR fragments (BR = 9 or 18 divides the 18 uses of a group: use uu sits in slot uu % BR in every group)
+    constexpr int BR = W4_BRING;
+    float4 bq[BR];
 #pragma unroll
-    for (int uu = 0; uu < 9; ++uu) bq[uu] = bload(uu, 0);
+    for (int uu = 0; uu < BR; ++uu) bq[uu] = bload(uu, 0);
 
     __syncthreads();                                      // affine table visible
     {                                                     // pair 0: all staging rounds in flight together
         float4 p0[6], p1[6];
-        st_load(p0, tid, 0, 0);
-        st_load(p1, tid, RS, 0);
-        st_store(p0, tid, 0, lds, 0);
-        st_load(p0, tid, 2 * RS, 0);                      // leftover rows (every wave redundantly here: prologue only)
-        st_store(p1, tid, RS, lds, 0);
-        st_store(p0, tid, 2 * RS, lds, 0);
+        st_load(p0, 0, 0, true);
+        st_load(p1, 1, 0, true);
+        st_store(p0, 0, lds, 0);
+        st_load(p0, 2, 0, wave == 0);                     // leftover rows
+        st_store(p1, 1, lds, 0);
+        if (wave == 0) st_store(p0, 2, lds, 0);
     }
-    float4 pv[6];
-    st_load(pv, tid, 0, npairs > 1 ? 1 : 0);              // round 0 of pair 1
+    // two register sets for the pixels in flight: every staging load is requested >= 15 steps (3840 matrix cycles) before its use
+    float4 pvA[6], pvB[6];
+    st_load(pvA, 0, npairs > 1 ? 1 : 0, true);            // rounds 0 and 1 of pair 1
+    st_load(pvB, 1, npairs > 1 ? 1 : 0, true);
     __syncthreads();
 
     f32x16 acc[9][2];
@@ -254,92 +313,135 @@ __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[s][nt][r] = 0.f;
 
-    // A fragments of one 8-channel group from buffer Cs
-    auto a_read_full = [&](float4 (&c)[6], const char *Cs) {
-        const char *pf = Cs + planeF;
-        c[0] = *reinterpret_cast<const float4 *>(pf + o_[0]);
-        c[1] = *reinterpret_cast<const float4 *>(pf + o_[1]);
-        c[2] = *reinterpret_cast<const float4 *>(pf + o_[2]);
-        c[3] = *reinterpret_cast<const float4 *>(pf + o_[3]);
-        c[4] = *reinterpret_cast<const float4 *>(pf + o_[1] + ROW4);
-        c[5] = *reinterpret_cast<const float4 *>(pf + o_[2] + ROW4);
+    // A fragments of one 8-channel group: 6 + 7 ds_read_b128, 48 + 24 VALU, in four separately placed parts.  bF / bH / bZ:
+    // the pair's base addresses (read offsets + the pair's buffer), made once per pair; the pair's second group = + CBUF * 4
+    float4 cF[6], cP[4], cZ[3];
+    float4 a[9];                                          // ONE set: a fragment is overwritten for the next group once its MFMAs are issued
+    int bF[4], bH[3], bZ[3];
+    const char *ldsb = reinterpret_cast<const char *>(lds);
+    auto a_reads_full = [&](int g) {
+        cF[0] = *reinterpret_cast<const float4 *>(ldsb + bF[0] + g * (CBUF * 4));
+        cF[1] = *reinterpret_cast<const float4 *>(ldsb + bF[1] + g * (CBUF * 4));
+        cF[2] = *reinterpret_cast<const float4 *>(ldsb + bF[2] + g * (CBUF * 4));
+        cF[3] = *reinterpret_cast<const float4 *>(ldsb + bF[3] + g * (CBUF * 4));
+        cF[4] = *reinterpret_cast<const float4 *>(ldsb + bF[1] + g * (CBUF * 4) + ROW4);
+        cF[5] = *reinterpret_cast<const float4 *>(ldsb + bF[2] + g * (CBUF * 4) + ROW4);
     };
-    auto a_read_half = [&](float4 (&c)[5], const char *Cs) {     // rows hh .. hh + 4
-        const char *ph_ = Cs + planeH;
-        if (hh == 0) {
-            c[0] = *reinterpret_cast<const float4 *>(ph_ + o_[0]);
-            c[1] = *reinterpret_cast<const float4 *>(ph_ + o_[1]);
-            c[2] = *reinterpret_cast<const float4 *>(ph_ + o_[2]);
-            c[3] = *reinterpret_cast<const float4 *>(ph_ + o_[3]);
-            c[4] = *reinterpret_cast<const float4 *>(ph_ + o_[1] + ROW4);
-        } else {
-            c[0] = *reinterpret_cast<const float4 *>(ph_ + o_[1]);
-            c[1] = *reinterpret_cast<const float4 *>(ph_ + o_[2]);
-            c[2] = *reinterpret_cast<const float4 *>(ph_ + o_[3]);
-            c[3] = *reinterpret_cast<const float4 *>(ph_ + o_[1] + ROW4);
-            c[4] = *reinterpret_cast<const float4 *>(ph_ + o_[2] + ROW4);
-        }
+    auto a_reads_half = [&](int g) {
+        cP[0] = *reinterpret_cast<const float4 *>(ldsb + bH[0] + g * (CBUF * 4));
+        cP[1] = *reinterpret_cast<const float4 *>(ldsb + bH[1] + g * (CBUF * 4));
+        cP[2] = *reinterpret_cast<const float4 *>(ldsb + bH[2] + g * (CBUF * 4));
+        cP[3] = *reinterpret_cast<const float4 *>(ldsb + bH[0] + g * (CBUF * 4) + ROW4);
+        cZ[0] = *reinterpret_cast<const float4 *>(ldsb + bZ[0] + g * (CBUF * 4));
+        cZ[1] = *reinterpret_cast<const float4 *>(ldsb + bZ[1] + g * (CBUF * 4));
+        cZ[2] = *reinterpret_cast<const float4 *>(ldsb + bZ[2] + g * (CBUF * 4));
+    };
+    auto a_xform_full = [&]() {
+        float4 tF[6];
+        bt6(cF, tF);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) a[s] = tF[s];
+    };
+    auto a_xform_half = [&]() {
+        float4 tH[3];
+        bt3(cP, cZ, tH, K2, KP);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) a[6 + s] = tH[s];
     };
 
-    float4 a0[9], a1[9];                                  // A fragments of the pair's two groups
+    // The pair loop is a hand-placed software pipeline of 36 steps (step = one accumulator tile's four MFMAs = 256 matrix
+    // cycles), pinned with __builtin_amdgcn_sched_barrier(0): left alone, the scheduler sinks every load to just above its
+    // use (first version: each B refill followed by its own vmcnt wait).  Per step: [side work + 4 MFMAs] | the step's loads.
+    //   B ring: the fragment of step t + 9 is requested right after step t (2304 matrix cycles ahead);
+    //   A fragments: fragments 0..5 (6..8) of the pair's second group are read at step 8 (16) and transformed under step 12
+    //   (18), i.e. right after the first group's MFMAs on those registers are issued; the first group's are made after the
+    //   pair's barrier (the six of the full column before step 0, the rest under step 2);
+    //   staging of the next pair (two register sets A, B): round 0 (A) transformed under step 4, written under 6; round 1 (B)
+    //   transformed under 14, written under 16; leftover rows requested at 17 (B), written (one wave) under 32; rounds 0 / 1 of
+    //   the pair after requested at 16 (A) / 34 (B).
     for (int pr = 0; pr < npairs; ++pr) {
-        const char *Cs = reinterpret_cast<const char *>(lds) + (pr & 1) * (2 * CBUF * 4);
+        const int pboff = (pr & 1) * (2 * CBUF * 4);
         float *Cn = lds + ((pr + 1) & 1) * (2 * CBUF);
         const int prn = pr + 1 < npairs ? pr + 1 : npairs - 1;                 // pair being staged (clamped)
         const int prn2 = pr + 2 < npairs ? pr + 2 : npairs - 1;
         const bool lwave = wave == (pr & 3);                                   // this wave stages the leftover rows of the pair
-        {
-            float4 cF[6], cH[5];
-            a_read_full(cF, Cs);
-            a_read_half(cH, Cs);
-            float4 tF[6], tH[3];
-            bt6(cF, tF);
-            bt3(cH, tH, hh);
+        if (!(W4_WHATIF & 4) || pr == 0) {
 #pragma unroll
-            for (int s = 0; s < 6; ++s) a0[s] = tF[s];
+            for (int j = 0; j < 4; ++j) bF[j] = oF[j] + pboff;
 #pragma unroll
-            for (int s = 0; s < 3; ++s) a0[6 + s] = tH[s];
+            for (int j = 0; j < 3; ++j) {
+                bH[j] = oH[j] + pboff;
+                bZ[j] = oZ[j] + pboff;
+            }
+            a_reads_full(0);
+            __builtin_amdgcn_sched_barrier(0);
+            a_xform_full();
+            __builtin_amdgcn_sched_barrier(0);
+            a_reads_half(0);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int kg = 2 * pr + half;
             const int kgn = kg + 1 < nkg ? kg + 1 : nkg - 1;
-            if (half == 0) {
-                // A fragments of the second group, under the first group's MFMAs
-                float4 cF[6], cH[5];
-                a_read_full(cF, Cs + CBUF * 4);
-                a_read_half(cH, Cs + CBUF * 4);
-                float4 tF[6], tH[3];
-                bt6(cF, tF);
-                bt3(cH, tH, hh);
-#pragma unroll
-                for (int s = 0; s < 6; ++s) a1[s] = tF[s];
-#pragma unroll
-                for (int s = 0; s < 3; ++s) a1[6 + s] = tH[s];
-            }
 #pragma unroll
             for (int s = 0; s < 9; ++s) {
-                const float4 a = half == 0 ? a0[s] : a1[s];
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    const int uu = 2 * s + nt, slot = uu % 9;
-                    acc[s][nt] = mfma32(a.x, bq[slot].x, acc[s][nt]);
-                    acc[s][nt] = mfma32(a.y, bq[slot].y, acc[s][nt]);
-                    acc[s][nt] = mfma32(a.z, bq[slot].z, acc[s][nt]);
-                    acc[s][nt] = mfma32(a.w, bq[slot].w, acc[s][nt]);
-                    bq[slot] = uu + 9 < 18 ? bload(uu + 9, kg) : bload(uu - 9, kgn);
-                }
-                if (half == 0 && s == 4) {
-                    st_store(pv, tid, 0, Cn, prn);
-                    st_load(pv, tid, RS, prn);
-                }
-                if (half == 1 && s == 0) {
-                    st_store(pv, tid, RS, Cn, prn);
-                    if (lwave) st_load(pv, lane, 2 * RS, prn);
-                }
-                if (half == 1 && s == 6) {
-                    if (lwave) st_store(pv, lane, 2 * RS, Cn, prn);
-                    st_load(pv, tid, 0, prn2);
+                    const int step = half * 18 + 2 * s + nt;
+                    const int uu = 2 * s + nt, slot = uu % BR;
+                    // ---- side work of the step (VALU / LDS writes), free to interleave with its MFMAs
+                    if (!(W4_WHATIF & 4) || pr == 0) {
+                        if (step == 2) a_xform_half();
+                        if (step == 12) a_xform_full();
+                        if (step == 18) a_xform_half();
+                    }
+                    if (!(W4_WHATIF & 1)) {
+                        if (!(W4_WHATIF & 64)) {
+                            if (step == 4) st_xform(pvA, 0, prn);
+                            if (step == 14) st_xform(pvB, 1, prn);
+                        }
+                        if (!(W4_WHATIF & 128)) {
+                            if (step == 6) st_write(pvA, 0, Cn);
+                            if (step == 16) st_write(pvB, 1, Cn);
+                        }
+                        if (!(W4_WHATIF & 256))
+                            if (step == 32 && lwave) st_store(pvB, 2, Cn, prn);
+                    }
+                    if (W4_WHATIF & 16) {
+                        asm volatile("" : "+v"(a[s].x), "+v"(a[s].y), "+v"(a[s].z), "+v"(a[s].w));
+                        asm volatile("" : "+v"(bq[slot].x), "+v"(bq[slot].y), "+v"(bq[slot].z), "+v"(bq[slot].w));
+                    } else if (s < 8) {
+                        // MFMAs are pure: instruction selection may emit them anywhere their operands allow, also on the far
+                        // side of a sched_barrier (seen: the refills of twelve steps ahead of the first MFMA).  Two empty asm
+                        // statements -- one defining an operand, one using the result -- tie them to their step.
+                        asm volatile("" : "+v"(a[s].x));
+                        acc[s][nt] = mfma32(a[s].x, bq[slot].x, acc[s][nt]);
+                        acc[s][nt] = mfma32(a[s].y, bq[slot].y, acc[s][nt]);
+                        acc[s][nt] = mfma32(a[s].z, bq[slot].z, acc[s][nt]);
+                        acc[s][nt] = mfma32(a[s].w, bq[slot].w, acc[s][nt]);
+                        asm volatile("" : "+a"(acc[s][nt]));
+                    } else {
+                        mfma32x4_vgpr(acc[s][nt], a[s], bq[slot]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // ---- loads of the step
+                    if (!(W4_WHATIF & 2)) bq[slot] = uu + BR < 18 ? bload(uu + BR, kg) : bload(uu + BR - 18, kgn);
+                    if (!(W4_WHATIF & 4) || pr == 0) {
+                        if (step == 8) a_reads_full(1);
+                        if (step == 16) a_reads_half(1);
+                    }
+                    if (!(W4_WHATIF & 1)) {
+                        if (!(W4_WHATIF & 32)) {
+                            if (step == 16) st_load(pvA, 0, prn2, true);
+                            if (step == 34) st_load(pvB, 1, prn2, true);
+                        }
+                        // the leftover rows: every wave issues the loads (all lanes out of range unless it is its turn), so that
+                        // the compiler's vmcnt bookkeeping is the same on both sides of the branch under step 32
+                        if (!(W4_WHATIF & (32 | 256)))
+                            if (step == 17) st_load(pvB, 2, prn, lwave);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -347,7 +449,15 @@ __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
     }
 
     // ---- epilogue.  xi-sum of A^T . A in registers: Q[p] (p = output row inside the tile) of the full column and the partial
-    // one of the half column; nu-sum through LDS, one output row p per round: slot 2 w = full column of wave w, 2 w + 1 = half
+    // one of the half column; nu-sum through LDS, TWO output rows p per round (2 x 72 KB): slot 2 w = full column of wave w,
+    // 2 w + 1 = its half column
+    if (W4_WHATIF & 8) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int s = 0; s < 9; ++s) sacc += acc[s][0][0] + acc[s][1][3];
+        y[(size_t)blockIdx.x * 256 + tid] = sacc;
+        return;
+    }
     float *Pb = lds;
     constexpr int C4 = 16;                                // float4 pieces per pixel (64 channels)
     const int c4 = tid % C4, m0 = tid / C4;               // epilogue thread: tiles m0 and m0 + 16, channel quad c4
@@ -359,9 +469,13 @@ __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
         smean = *reinterpret_cast<const float4 *>(stat_mean + co);
         sinv = *reinterpret_cast<const float4 *>(stat_invstd + co);
     }
+    const float hc0 = hh ? 0.f : 1.f, hc3 = hh ? 1.f : 0.f, hk1 = hh ? PB : PA, hk2 = hh ? B2 : A2, hk3 = hh ? B3 : A3;
+    // addresses / validity of the thread's pixels: tiles m0, m0 + 16 (it), output row p of the tile, columns b = 0..3
+    const int etc0 = m0 & (TC - 1), etr0 = m0 >> C::LOG_TC;
+    constexpr int DTR = 16 >> C::LOG_TC;                  // tile-row distance of tiles m0 and m0 + 16 (same tile column)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        if (p) __syncthreads();
+    for (int pp = 0; pp < 2; ++pp) {
+        if (pp) __syncthreads();
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -369,76 +483,133 @@ __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
                 const int m = mfma_row(r, lane);
                 float q0, q1, q2, q3;
                 at4(acc[0][nt][r], acc[1][nt][r], acc[2][nt][r], acc[3][nt][r], acc[4][nt][r], acc[5][nt][r], q0, q1, q2, q3);
-                const float qf = p == 0 ? q0 : p == 1 ? q1 : p == 2 ? q2 : q3;
-                float h0, h1, h2, h3;
-                if (hh == 0) at4(acc[6][nt][r], acc[7][nt][r], acc[8][nt][r], 0.f, 0.f, 0.f, h0, h1, h2, h3);
-                else at4(0.f, 0.f, 0.f, acc[6][nt][r], acc[7][nt][r], acc[8][nt][r], h0, h1, h2, h3);
-                const float qh = p == 0 ? h0 : p == 1 ? h1 : p == 2 ? h2 : h3;
-                Pb[((wave * 2 + 0) * 32 + m) * CBP + nt * 32 + li] = qf;
-                Pb[((wave * 2 + 1) * 32 + m) * CBP + nt * 32 + li] = qh;
+                // the half column, branch-free: (acc 6, 7, 8) = xi (0, 1, 2) or (5, 3, 4); wave-uniform constants pick the terms
+                const float hs = acc[7][nt][r] + acc[8][nt][r], hd = acc[7][nt][r] - acc[8][nt][r];
+                const float h0 = fmaf(hc0, acc[6][nt][r], hs), h1 = hk1 * hd, h2 = hk2 * hs, h3 = fmaf(hk3, hd, hc3 * acc[6][nt][r]);
+                float *d = &Pb[((wave * 2 + 0) * 32 + m) * CBP + nt * 32 + li];
+                if (W4_WHATIF & 512) {
+                    if (r == 0 && nt == 0) d[0] = acc[0][0][0] + acc[8][1][1];
+                    continue;
+                }
+                d[0] = pp == 0 ? q0 : q2;
+                d[32 * CBP] = pp == 0 ? h0 : h2;
+                d[C::EXCH] = pp == 0 ? q1 : q3;
+                d[C::EXCH + 32 * CBP] = pp == 0 ? h1 : h3;
             }
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int m_ = m0 + it * 16;
-            const int etr = m_ >> C::LOG_TC, etc = m_ & (TC - 1);
-            float4 S[8];
+        for (int e = 0; e < 2; ++e) {
+            const int p = 2 * pp + e;
+            // the fused operands of the 8 pixels of this row pair first, all loads in flight together (one workgroup per CU: nobody
+            // else covers their latency); out-of-image pixels read the clamped address and are dropped at the store
+            size_t o[2][4];
+            bool ok[2][4];
+            float4 ad[2][4], ax[2][4];
+            unsigned amk[2][4], smk[2][4];                // 4-bit keep masks of the addend / of the statistics
 #pragma unroll
-            for (int k = 0; k < 8; ++k) S[k] = *reinterpret_cast<const float4 *>(&Pb[(k * 32 + m_) * CBP + c4 * 4]);
-            // Q[p][nu]: nu0 = S0, nu1 = S1 + S3, nu2 = S2, nu3 = S4, nu4 = S5 + S7, nu5 = S6
-            const float4 n1 = f4_add(S[1], S[3]), n4 = f4_add(S[5], S[7]);
-            float4 Y[4];
-            at4(S[0].x, n1.x, S[2].x, S[4].x, n4.x, S[6].x, Y[0].x, Y[1].x, Y[2].x, Y[3].x);
-            at4(S[0].y, n1.y, S[2].y, S[4].y, n4.y, S[6].y, Y[0].y, Y[1].y, Y[2].y, Y[3].y);
-            at4(S[0].z, n1.z, S[2].z, S[4].z, n4.z, S[6].z, Y[0].z, Y[1].z, Y[2].z, Y[3].z);
-            at4(S[0].w, n1.w, S[2].w, S[4].w, n4.w, S[6].w, Y[0].w, Y[1].w, Y[2].w, Y[3].w);
-            const int gy = ty0 + 4 * etr + p;
+            for (int it = 0; it < 2; ++it) {
+                const int gy = ty0 + 4 * (etr0 + it * DTR) + p;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int gx = tx0 + 4 * etc + b;
-                float4 v = Y[b];
-                if (gy < H && gx < W) {
-                    const size_t o = (((size_t)n * H + gy) * W + gx) * Cout + co;
-                    v = f4_add(v, bv);
-                    if (addend) {
-                        float4 ad = *reinterpret_cast<const float4 *>(addend + o);
-                        if (addend_mask) {
+                for (int b = 0; b < 4; ++b) {
+                    const int gx = tx0 + 4 * etc0 + b;
+                    ok[it][b] = gy < H && gx < W;
+                    o[it][b] = (((size_t)n * H + min(gy, H - 1)) * W + min(gx, W - 1)) * Cout + co;
+                }
+            }
+            if (addend) {
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) ad[it][b] = *reinterpret_cast<const float4 *>(addend + o[it][b]);
+                if (addend_mask) {
+#pragma unroll
+                    for (int it = 0; it < 2; ++it)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
                             bool kx, ky, kz, kw;
                             if (mask_bits & 1) {
-                                mask_bits4(reinterpret_cast<const unsigned long long *>(addend_mask), o >> 2, kx, ky, kz, kw);
+                                mask_bits4(reinterpret_cast<const unsigned long long *>(addend_mask), o[it][b] >> 2, kx, ky, kz, kw);
                             } else {
-                                const float4 mk = *reinterpret_cast<const float4 *>(addend_mask + o);
+                                const float4 mk = *reinterpret_cast<const float4 *>(addend_mask + o[it][b]);
                                 kx = mk.x > 0.f; ky = mk.y > 0.f; kz = mk.z > 0.f; kw = mk.w > 0.f;
                             }
-                            ad = make_float4(kx ? ad.x : 0.f, ky ? ad.y : 0.f, kz ? ad.z : 0.f, kw ? ad.w : 0.f);
+                            amk[it][b] = (kx ? 1u : 0u) | (ky ? 2u : 0u) | (kz ? 4u : 0u) | (kw ? 8u : 0u);
                         }
-                        v = f4_add(v, ad);
-                    }
-                    if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-                    *reinterpret_cast<float4 *>(y + o) = v;
-                    if (stats) {
-                        if (stat_mask) {
+                }
+            }
+            if (stats) {
+                if (stat_mask) {
+#pragma unroll
+                    for (int it = 0; it < 2; ++it)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
                             bool kx, ky, kz, kw;
                             if (mask_bits & 2) {
-                                mask_bits4(reinterpret_cast<const unsigned long long *>(stat_mask), o >> 2, kx, ky, kz, kw);
+                                mask_bits4(reinterpret_cast<const unsigned long long *>(stat_mask), o[it][b] >> 2, kx, ky, kz, kw);
                             } else {
-                                const float4 mk = *reinterpret_cast<const float4 *>(stat_mask + o);
+                                const float4 mk = *reinterpret_cast<const float4 *>(stat_mask + o[it][b]);
                                 kx = mk.x > 0.f; ky = mk.y > 0.f; kz = mk.z > 0.f; kw = mk.w > 0.f;
                             }
-                            v = make_float4(kx ? v.x : 0.f, ky ? v.y : 0.f, kz ? v.z : 0.f, kw ? v.w : 0.f);
+                            smk[it][b] = (kx ? 1u : 0u) | (ky ? 2u : 0u) | (kz ? 4u : 0u) | (kw ? 8u : 0u);
                         }
-                        ssum = f4_add(ssum, v);
-                        if (stat_aux) {
-                            const float4 ax = *reinterpret_cast<const float4 *>(stat_aux + o);
-                            ssq.x += v.x * (ax.x - smean.x) * sinv.x;
-                            ssq.y += v.y * (ax.y - smean.y) * sinv.y;
-                            ssq.z += v.z * (ax.z - smean.z) * sinv.z;
-                            ssq.w += v.w * (ax.w - smean.w) * sinv.w;
-                        } else {
-                            ssq.x += v.x * v.x;
-                            ssq.y += v.y * v.y;
-                            ssq.z += v.z * v.z;
-                            ssq.w += v.w * v.w;
+                }
+                if (stat_aux) {
+#pragma unroll
+                    for (int it = 0; it < 2; ++it)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) ax[it][b] = *reinterpret_cast<const float4 *>(stat_aux + o[it][b]);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int m_ = m0 + it * 16;
+                float4 S[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    S[k] = *reinterpret_cast<const float4 *>(&Pb[e * C::EXCH + (k * 32 + m_) * CBP + c4 * 4]);
+                // Q[p][nu]: nu0 = S0, nu1 = S1 + S3, nu2 = S2, nu3 = S4, nu4 = S5 + S7, nu5 = S6
+                const float4 n1 = f4_add(S[1], S[3]), n4 = f4_add(S[5], S[7]);
+                float4 Y[4];
+                at4(S[0].x, n1.x, S[2].x, S[4].x, n4.x, S[6].x, Y[0].x, Y[1].x, Y[2].x, Y[3].x);
+                at4(S[0].y, n1.y, S[2].y, S[4].y, n4.y, S[6].y, Y[0].y, Y[1].y, Y[2].y, Y[3].y);
+                at4(S[0].z, n1.z, S[2].z, S[4].z, n4.z, S[6].z, Y[0].z, Y[1].z, Y[2].z, Y[3].z);
+                at4(S[0].w, n1.w, S[2].w, S[4].w, n4.w, S[6].w, Y[0].w, Y[1].w, Y[2].w, Y[3].w);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    float4 v = f4_add(Y[b], bv);
+                    if (addend) {
+                        float4 a_ = ad[it][b];
+                        if (addend_mask) {
+                            const unsigned k = amk[it][b];
+                            a_ = make_float4((k & 1u) ? a_.x : 0.f, (k & 2u) ? a_.y : 0.f, (k & 4u) ? a_.z : 0.f, (k & 8u) ? a_.w : 0.f);
+                        }
+                        v = f4_add(v, a_);
+                    }
+                    if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                    if (W4_WHATIF & 1024) {
+                        if (b == 0 && it == 0) ssum = f4_add(ssum, v);
+                        continue;
+                    }
+                    if (ok[it][b]) {
+                        *reinterpret_cast<float4 *>(y + o[it][b]) = v;
+                        if (stats) {
+                            if (stat_mask) {
+                                const unsigned k = smk[it][b];
+                                v = make_float4((k & 1u) ? v.x : 0.f, (k & 2u) ? v.y : 0.f, (k & 4u) ? v.z : 0.f, (k & 8u) ? v.w : 0.f);
+                            }
+                            ssum = f4_add(ssum, v);
+                            if (stat_aux) {
+                                const float4 x_ = ax[it][b];
+                                ssq.x += v.x * (x_.x - smean.x) * sinv.x;
+                                ssq.y += v.y * (x_.y - smean.y) * sinv.y;
+                                ssq.z += v.z * (x_.z - smean.z) * sinv.z;
+                                ssq.w += v.w * (x_.w - smean.w) * sinv.w;
+                            } else {
+                                ssq.x += v.x * v.x;
+                                ssq.y += v.y * v.y;
+                                ssq.z += v.z * v.z;
+                                ssq.w += v.w * v.w;
+                            }
                         }
                     }
                 }
@@ -464,7 +635,7 @@ __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
 
 // U = G g G^T (6 x 6 positions, computed in double) in fragment order [36 P][Cout/32][Cin/8][64 lanes][4]: lane (n, h) element j
 // = U_P[cin 8 g + 4 h + j][cout 32 cb + n]; P = 9 w + s is the position owned by accumulator s of wave w:
-//   s < 6: (xi = s, nu = nuF(w)), nuF = 0, 2, 3, 5;   s >= 6: (xi = 3 (w & 1) + s - 6, nu = nuH(w)), nuH = 1, 1, 4, 4.
+//   s < 6: (xi = s, nu = nuF(w)), nuF = 0, 2, 3, 5;   s >= 6: nu = nuH(w) = 1, 1, 4, 4 and xi = 0, 1, 2 (w even) or 5, 3, 4 (w odd).
 // mode 0: forward filter g = w[cout][cin];  mode 1: data-gradient filter g[ky][kx] = w[k][n][2-ky][2-kx]
 __device__ __forceinline__ void wino4_pack_one(const float *__restrict__ w, float *__restrict__ u, int Cin_real, int K,
                                                int Nn, int mode, long idx, long total) {
@@ -499,7 +670,7 @@ __device__ __forceinline__ void wino4_pack_one(const float *__restrict__ w, floa
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
             const int nu = s < 6 ? (wv == 0 ? 0 : wv == 1 ? 2 : wv == 2 ? 3 : 5) : (wv < 2 ? 1 : 4);
-            const int xi = s < 6 ? s : 3 * (wv & 1) + s - 6;
+            const int xi = s < 6 ? s : (wv & 1) ? (s == 6 ? 5 : s - 4) : s - 6;
             const double v = tt[xi][0] * G[nu][0] + tt[xi][1] * G[nu][1] + tt[xi][2] * G[nu][2];
             u[(size_t)(wv * 9 + s) * (size_t)total + idx] = (float)v;
         }
@@ -589,11 +760,15 @@ extern "C" int adyolo_wino4_fwd(const float *x, const float *u, const float *bia
         blocks = cdiv(nsp, xcd_div) * 8;
     }
     hipStream_t st = as_stream(stream);
-#define ADYOLO_WINO4_FWD(TC_)                                                                                          \
-    hipLaunchKernelGGL((w4::wino4_fwd_kernel<TC_>), dim3((unsigned)blocks), dim3(256), 0, st, x, u, bias, addend,          \
+#define ADYOLO_WINO4_FWD(TC_, AFF_)                                                                                    \
+    hipLaunchKernelGGL((w4::wino4_fwd_kernel<TC_, AFF_>), dim3((unsigned)blocks), dim3(256), 0, st, x, u, bias, addend,    \
                        addend_mask, in_scale, in_shift, y, stats, stat_aux, stat_mean, stat_invstd, stat_mask, H, W, Cin, \
                        Cout, patchesW, patchesH, nsp, ncb, xcd_div, relu, mask_bits)
-    if (tc == 8) ADYOLO_WINO4_FWD(8); else ADYOLO_WINO4_FWD(4);
+    if (tc == 8) {
+        if (in_scale) ADYOLO_WINO4_FWD(8, true); else ADYOLO_WINO4_FWD(8, false);
+    } else {
+        if (in_scale) ADYOLO_WINO4_FWD(4, true); else ADYOLO_WINO4_FWD(4, false);
+    }
 #undef ADYOLO_WINO4_FWD
     return check_launch("wino4_fwd");
 }
