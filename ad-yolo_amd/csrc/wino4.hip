@@ -24,6 +24,7 @@
 // a nine-slot register ring (half a group = 2304 matrix cycles ahead).  Epilogue: the xi-sum of A^T . A in registers, the
 // nu-sum through LDS in four rounds (one output row of the tiles per round), then bias / masked addend / ReLU / per-patch
 // BatchNorm sums as in conv.hip.
+#include <type_traits>
 #include "wino_common.hpp"
 
 namespace adyolo {
@@ -32,6 +33,8 @@ namespace w4 {
 constexpr float PA = 0.75f, PB = 1.5f;                 // interpolation points +-PA, +-PB (besides 0 and infinity)
 constexpr float A2 = PA * PA, B2 = PB * PB, S2 = A2 + B2, P2 = A2 * B2;
 constexpr float A3 = PA * PA * PA, B3 = PB * PB * PB;
+
+typedef unsigned int u32x4_t __attribute__((__vector_size__(16)));
 
 template <int TC>
 struct Cfg {
@@ -469,6 +472,8 @@ __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
         smean = *reinterpret_cast<const float4 *>(stat_mean + co);
         sinv = *reinterpret_cast<const float4 *>(stat_invstd + co);
     }
+    const float rl = relu ? 0.f : -__builtin_inff();      // ReLU as a maximum with a wave-uniform floor
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(y + (size_t)n * H * W * Cout, 0, H * W * Cout * 4, 0x00020000);
     const float hc0 = hh ? 0.f : 1.f, hc3 = hh ? 1.f : 0.f, hk1 = hh ? PB : PA, hk2 = hh ? B2 : A2, hk3 = hh ? B3 : A3;
     // addresses / validity of the thread's pixels: tiles m0, m0 + 16 (it), output row p of the tile, columns b = 0..3
     const int etc0 = m0 & (TC - 1), etr0 = m0 >> C::LOG_TC;
@@ -500,118 +505,129 @@ __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int p = 2 * pp + e;
-            // the fused operands of the 8 pixels of this row pair first, all loads in flight together (one workgroup per CU: nobody
-            // else covers their latency); out-of-image pixels read the clamped address and are dropped at the store
-            size_t o[2][4];
-            bool ok[2][4];
-            float4 ad[2][4], ax[2][4];
-            unsigned amk[2][4], smk[2][4];                // 4-bit keep masks of the addend / of the statistics
+            // One body per combination of (statistics, addend, addend mask), chosen by wave-uniform branches ONCE per output row:
+            // inside the body there is no branch (a uniform branch per pixel and operand cost more than the arithmetic: the first
+            // version of this epilogue took 12 us per workgroup), the fused operands of the row's 8 pixels are requested together
+            // (one workgroup per CU: nobody else covers their latency), out-of-image pixels are stored to an out-of-range offset
+            // of the output's buffer descriptor and counted with weight 0.
+            auto body = [&](auto ST_, auto AD_, auto MK_) {
+                constexpr bool ST = decltype(ST_)::value, AD = decltype(AD_)::value, MK = decltype(MK_)::value;
+                int off[2][4];                                // byte offset of the pixel's channel quad inside the sample
+                bool ok[2][4];
+                float4 ad[2][4], ax[2][4];
+                unsigned amk[2][4], smk[2][4];                // 4-bit keep masks of the addend / of the statistics
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int gy = ty0 + 4 * (etr0 + it * DTR) + p;
+                for (int it = 0; it < 2; ++it) {
+                    const int gy = ty0 + 4 * (etr0 + it * DTR) + p;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int gx = tx0 + 4 * etc0 + b;
-                    ok[it][b] = gy < H && gx < W;
-                    o[it][b] = (((size_t)n * H + min(gy, H - 1)) * W + min(gx, W - 1)) * Cout + co;
-                }
-            }
-            if (addend) {
-#pragma unroll
-                for (int it = 0; it < 2; ++it)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) ad[it][b] = *reinterpret_cast<const float4 *>(addend + o[it][b]);
-                if (addend_mask) {
-#pragma unroll
-                    for (int it = 0; it < 2; ++it)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            bool kx, ky, kz, kw;
-                            if (mask_bits & 1) {
-                                mask_bits4(reinterpret_cast<const unsigned long long *>(addend_mask), o[it][b] >> 2, kx, ky, kz, kw);
-                            } else {
-                                const float4 mk = *reinterpret_cast<const float4 *>(addend_mask + o[it][b]);
-                                kx = mk.x > 0.f; ky = mk.y > 0.f; kz = mk.z > 0.f; kw = mk.w > 0.f;
-                            }
-                            amk[it][b] = (kx ? 1u : 0u) | (ky ? 2u : 0u) | (kz ? 4u : 0u) | (kw ? 8u : 0u);
-                        }
-                }
-            }
-            if (stats) {
-                if (stat_mask) {
-#pragma unroll
-                    for (int it = 0; it < 2; ++it)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            bool kx, ky, kz, kw;
-                            if (mask_bits & 2) {
-                                mask_bits4(reinterpret_cast<const unsigned long long *>(stat_mask), o[it][b] >> 2, kx, ky, kz, kw);
-                            } else {
-                                const float4 mk = *reinterpret_cast<const float4 *>(stat_mask + o[it][b]);
-                                kx = mk.x > 0.f; ky = mk.y > 0.f; kz = mk.z > 0.f; kw = mk.w > 0.f;
-                            }
-                            smk[it][b] = (kx ? 1u : 0u) | (ky ? 2u : 0u) | (kz ? 4u : 0u) | (kw ? 8u : 0u);
-                        }
-                }
-                if (stat_aux) {
-#pragma unroll
-                    for (int it = 0; it < 2; ++it)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) ax[it][b] = *reinterpret_cast<const float4 *>(stat_aux + o[it][b]);
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int m_ = m0 + it * 16;
-                float4 S[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    S[k] = *reinterpret_cast<const float4 *>(&Pb[e * C::EXCH + (k * 32 + m_) * CBP + c4 * 4]);
-                // Q[p][nu]: nu0 = S0, nu1 = S1 + S3, nu2 = S2, nu3 = S4, nu4 = S5 + S7, nu5 = S6
-                const float4 n1 = f4_add(S[1], S[3]), n4 = f4_add(S[5], S[7]);
-                float4 Y[4];
-                at4(S[0].x, n1.x, S[2].x, S[4].x, n4.x, S[6].x, Y[0].x, Y[1].x, Y[2].x, Y[3].x);
-                at4(S[0].y, n1.y, S[2].y, S[4].y, n4.y, S[6].y, Y[0].y, Y[1].y, Y[2].y, Y[3].y);
-                at4(S[0].z, n1.z, S[2].z, S[4].z, n4.z, S[6].z, Y[0].z, Y[1].z, Y[2].z, Y[3].z);
-                at4(S[0].w, n1.w, S[2].w, S[4].w, n4.w, S[6].w, Y[0].w, Y[1].w, Y[2].w, Y[3].w);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    float4 v = f4_add(Y[b], bv);
-                    if (addend) {
-                        float4 a_ = ad[it][b];
-                        if (addend_mask) {
-                            const unsigned k = amk[it][b];
-                            a_ = make_float4((k & 1u) ? a_.x : 0.f, (k & 2u) ? a_.y : 0.f, (k & 4u) ? a_.z : 0.f, (k & 8u) ? a_.w : 0.f);
-                        }
-                        v = f4_add(v, a_);
+                    for (int b = 0; b < 4; ++b) {
+                        const int gx = tx0 + 4 * etc0 + b;
+                        ok[it][b] = gy < H && gx < W;
+                        off[it][b] = ((min(gy, H - 1) * W + min(gx, W - 1)) * Cout + co) * 4;
                     }
-                    if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-                    if (W4_WHATIF & 1024) {
-                        if (b == 0 && it == 0) ssum = f4_add(ssum, v);
-                        continue;
+                }
+                const size_t sbase = (size_t)n * H * W * Cout;    // floats
+                auto keep4 = [&](const float *mptr, bool bits, int o_) {
+                    bool kx, ky, kz, kw;
+                    if (bits) {
+                        mask_bits4(reinterpret_cast<const unsigned long long *>(mptr), (sbase + (size_t)(o_ >> 2)) >> 2, kx, ky, kz, kw);
+                    } else {
+                        const float4 mk = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(mptr + sbase) + o_);
+                        kx = mk.x > 0.f; ky = mk.y > 0.f; kz = mk.z > 0.f; kw = mk.w > 0.f;
                     }
-                    if (ok[it][b]) {
-                        *reinterpret_cast<float4 *>(y + o[it][b]) = v;
-                        if (stats) {
-                            if (stat_mask) {
-                                const unsigned k = smk[it][b];
-                                v = make_float4((k & 1u) ? v.x : 0.f, (k & 2u) ? v.y : 0.f, (k & 4u) ? v.z : 0.f, (k & 8u) ? v.w : 0.f);
+                    return (kx ? 1u : 0u) | (ky ? 2u : 0u) | (kz ? 4u : 0u) | (kw ? 8u : 0u);
+                };
+                if (AD) {
+#pragma unroll
+                    for (int it = 0; it < 2; ++it)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            ad[it][b] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(addend + sbase) + off[it][b]);
+                    if (MK) {
+                        const bool bits = (mask_bits & 1) != 0;
+#pragma unroll
+                        for (int it = 0; it < 2; ++it)
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) amk[it][b] = keep4(addend_mask, bits, off[it][b]);
+                    }
+                }
+                const bool has_smk = ST && stat_mask != nullptr, has_aux = ST && stat_aux != nullptr;
+                if (has_smk) {
+                    const bool bits = (mask_bits & 2) != 0;
+#pragma unroll
+                    for (int it = 0; it < 2; ++it)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) smk[it][b] = keep4(stat_mask, bits, off[it][b]);
+                }
+                if (has_aux) {
+#pragma unroll
+                    for (int it = 0; it < 2; ++it)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            ax[it][b] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(stat_aux + sbase) + off[it][b]);
+                }
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int m_ = m0 + it * 16;
+                    float4 S[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        S[k] = *reinterpret_cast<const float4 *>(&Pb[e * C::EXCH + (k * 32 + m_) * CBP + c4 * 4]);
+                    // Q[p][nu]: nu0 = S0, nu1 = S1 + S3, nu2 = S2, nu3 = S4, nu4 = S5 + S7, nu5 = S6
+                    const float4 n1 = f4_add(S[1], S[3]), n4 = f4_add(S[5], S[7]);
+                    float4 Y[4];
+                    at4(S[0].x, n1.x, S[2].x, S[4].x, n4.x, S[6].x, Y[0].x, Y[1].x, Y[2].x, Y[3].x);
+                    at4(S[0].y, n1.y, S[2].y, S[4].y, n4.y, S[6].y, Y[0].y, Y[1].y, Y[2].y, Y[3].y);
+                    at4(S[0].z, n1.z, S[2].z, S[4].z, n4.z, S[6].z, Y[0].z, Y[1].z, Y[2].z, Y[3].z);
+                    at4(S[0].w, n1.w, S[2].w, S[4].w, n4.w, S[6].w, Y[0].w, Y[1].w, Y[2].w, Y[3].w);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        float4 v = f4_add(Y[b], bv);
+                        if (AD) {
+                            float4 a_ = ad[it][b];
+                            if (MK) {
+                                const unsigned k = amk[it][b];
+                                a_ = make_float4((k & 1u) ? a_.x : 0.f, (k & 2u) ? a_.y : 0.f, (k & 4u) ? a_.z : 0.f, (k & 8u) ? a_.w : 0.f);
                             }
+                            v = f4_add(v, a_);
+                        }
+                        v = make_float4(fmaxf(v.x, rl), fmaxf(v.y, rl), fmaxf(v.z, rl), fmaxf(v.w, rl));
+                        if (!(W4_WHATIF & 1024))
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yrs,
+                                                                   ok[it][b] ? off[it][b] : (int)0x80000000, 0, 0);
+                        if (ST) {
+                            // out-of-image pixels and masked-out components count 0
+                            unsigned k = ok[it][b] ? 15u : 0u;
+                            if (has_smk) k &= smk[it][b];
+                            v = make_float4((k & 1u) ? v.x : 0.f, (k & 2u) ? v.y : 0.f, (k & 4u) ? v.z : 0.f, (k & 8u) ? v.w : 0.f);
                             ssum = f4_add(ssum, v);
-                            if (stat_aux) {
+                            float4 w_ = v;
+                            if (has_aux) {
                                 const float4 x_ = ax[it][b];
-                                ssq.x += v.x * (x_.x - smean.x) * sinv.x;
-                                ssq.y += v.y * (x_.y - smean.y) * sinv.y;
-                                ssq.z += v.z * (x_.z - smean.z) * sinv.z;
-                                ssq.w += v.w * (x_.w - smean.w) * sinv.w;
-                            } else {
-                                ssq.x += v.x * v.x;
-                                ssq.y += v.y * v.y;
-                                ssq.z += v.z * v.z;
-                                ssq.w += v.w * v.w;
+                                w_ = make_float4((x_.x - smean.x) * sinv.x, (x_.y - smean.y) * sinv.y, (x_.z - smean.z) * sinv.z,
+                                                 (x_.w - smean.w) * sinv.w);
                             }
+                            ssq.x = fmaf(v.x, w_.x, ssq.x);
+                            ssq.y = fmaf(v.y, w_.y, ssq.y);
+                            ssq.z = fmaf(v.z, w_.z, ssq.z);
+                            ssq.w = fmaf(v.w, w_.w, ssq.w);
                         }
                     }
+                }
+            };
+            using T_ = std::true_type;
+            using F_ = std::false_type;
+            if (stats) {
+                if (addend) {
+                    if (addend_mask) body(T_{}, T_{}, T_{}); else body(T_{}, T_{}, F_{});
+                } else {
+                    body(T_{}, F_{}, F_{});
+                }
+            } else {
+                if (addend) {
+                    if (addend_mask) body(F_{}, T_{}, T_{}); else body(F_{}, T_{}, F_{});
+                } else {
+                    body(F_{}, F_{}, F_{});
                 }
             }
         }

@@ -198,7 +198,7 @@ class SEResnet34(nn.Module):
         link = None                              # BlockLink between consecutive blocks (functional.FUSE_SEBWD)
         blocks = [blk for li in range(1, 5) for blk in getattr(self, "layer%d" % li)]
         packs = None
-        if ops.conv_algo() == "winograd":        # every block filter packed by ONE launch (64 otherwise)
+        if ops.conv_algo() in ("winograd", "winograd4"):     # every block filter packed by ONE launch (two with winograd4)
             packs = self._packs.refresh([w for blk in blocks for w in (blk.conv1.weight, blk.conv2.weight)],
                                         frozen=not self.training)
         for bi, blk in enumerate(blocks):

@@ -119,18 +119,22 @@ def params_changed():
 
 # ---------------------------------------------------------------------------------------------- conv
 def conv_algo():
-    """'winograd4' (F(4x4,3x3) on the fp32 MFMA where the shape allows it -- 4x fewer matrix FLOPs than the direct form --
-    and F(2x2,3x3) elsewhere), 'winograd' (F(2x2,3x3) everywhere, 2.25x fewer) or 'direct' (implicit GEMM); chosen per call
-    of ``pack_w3x3`` / ``WinoPackSet.refresh`` from ADYOLO_CONV_ALGO."""
-    a = os.environ.get("ADYOLO_CONV_ALGO", "winograd").lower()
+    """'winograd4' (default since round 4: F(4x4,3x3) on the fp32 MFMA where ``_w4_eligible`` says so -- 4x fewer matrix FLOPs
+    than the direct form -- and F(2x2,3x3) elsewhere), 'winograd' (F(2x2,3x3) everywhere, 2.25x fewer) or 'direct' (implicit
+    GEMM); chosen per call of ``pack_w3x3`` / ``WinoPackSet.refresh`` from ADYOLO_CONV_ALGO."""
+    a = os.environ.get("ADYOLO_CONV_ALGO", "winograd4").lower()
     if a not in ("winograd4", "winograd", "direct"):
         raise _lib.AdyoloHipError("ADYOLO_CONV_ALGO must be 'winograd4', 'winograd' or 'direct' (got %r)" % a)
     return a
 
 
 def _w4_eligible(k_gemm, n_gemm):
-    """F(4x4,3x3) kernel (csrc/wino4.hip): 64 output channels per workgroup, 16-channel pairs of the contraction."""
-    return n_gemm % 64 == 0 and k_gemm % 32 == 0 and k_gemm <= 512
+    """Does this GEMM direction (contraction over k_gemm channels, n_gemm output channels) run on the F(4x4,3x3) kernel
+    (csrc/wino4.hip)?  The kernel needs 64 output channels per workgroup and 16-channel pairs of the contraction; it beats
+    the F(2x2) kernel from 128 contraction channels on (its per-workgroup prologue / epilogue is not overlapped: one workgroup
+    per CU) -- 1.30-1.47 x per plain launch at 128 / 256 channels, 1.2 x at 64 but below 1 with the fused operands there
+    ("F(4x4,3x3), round 4"); ADYOLO_W4_MIN_K moves the threshold."""
+    return n_gemm % 64 == 0 and k_gemm % 32 == 0 and int(os.environ.get("ADYOLO_W4_MIN_K", "128")) <= k_gemm <= 512
 
 
 def math_mode():
@@ -204,29 +208,46 @@ class WinoPackSet:
         """frozen (evaluation mode): skip the launch when nothing was written to the filters since the last one
         (``PARAMS_EPOCH`` for in-place kernels, the tensors' version counters for ``copy_`` / ``load_state_dict``)."""
         math = math_mode()
-        key = (math,) + tuple(w.data_ptr() for w in weights)
+        w4 = conv_algo() == "winograd4"
+        key = (math, w4, os.environ.get("ADYOLO_W4_MIN_K")) + tuple(w.data_ptr() for w in weights)
         stamp = (PARAMS_EPOCH[0],) + tuple(w._version for w in weights)
         if frozen and key == self.key and stamp == self.stamp:
             return self
         self.stamp = stamp
         if key != self.key:
             dev = weights[0].device
-            self.packs, rows = [], []
+            self.packs, rows, rows4 = [], [], []
             for w in weights:
                 _chk(w)
                 cout, cin = w.shape[0], w.shape[1]
                 if cout % 32 or cin % 32:
                     raise _lib.AdyoloHipError("WinoPackSet: channel counts must be multiples of 32")
-                fb, db = _b3_eligible(cin, math), _b3_eligible(cout, math)
-                uf = _new(w, 16, cout // 32, cin // 16, 768) if fb else _new(w, 16, cout // 32, cin // 8, 256)
-                ud = _new(w, 16, cin // 32, cout // 16, 768) if db else _new(w, 16, cin // 32, cout // 8, 256)
+                # per direction: F(4x4) form [36][N/32][K/8][256] where it applies (winograd4), else F(2x2) (fp32 or bf16x3)
+                f4, d4 = w4 and _w4_eligible(cin, cout), w4 and _w4_eligible(cout, cin)
+                fb, db = not f4 and _b3_eligible(cin, math), not d4 and _b3_eligible(cout, math)
+                if f4:
+                    uf = _new(w, 36, cout // 32, cin // 8, 256)
+                else:
+                    uf = _new(w, 16, cout // 32, cin // 16, 768) if fb else _new(w, 16, cout // 32, cin // 8, 256)
+                if d4:
+                    ud = _new(w, 36, cin // 32, cout // 8, 256)
+                else:
+                    ud = _new(w, 16, cin // 32, cout // 16, 768) if db else _new(w, 16, cin // 32, cout // 8, 256)
                 self.packs.append((uf, ud))
-                rows.append([w.data_ptr(), uf.data_ptr(), ud.data_ptr(), cout, cin, cin, int(fb), int(db)])
-            self.table = torch.tensor(rows, dtype=torch.int64, device=dev)
+                if not (f4 and d4):
+                    rows.append([w.data_ptr(), 0 if f4 else uf.data_ptr(), 0 if d4 else ud.data_ptr(), cout, cin, cin, int(fb), int(db)])
+                if f4 or d4:
+                    rows4.append([w.data_ptr(), uf.data_ptr() if f4 else 0, ud.data_ptr() if d4 else 0, cout, cin, cin, 0, 0])
+            self.table = torch.tensor(rows, dtype=torch.int64, device=dev) if rows else None
+            self.table4 = torch.tensor(rows4, dtype=torch.int64, device=dev) if rows4 else None
+            self.nrows, self.nrows4 = len(rows), len(rows4)
             self.max_cout = max(w.shape[0] for w in weights)
             self.max_cin = max(w.shape[1] for w in weights)
             self.key = key
-        _c("adyolo_wino_pack_many", _p(self.table), len(self.packs), self.max_cout, self.max_cin, _stream())
+        if self.table is not None:
+            _c("adyolo_wino_pack_many", _p(self.table), self.nrows, self.max_cout, self.max_cin, _stream())
+        if self.table4 is not None:
+            _c("adyolo_wino4_pack_many", _p(self.table4), self.nrows4, self.max_cout, self.max_cin, _stream())
         return self
 
     def get(self, i):
@@ -280,7 +301,7 @@ def conv3x3_wgrad(x, dy, cin_real, in_affine=None, algo=None, out=None):
     sc, sh = in_affine if in_affine is not None else (None, None)
     dw = out if out is not None else _new(x, cout, cin_real, 3, 3)      # out: e.g. the parameter's slice of the flat gradient buffer
     algo = algo or os.environ.get("ADYOLO_WGRAD_ALGO") or conv_algo()
-    if algo == "winograd" and cin % 32 == 0 and cout % 32 == 0:
+    if algo in ("winograd", "winograd4") and cin % 32 == 0 and cout % 32 == 0:      # (the weight gradient has the F(2x2) form only)
         nslab = _lib.load().adyolo_wino_wgrad_slabs(n, h, w, cin, cout)
         if nslab <= 0:
             raise _lib.AdyoloHipError("wino_wgrad_slabs rejected the shape")

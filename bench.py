@@ -128,6 +128,14 @@ class KernelTimer:
         return len(recs), ms, float(sum(w[0] for _, _, w in recs)), float(sum(w[1] for _, _, w in recs))
 
 
+def _issued_share(wpk):
+    """matrix FLOPs issued / direct-convolution FLOPs for a packed filter: Winograd F(4x4,3x3) 36 multiplies per 144 (first
+    axis 36), F(2x2,3x3) 16 per 36 (first axis 16), direct form 1"""
+    if wpk.dim() != 4:
+        return 1.0
+    return 9.0 / 36.0 if wpk.shape[0] == 36 else 16.0 / 36.0
+
+
 def load_traffic(wino):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r0N_traffic.json: rocprofv3
     --pmc FETCH_SIZE and --pmc WRITE_SIZE over this same command, corrected as MI355X_MICROARCH.md prescribes);
@@ -353,7 +361,7 @@ def _run_extra_config(name, cfg, torch, modes):
             kt.wrap(_ops, "attn_bwd", "attention backward (7 products)",
                     lambda q, *a, **kw: fl(14.0 * q.shape[0] * q.shape[1] ** 2 * q.shape[2]))
             kt.wrap(_ops, "conv3x3", "Winograd 3x3 forward / dgrad [issued FLOPs]",
-                    lambda x, wpk, cout, **kw: fl(2.0 * x.shape[0] * x.shape[1] * x.shape[2] * cout * 9 * x.shape[3] * (16.0 / 36.0 if wpk.dim() == 4 else 1.0)))
+                    lambda x, wpk, cout, **kw: fl(2.0 * x.shape[0] * x.shape[1] * x.shape[2] * cout * 9 * x.shape[3] * (_issued_share(wpk))))
             kt.wrap(_ops, "conv3x3_wgrad", "Winograd 3x3 weight-gradient [issued FLOPs]",
                     lambda x, dy, cin_real, **kw: fl(2.0 * x.shape[0] * x.shape[1] * x.shape[2] * dy.shape[3] * 9 * x.shape[3] * 16.0 / 36.0))
             torch.manual_seed(100)
@@ -472,7 +480,8 @@ def main():
     fx = FeatureExtractor(None, device)
     audio = synthetic_audio(B, n_samples, seed=1234 + rank).to(device)
     target = synthetic_targets(B, T // 4, 12, seed=1234 + rank).to(device)
-    wino = ops.conv_algo() == "winograd"
+    conv_algo = ops.conv_algo()
+    wino = conv_algo in ("winograd", "winograd4")
 
     # parity gate at the benchmark shape: the first forward loss with the benchmarked (Winograd) convolutions must equal
     # the direct implicit-GEMM path within 1e-3 (both are checked against torch / the oracle in tests/)
@@ -482,14 +491,15 @@ def main():
         vals = {}
         with torch.no_grad():
             feat = fx(audio, channels_last8=True)
-            for algo in ("winograd", "direct"):
+            for algo in (conv_algo, "direct"):
                 os.environ["ADYOLO_CONV_ALGO"] = algo
                 model.encoder.dropout_stream.offset = 0    # same inter-layer GRU dropout mask for both runs
                 vals[algo] = float(criterion(model(feat, channels_last8=True), target))
             del feat
-        os.environ["ADYOLO_CONV_ALGO"] = "winograd"
+        os.environ["ADYOLO_CONV_ALGO"] = conv_algo
+        vals["winograd"] = vals[conv_algo]
         rel = abs(vals["winograd"] - vals["direct"]) / abs(vals["direct"])
-        parity = {"first_loss_winograd": round(vals["winograd"], 6), "first_loss_direct": round(vals["direct"], 6),
+        parity = {"algo": conv_algo, "first_loss_winograd": round(vals["winograd"], 6), "first_loss_direct": round(vals["direct"], 6),
                   "rel_diff": float("%.3g" % rel), "tol": 1e-3}
         assert rel <= 1e-3, "Winograd vs direct loss at the bench shape: %r" % (vals,)
         torch.manual_seed(100)                     # BatchNorm running statistics moved: rebuild the model
@@ -501,7 +511,7 @@ def main():
 
     def conv_work(x, wpk, cout, **kw):
         alg = 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * cout * 9 * x.shape[3]
-        return alg, alg * (16.0 / 36.0 if wpk.dim() == 4 else 1.0)
+        return alg, alg * _issued_share(wpk)
 
     def wgrad_work(x, dy, cin_real, **kw):
         alg = 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * dy.shape[3] * 9 * x.shape[3]

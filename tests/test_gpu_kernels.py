@@ -62,8 +62,9 @@ def assert_close(got, ref, tol, what):
     (5, 8, 16, 512, 64, True, False, False),     # deepest reduction the Winograd affine table allows (Cin = 512)
     (7, 24, 16, 32, 128, False, False, False),   # one-chunk variant, 21 patches on 4 channel blocks (ragged block deal)
 ])
-@pytest.mark.parametrize("algo", ["direct", "winograd"])
-def test_conv3x3_forward(ops, n, h, w, cin, cout, relu, bias, addend, algo):
+@pytest.mark.parametrize("algo", ["direct", "winograd", "winograd4"])
+def test_conv3x3_forward(ops, monkeypatch, n, h, w, cin, cout, relu, bias, addend, algo):
+    monkeypatch.setenv("ADYOLO_W4_MIN_K", "32")      # winograd4: the F(4x4) kernel wherever the shape allows it (else F(2x2))
     g = torch.Generator().manual_seed(n * 1000 + h * 10 + cin)
     x = torch.randn(n, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
@@ -79,7 +80,8 @@ def test_conv3x3_forward(ops, n, h, w, cin, cout, relu, bias, addend, algo):
     if cin_p != cin:
         xg = dev(F.pad(nhwc(x), (0, cin_p - cin)))
     wpk, _ = ops.pack_w3x3(dev(wt), cin_p, want_dgrad=False, algo=algo)
-    assert (wpk.dim() == 4) == (algo == "winograd" and cin != 7)
+    assert (wpk.dim() == 4) == (algo != "direct" and cin != 7)
+    assert (wpk.shape[0] == 36) == (algo == "winograd4" and cin != 7 and cout % 64 == 0)
     y = ops.conv3x3(xg, wpk, cout, bias=dev(b) if bias else None, addend=dev(nhwc(add)) if addend else None, relu=relu)
     torch.cuda.synchronize()
     assert_close(nchw(y), ref, 2e-5, "conv3x3 fwd (%s)" % algo)
@@ -92,8 +94,9 @@ def test_conv3x3_forward(ops, n, h, w, cin, cout, relu, bias, addend, algo):
     (2, 21, 19, 96, 32),         # odd H and W (general masking path), 3 input-channel blocks
     (3, 11, 37, 7, 32), (1, 5, 64, 7, 32), (5, 3, 6, 7, 32),    # stem weight-gradient kernel: odd W, fewer rows than waves
 ])
-@pytest.mark.parametrize("algo", ["direct", "winograd"])
-def test_conv3x3_dgrad_wgrad(ops, n, h, w, cin, cout, algo):
+@pytest.mark.parametrize("algo", ["direct", "winograd", "winograd4"])
+def test_conv3x3_dgrad_wgrad(ops, monkeypatch, n, h, w, cin, cout, algo):
+    monkeypatch.setenv("ADYOLO_W4_MIN_K", "32")
     g = torch.Generator().manual_seed(7 + cin + cout)
     x = torch.randn(n, cin, h, w, generator=g, requires_grad=True)
     wt = (torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)).requires_grad_(True)
@@ -112,10 +115,11 @@ def test_conv3x3_dgrad_wgrad(ops, n, h, w, cin, cout, algo):
         assert_close(nchw(dx), x.grad, 2e-5, "conv3x3 dgrad (%s)" % algo)
 
 
-@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 20, 64, 32, 32), (3, 17, 16, 64, 128), (2, 9, 32, 32, 64)])
-@pytest.mark.parametrize("algo", ["direct", "winograd"])
-def test_conv3x3_fused_affine_mask_stats(ops, n, h, w, cin, cout, algo):
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 20, 64, 32, 32), (3, 17, 16, 64, 128), (2, 9, 32, 32, 64), (2, 37, 16, 128, 64)])
+@pytest.mark.parametrize("algo", ["direct", "winograd", "winograd4"])
+def test_conv3x3_fused_affine_mask_stats(ops, monkeypatch, n, h, w, cin, cout, algo):
     """in_affine (producer BN affine applied while staging; padding stays zero), masked addend, epilogue statistics."""
+    monkeypatch.setenv("ADYOLO_W4_MIN_K", "32")
     g = torch.Generator().manual_seed(h * 7 + cin)
     x = torch.randn(n, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
@@ -544,7 +548,7 @@ def _params(nb_classes=12):
                              "optim": "Adam", "lr": 1e-3, "weight_decay": 0.0}}
 
 
-@pytest.mark.parametrize("algo", ["direct", "winograd"])
+@pytest.mark.parametrize("algo", ["direct", "winograd", "winograd4", "winograd4-all"])
 def test_wrapper_model_matches_reference_golden(ops, monkeypatch, algo):
     """Forward outputs (eval and train mode) hold the 1e-3 bar with either convolution algorithm, and every kernel on
     its own holds 2e-5 against torch.  Whole-model gradients on this golden (random filler weights, 34 normalised
@@ -555,6 +559,9 @@ def test_wrapper_model_matches_reference_golden(ops, monkeypatch, algo):
       winograd  -- activations differ from the direct run by <= 7e-6, which flips two ReLU masks of pre-activations
                    within 1e-6 of zero; a flipped mask is a different (equally valid) subgradient and moves the weight
                    gradients of those blocks by up to 1.7e-2 of absmax.  Bound: 5e-2 of absmax and 0.999 cosine."""
+    if algo == "winograd4-all":                      # the F(4x4) kernel on every eligible layer, not only from 128 channels on
+        monkeypatch.setenv("ADYOLO_W4_MIN_K", "32")
+        algo = "winograd4"
     monkeypatch.setenv("ADYOLO_CONV_ALGO", algo)
     from oracle.filler import fill_module_
     from adyolo_amd.wrapper import WrapperModel

@@ -77,7 +77,7 @@ def _align_relu_masks(model, captured, g, bits=None):
     return flips
 
 
-@pytest.mark.parametrize("algo", ["direct", "winograd"])
+@pytest.mark.parametrize("algo", ["direct", "winograd", "winograd4"])
 def test_seed100_training_step_matches_reference(ops, monkeypatch, algo):
     """One training step at the reference's training shape (2, 7, 800, 64) with the reference's default initialisation
     under torch.manual_seed(100) (src/main.py:47; the build's init is bit-identical, test_host_cpu.py), against
@@ -213,14 +213,18 @@ def test_training_trajectories_direct_vs_winograd(ops, monkeypatch):
         losses = torch.stack([tr.step(audio, target).reshape(()) for _ in range(steps)])
         return losses.cpu().double().numpy()
 
-    a, w, a2 = run("direct"), run("winograd"), run("direct", fuse_bnbwd=False)
-    assert np.all(np.isfinite(a)) and np.all(np.isfinite(w))
-    assert abs(a[0] - w[0]) <= 1e-5 * abs(a[0]) and abs(a[0] - a2[0]) <= 1e-6 * abs(a[0])
-    rel, noise = np.abs(a - w) / np.abs(a), np.abs(a - a2) / np.abs(a)
-    print("direct %.5f -> %.5f, winograd %.5f -> %.5f, worst relative gap %.2e (same-algorithm round-off yardstick %.2e)"
-          % (a[0], a[-1], w[0], w[-1], rel.max(), noise.max()))
-    assert rel.max() <= max(2e-3, 3 * noise.max()), (rel, noise)
-    assert a[-1] < 0.7 * a[0] and w[-1] < 0.7 * w[0]
+    a, a2 = run("direct"), run("direct", fuse_bnbwd=False)
+    noise = np.abs(a - a2) / np.abs(a)
+    assert abs(a[0] - a2[0]) <= 1e-6 * abs(a[0])
+    for algo in ("winograd", "winograd4"):          # F(2x2,3x3) everywhere; F(4x4,3x3) from 128 channels on (round 4)
+        w = run(algo)
+        assert np.all(np.isfinite(a)) and np.all(np.isfinite(w))
+        assert abs(a[0] - w[0]) <= 1e-5 * abs(a[0])
+        rel = np.abs(a - w) / np.abs(a)
+        print("direct %.5f -> %.5f, %s %.5f -> %.5f, worst relative gap %.2e (same-algorithm round-off yardstick %.2e)"
+              % (a[0], a[-1], algo, w[0], w[-1], rel.max(), noise.max()))
+        assert rel.max() <= max(2e-3, 3 * noise.max()), (algo, rel, noise)
+        assert a[-1] < 0.7 * a[0] and w[-1] < 0.7 * w[0]
 
 
 # ------------------------------------------------------------------------------ the reference's evaluation shape
@@ -307,12 +311,15 @@ BENCH_STAGES = [  # (Cin, Cout, H, W) of the 3x3 convolutions of stages 1-4 at 6
 
 
 @pytest.mark.parametrize("cin,cout,h,w", BENCH_STAGES)
-@pytest.mark.parametrize("algo", ["winograd", "direct"])
-def test_conv3x3_at_bench_shape_slices(ops, algo, cin, cout, h, w):
+@pytest.mark.parametrize("algo", ["winograd4", "winograd", "direct"])
+def test_conv3x3_at_bench_shape_slices(ops, monkeypatch, algo, cin, cout, h, w):
     """conv3x3 forward, data-gradient and weight-gradient launched at the FULL benchmark shape (N = 64 clips); forward and
     data-gradient are compared on two clips x 64 rows (first clip/top rows incl. the zero padding, last clip/an interior
     window crossing patch boundaries) with F.conv2d on the slice (2e-5 of absmax), the weight-gradient on an 8 x 8
     (Cout, Cin) block against a float64 contraction over ALL N*H*W pixels (5e-5 of absmax: 9.8 M-term fp32 sums)."""
+    monkeypatch.setenv("ADYOLO_W4_MIN_K", "32")      # winograd4: the F(4x4) kernel at every stage it can run (Cout % 64 == 0)
+    if algo == "winograd4" and cout % 64:
+        pytest.skip("the F(4x4) kernel needs 64 output channels per workgroup: this stage runs the F(2x2) kernel")
     n = 64
     gen = torch.Generator(device="cuda:0").manual_seed(cin * 7 + cout)
     x = torch.randn(n, h, w, cin, generator=gen, device="cuda:0")
@@ -450,7 +457,7 @@ def test_bench_shape_step_loss_direct_vs_winograd(ops, monkeypatch):
     target = synthetic_targets(b, t // 4, 12, seed=1234).to("cuda:0")
     fx = FeatureExtractor(None, "cuda:0")
     vals = {}
-    for algo in ("winograd", "direct"):
+    for algo in ("winograd4", "winograd", "direct"):
         monkeypatch.setenv("ADYOLO_CONV_ALGO", algo)
         torch.manual_seed(100)
         prm = bench.params("cuda:0")
@@ -462,7 +469,8 @@ def test_bench_shape_step_loss_direct_vs_winograd(ops, monkeypatch):
         del model, out
         torch.cuda.empty_cache()
     print(vals)
-    assert np.isfinite(vals["winograd"]) and abs(vals["winograd"] - vals["direct"]) <= 1e-3 * abs(vals["direct"])
+    for algo in ("winograd4", "winograd"):
+        assert np.isfinite(vals[algo]) and abs(vals[algo] - vals["direct"]) <= 1e-3 * abs(vals["direct"]), (algo, vals)
 
 
 # ------------------------------------------------------------------------------ data-parallel path on one GPU (RCCL, 1 rank)

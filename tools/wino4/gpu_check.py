@@ -6,6 +6,8 @@ import argparse
 import os
 import sys
 
+os.environ.setdefault("ADYOLO_W4_MIN_K", "32")      # the F(4x4) kernel at every eligible shape, not only where the library would choose it
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
