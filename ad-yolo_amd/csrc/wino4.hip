@@ -355,33 +355,35 @@ __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
     // The pair loop is a hand-placed software pipeline of 36 steps (step = one accumulator tile's four MFMAs = 256 matrix
     // cycles), pinned with __builtin_amdgcn_sched_barrier(0): left alone, the scheduler sinks every load to just above its
     // use (first version: each B refill followed by its own vmcnt wait).  Per step: [side work + 4 MFMAs] | the step's loads.
-    //   B ring: the fragment of step t + 9 is requested right after step t (2304 matrix cycles ahead);
+    //   B ring: the fragment of step t + BR is requested right after step t (BR = 9: 2304 matrix cycles ahead);
     //   A fragments: fragments 0..5 (6..8) of the pair's second group are read at step 8 (16) and transformed under step 12
-    //   (18), i.e. right after the first group's MFMAs on those registers are issued; the first group's are made after the
-    //   pair's barrier (the six of the full column before step 0, the rest under step 2);
+    //   (18), i.e. right after the first group's MFMAs on those registers are issued;
     //   staging of the next pair (two register sets A, B): round 0 (A) transformed under step 4, written under 6; round 1 (B)
-    //   transformed under 14, written under 16; leftover rows requested at 17 (B), written (one wave) under 32; rounds 0 / 1 of
-    //   the pair after requested at 16 (A) / 34 (B).
-    for (int pr = 0; pr < npairs; ++pr) {
+    //   transformed under 12, written under 14; leftover rows requested at 8 (A), written (one wave) under 22; rounds 0 / 1 of
+    //   the pair after requested at 25 (A) / 16 (B);
+    //   the pair's ONE barrier sits after step 24, not at the end: every write of the next pair's image is done by then, and
+    //   the buffers they went to were last read at step 16 of the pair before -- so the next pair's first A fragments are
+    //   read at steps 28 / 32 and transformed under step 30 (full column; the half column follows under step 2 of the next
+    //   pair), and the first MFMA of a pair never waits for an LDS round trip and a transform.
+    auto pair_bases = [&](int pr) {
         const int pboff = (pr & 1) * (2 * CBUF * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bF[j] = oF[j] + pboff;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            bH[j] = oH[j] + pboff;
+            bZ[j] = oZ[j] + pboff;
+        }
+    };
+    pair_bases(0);
+    a_reads_full(0);
+    a_xform_full();
+    a_reads_half(0);
+    for (int pr = 0; pr < npairs; ++pr) {
         float *Cn = lds + ((pr + 1) & 1) * (2 * CBUF);
         const int prn = pr + 1 < npairs ? pr + 1 : npairs - 1;                 // pair being staged (clamped)
         const int prn2 = pr + 2 < npairs ? pr + 2 : npairs - 1;
         const bool lwave = wave == (pr & 3);                                   // this wave stages the leftover rows of the pair
-        if (!(W4_WHATIF & 4) || pr == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bF[j] = oF[j] + pboff;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                bH[j] = oH[j] + pboff;
-                bZ[j] = oZ[j] + pboff;
-            }
-            a_reads_full(0);
-            __builtin_amdgcn_sched_barrier(0);
-            a_xform_full();
-            __builtin_amdgcn_sched_barrier(0);
-            a_reads_half(0);
-        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -398,18 +400,19 @@ __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
                         if (step == 2) a_xform_half();
                         if (step == 12) a_xform_full();
                         if (step == 18) a_xform_half();
+                        if (step == 30) a_xform_full();                        // the next pair's first group
                     }
                     if (!(W4_WHATIF & 1)) {
                         if (!(W4_WHATIF & 64)) {
                             if (step == 4) st_xform(pvA, 0, prn);
-                            if (step == 14) st_xform(pvB, 1, prn);
+                            if (step == 12) st_xform(pvB, 1, prn);
                         }
                         if (!(W4_WHATIF & 128)) {
                             if (step == 6) st_write(pvA, 0, Cn);
-                            if (step == 16) st_write(pvB, 1, Cn);
+                            if (step == 14) st_write(pvB, 1, Cn);
                         }
                         if (!(W4_WHATIF & 256))
-                            if (step == 32 && lwave) st_store(pvB, 2, Cn, prn);
+                            if (step == 22 && lwave) st_store(pvA, 2, Cn, prn);
                     }
                     if (W4_WHATIF & 16) {
                         asm volatile("" : "+v"(a[s].x), "+v"(a[s].y), "+v"(a[s].z), "+v"(a[s].w));
@@ -430,26 +433,32 @@ __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
                     __builtin_amdgcn_sched_barrier(0);
                     // ---- loads of the step
                     if (!(W4_WHATIF & 2)) bq[slot] = uu + BR < 18 ? bload(uu + BR, kg) : bload(uu + BR - 18, kgn);
+                    if (step == 24) {
+                        __syncthreads();                                       // the next pair's image is complete
+                        pair_bases(pr + 1);
+                    }
                     if (!(W4_WHATIF & 4) || pr == 0) {
                         if (step == 8) a_reads_full(1);
                         if (step == 16) a_reads_half(1);
+                        if (step == 28) a_reads_full(0);                       // (bases: the next pair's already)
+                        if (step == 32) a_reads_half(0);
                     }
                     if (!(W4_WHATIF & 1)) {
                         if (!(W4_WHATIF & 32)) {
-                            if (step == 16) st_load(pvA, 0, prn2, true);
-                            if (step == 34) st_load(pvB, 1, prn2, true);
+                            if (step == 25) st_load(pvA, 0, prn2, true);
+                            if (step == 16) st_load(pvB, 1, prn2, true);
                         }
                         // the leftover rows: every wave issues the loads (all lanes out of range unless it is its turn), so that
-                        // the compiler's vmcnt bookkeeping is the same on both sides of the branch under step 32
+                        // the compiler's vmcnt bookkeeping is the same on both sides of the branch under step 22
                         if (!(W4_WHATIF & (32 | 256)))
-                            if (step == 17) st_load(pvB, 2, prn, lwave);
+                            if (step == 8) st_load(pvA, 2, prn, lwave);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
-        __syncthreads();
     }
+    __syncthreads();                                      // (the epilogue reuses the LDS image)
 
     // ---- epilogue.  xi-sum of A^T . A in registers: Q[p] (p = output row inside the tile) of the full column and the partial
     // one of the half column; nu-sum through LDS, TWO output rows p per round (2 x 72 KB): slot 2 w = full column of wave w,

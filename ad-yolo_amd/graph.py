@@ -15,6 +15,9 @@ varies from batch to batch) is padded to a fixed capacity with rows the assignme
 
 Results are bit-identical to the eager path (tests/test_gpu_graph.py compares losses and parameters with torch.equal).
 """
+import contextlib
+import gc
+
 import torch
 
 from . import functional as Fn
@@ -22,6 +25,22 @@ from . import ops
 from . import rng as _rng
 
 TARGET_QUANTUM = 4096          # AD-YOLO target rows are padded up to a multiple of this (bounds the number of graphs)
+
+
+@contextlib.contextmanager
+def _quiet_collector():
+    """No garbage collection while a stream is capturing: a recorded graph whose last reference dies in a collection that
+    happens to run DURING another capture is destroyed there (``~CUDAGraph`` -> hipGraphDestroy), which HIP refuses with
+    "operation not permitted when stream is capturing" and the process aborts (seen once in ten runs of bench.py's
+    extra_configs, round 4).  Collect first, then keep the collector off until the capture has ended."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class _Entry:
@@ -93,7 +112,7 @@ class StepGraphs:
             s.sync_device()
         graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(graph):
+            with _quiet_collector(), torch.cuda.graph(graph):
                 loss = tr.step_eager(ent.audio, ent.target)
                 for s in self.streams:
                     ops.counter_add_(s.dev, s.offset - s.capture_base)
@@ -169,7 +188,7 @@ class ForwardGraphs:
                     return self._run(audio)
                 static = audio.clone()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with _quiet_collector(), torch.cuda.graph(graph):
                     outs = self._run(static)
                 ent = (graph, static, outs)
                 self.entries[key] = ent

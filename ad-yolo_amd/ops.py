@@ -195,6 +195,20 @@ def pack_w3x3(w, cin_pad, want_dgrad=True, algo=None, math=None):
     return wf, wd
 
 
+class DualPack:
+    """Both Winograd forms of one filter direction: ``f4`` [36][N/32][K/8][256] for the F(4x4,3x3) kernel, ``f2`` [16][...] for
+    the F(2x2) kernel.  ``conv3x3`` takes the F(4x4) form when its launch fills the chip and the F(2x2) form for small grids
+    (one workgroup per CU and 32 x 16 / 16 x 32-pixel patches: a single 60 s clip is 76 workgroups at stage 4)."""
+    __slots__ = ("f4", "f2")
+
+    def __init__(self, f4, f2):
+        self.f4, self.f2 = f4, f2
+
+    def pick(self, n, h, w, cout):
+        wgs = _lib.load().adyolo_wino4_tiles(n, h, w) * (cout // 64)
+        return self.f4 if wgs >= int(os.environ.get("ADYOLO_W4_MIN_WGS", "200")) else self.f2
+
+
 class WinoPackSet:
     """The Winograd-packed forms (forward + data-gradient) of a fixed list of 3x3 filters, refreshed by ONE launch
     (``adyolo_wino_pack_many``) instead of two per filter: ``refresh()`` at the start of a forward pass, ``get(i)`` ->
@@ -222,22 +236,20 @@ class WinoPackSet:
                 cout, cin = w.shape[0], w.shape[1]
                 if cout % 32 or cin % 32:
                     raise _lib.AdyoloHipError("WinoPackSet: channel counts must be multiples of 32")
-                # per direction: F(4x4) form [36][N/32][K/8][256] where it applies (winograd4), else F(2x2) (fp32 or bf16x3)
+                # per direction: the F(2x2) form (fp32 or bf16x3) always, the F(4x4) form [36][N/32][K/8][256] beside it where
+                # it applies (winograd4): ``conv3x3`` picks by the size of the launch (``DualPack``)
                 f4, d4 = w4 and _w4_eligible(cin, cout), w4 and _w4_eligible(cout, cin)
-                fb, db = not f4 and _b3_eligible(cin, math), not d4 and _b3_eligible(cout, math)
-                if f4:
-                    uf = _new(w, 36, cout // 32, cin // 8, 256)
-                else:
-                    uf = _new(w, 16, cout // 32, cin // 16, 768) if fb else _new(w, 16, cout // 32, cin // 8, 256)
-                if d4:
-                    ud = _new(w, 36, cin // 32, cout // 8, 256)
-                else:
-                    ud = _new(w, 16, cin // 32, cout // 16, 768) if db else _new(w, 16, cin // 32, cout // 8, 256)
-                self.packs.append((uf, ud))
-                if not (f4 and d4):
-                    rows.append([w.data_ptr(), 0 if f4 else uf.data_ptr(), 0 if d4 else ud.data_ptr(), cout, cin, cin, int(fb), int(db)])
+                fb, db = _b3_eligible(cin, math), _b3_eligible(cout, math)
+                uf = _new(w, 16, cout // 32, cin // 16, 768) if fb else _new(w, 16, cout // 32, cin // 8, 256)
+                ud = _new(w, 16, cin // 32, cout // 16, 768) if db else _new(w, 16, cin // 32, cout // 8, 256)
+                rows.append([w.data_ptr(), uf.data_ptr(), ud.data_ptr(), cout, cin, cin, int(fb), int(db)])
                 if f4 or d4:
-                    rows4.append([w.data_ptr(), uf.data_ptr() if f4 else 0, ud.data_ptr() if d4 else 0, cout, cin, cin, 0, 0])
+                    uf4 = _new(w, 36, cout // 32, cin // 8, 256) if f4 else None
+                    ud4 = _new(w, 36, cin // 32, cout // 8, 256) if d4 else None
+                    rows4.append([w.data_ptr(), uf4.data_ptr() if f4 else 0, ud4.data_ptr() if d4 else 0, cout, cin, cin, 0, 0])
+                    uf = DualPack(uf4, uf) if f4 else uf
+                    ud = DualPack(ud4, ud) if d4 else ud
+                self.packs.append((uf, ud))
             self.table = torch.tensor(rows, dtype=torch.int64, device=dev) if rows else None
             self.table4 = torch.tensor(rows4, dtype=torch.int64, device=dev) if rows4 else None
             self.nrows, self.nrows4 = len(rows), len(rows4)
@@ -269,8 +281,10 @@ def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, 
         mbits |= 1
     if stat_mask is not None and stat_mask.dtype == torch.int64:
         mbits |= 2
-    _chk(x, wpk, bias, addend, None if mbits & 1 else addend_mask, None if mbits & 2 else stat_mask)
     n, h, w, cin = x.shape
+    if isinstance(wpk, DualPack):
+        wpk = wpk.pick(n, h, w, cout)
+    _chk(x, wpk, bias, addend, None if mbits & 1 else addend_mask, None if mbits & 2 else stat_mask)
     wino = wpk.dim() == 4
     wino4 = wino and wpk.shape[0] == 36
     y = _new(x, n, h, w, cout)

@@ -131,9 +131,14 @@ class KernelTimer:
 def _issued_share(wpk):
     """matrix FLOPs issued / direct-convolution FLOPs for a packed filter: Winograd F(4x4,3x3) 36 multiplies per 144 (first
     axis 36), F(2x2,3x3) 16 per 36 (first axis 16), direct form 1"""
-    if wpk.dim() != 4:
+    if not hasattr(wpk, "dim") or wpk.dim() != 4:
         return 1.0
     return 9.0 / 36.0 if wpk.shape[0] == 36 else 16.0 / 36.0
+
+
+def _picked(ops_mod, x, wpk, cout):
+    """the packed form ``ops.conv3x3`` will launch with (``ops.DualPack``: F(4x4) or F(2x2) by the size of the launch)"""
+    return wpk.pick(x.shape[0], x.shape[1], x.shape[2], cout) if isinstance(wpk, ops_mod.DualPack) else wpk
 
 
 def load_traffic(wino):
@@ -361,7 +366,7 @@ def _run_extra_config(name, cfg, torch, modes):
             kt.wrap(_ops, "attn_bwd", "attention backward (7 products)",
                     lambda q, *a, **kw: fl(14.0 * q.shape[0] * q.shape[1] ** 2 * q.shape[2]))
             kt.wrap(_ops, "conv3x3", "Winograd 3x3 forward / dgrad [issued FLOPs]",
-                    lambda x, wpk, cout, **kw: fl(2.0 * x.shape[0] * x.shape[1] * x.shape[2] * cout * 9 * x.shape[3] * (_issued_share(wpk))))
+                    lambda x, wpk, cout, **kw: fl(2.0 * x.shape[0] * x.shape[1] * x.shape[2] * cout * 9 * x.shape[3] * (_issued_share(_picked(_ops, x, wpk, cout)))))
             kt.wrap(_ops, "conv3x3_wgrad", "Winograd 3x3 weight-gradient [issued FLOPs]",
                     lambda x, dy, cin_real, **kw: fl(2.0 * x.shape[0] * x.shape[1] * x.shape[2] * dy.shape[3] * 9 * x.shape[3] * 16.0 / 36.0))
             torch.manual_seed(100)
@@ -511,7 +516,7 @@ def main():
 
     def conv_work(x, wpk, cout, **kw):
         alg = 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * cout * 9 * x.shape[3]
-        return alg, alg * _issued_share(wpk)
+        return alg, alg * _issued_share(_picked(ops, x, wpk, cout))
 
     def wgrad_work(x, dy, cin_real, **kw):
         alg = 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * dy.shape[3] * 9 * x.shape[3]
