@@ -286,11 +286,11 @@ __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
         const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, ulane, so, 0));
         return make_float4(v[0], v[1], v[2], v[3]);
     };
-    // register ring of BR fragments (BR = 9 or 18 divides the 18 uses of a group: use uu sits in slot uu % BR in every group)
+    // register ring of BR fragments (BR = 9, 12 or 18 divides the 36 uses of a pair: step t uses slot t % BR in every pair)
     constexpr int BR = W4_BRING;
     float4 bq[BR];
 #pragma unroll
-    for (int uu = 0; uu < BR; ++uu) bq[uu] = bload(uu, 0);
+    for (int uu = 0; uu < BR; ++uu) bq[uu] = bload(uu % 18, uu / 18 < nkg ? uu / 18 : nkg - 1);
 
     __syncthreads();                                      // affine table visible
     {                                                     // pair 0: all staging rounds in flight together
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     const int step = half * 18 + 2 * s + nt;
-                    const int uu = 2 * s + nt, slot = uu % BR;
+                    const int uu = 2 * s + nt, slot = step % BR;
                     // ---- side work of the step (VALU / LDS writes), free to interleave with its MFMAs
                     if (!(W4_WHATIF & 4) || pr == 0) {
                         if (step == 2) a_xform_half();
@@ -432,7 +432,12 @@ __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     // ---- loads of the step
-                    if (!(W4_WHATIF & 2)) bq[slot] = uu + BR < 18 ? bload(uu + BR, kg) : bload(uu + BR - 18, kgn);
+                    if (!(W4_WHATIF & 2)) {
+                        // the use BR steps ahead (36 uses per pair): same group, the pair's other group, or the next pair's
+                        const int v = step + BR;
+                        const int kgv = 2 * pr + v / 18;
+                        bq[slot] = bload(v % 18, kgv < nkg ? kgv : nkg - 1);
+                    }
                     if (step == 24) {
                         __syncthreads();                                       // the next pair's image is complete
                         pair_bases(pr + 1);

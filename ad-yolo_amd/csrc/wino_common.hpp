@@ -2,6 +2,7 @@
 // patch geometry constants, the per-template configuration and the epilogue (output transform, bias / masked addend / ReLU,
 // per-patch BatchNorm sums).
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 
 namespace adyolo {
@@ -68,68 +69,115 @@ __device__ __forceinline__ void wino_epilogue(f32x16 (&acc)[4][NT], float *lds, 
         smean = *reinterpret_cast<const float4 *>(stat_mean + co);
         sinv = *reinterpret_cast<const float4 *>(stat_invstd + co);
     }
+    // One body per combination of (statistics, addend, addend mask), chosen by wave-uniform branches ONCE: inside it there is
+    // no branch per pixel and operand (round 4: on this chip a taken / not-taken scalar branch around a few vector instructions
+    // costs more than the instructions; the per-pixel form of this epilogue was 12-19 % of a stage-1 / stage-2 launch), the
+    // fused operands of the thread's pixels are requested together, out-of-image pixels are stored through the output's buffer
+    // descriptor at an out-of-range offset (dropped by the hardware) and counted with weight 0.
+    const float rl = relu ? 0.f : -__builtin_inff();      // ReLU as a maximum with a wave-uniform floor
+    const size_t sbase = (size_t)n * H * W * Cout;        // floats: the sample's base in y / addend / masks / stat_aux
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(y + sbase, 0, H * W * Cout * 4, 0x00020000);
+    typedef unsigned int u32x4_t_ __attribute__((__vector_size__(16)));
+    auto body = [&](auto ST_, auto AD_, auto MK_) {
+        constexpr bool ST = decltype(ST_)::value, AD = decltype(AD_)::value, MK = decltype(MK_)::value;
+        const bool has_smk = ST && stat_mask != nullptr, has_aux = ST && stat_aux != nullptr;
+        auto keep4 = [&](const float *mptr, bool bits, int o_) {
+            bool kx, ky, kz, kw;
+            if (bits) {
+                mask_bits4(reinterpret_cast<const unsigned long long *>(mptr), (sbase + (size_t)(o_ >> 2)) >> 2, kx, ky, kz, kw);
+            } else {
+                const float4 mk = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(mptr + sbase) + o_);
+                kx = mk.x > 0.f; ky = mk.y > 0.f; kz = mk.z > 0.f; kw = mk.w > 0.f;
+            }
+            return (kx ? 1u : 0u) | (ky ? 2u : 0u) | (kz ? 4u : 0u) | (kw ? 8u : 0u);
+        };
 #pragma unroll
-    for (int it = 0; it < MPT; ++it) {
-        const int m = m0 + it * (256 / C4);
-        float4 P[4][2];
+        for (int it = 0; it < MPT; ++it) {
+            const int m = m0 + it * (256 / C4);
+            const int mr = m >> 3, mc = m & 7;
+            int off[4];                                   // byte offset of the pixel's channel quad inside the sample
+            bool ok[4];
+            float4 ad[4], ax[4];
+            unsigned amk[4], smk[4];
 #pragma unroll
-        for (int w = 0; w < 4; ++w)
+            for (int q = 0; q < 4; ++q) {
+                const int gy = ty0 + 2 * mr + (q >> 1), gx = tx0 + 2 * mc + (q & 1);
+                ok[q] = gy < H && gx < W;
+                off[q] = ((min(gy, H - 1) * W + min(gx, W - 1)) * Cout + co) * 4;
+            }
+            if (AD) {
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-                P[w][b] = *reinterpret_cast<const float4 *>(&Pb[((w * 2 + b) * 32 + m) * CBP + c4 * 4]);
-        const int mr = m >> 3, mc = m & 7;
+                for (int q = 0; q < 4; ++q)
+                    ad[q] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(addend + sbase) + off[q]);
+                if (MK) {
+                    const bool bits = (mask_bits & 1) != 0;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                float4 v = a == 0 ? f4_add(f4_add(P[0][b], P[1][b]), P[2][b]) : f4_sub(f4_sub(P[1][b], P[2][b]), P[3][b]);
-                const int gy = ty0 + 2 * mr + a, gx = tx0 + 2 * mc + b;
-                if (gy < H && gx < W) {
-                    const size_t o = (((size_t)n * H + gy) * W + gx) * Cout + co;
-                    v = f4_add(v, bv);
-                    if (addend) {
-                        float4 ad = *reinterpret_cast<const float4 *>(addend + o);
-                        if (addend_mask) {
-                            bool kx, ky, kz, kw;
-                            if (mask_bits & 1) {
-                                mask_bits4(reinterpret_cast<const unsigned long long *>(addend_mask), o >> 2, kx, ky, kz, kw);
-                            } else {
-                                const float4 mk = *reinterpret_cast<const float4 *>(addend_mask + o);
-                                kx = mk.x > 0.f; ky = mk.y > 0.f; kz = mk.z > 0.f; kw = mk.w > 0.f;
-                            }
-                            ad = make_float4(kx ? ad.x : 0.f, ky ? ad.y : 0.f, kz ? ad.z : 0.f, kw ? ad.w : 0.f);
-                        }
-                        v = f4_add(v, ad);
-                    }
-                    if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-                    *reinterpret_cast<float4 *>(y + o) = v;      // (non-temporal loads/stores here: measured 1 % slower)
-                    if (stats) {
-                        if (stat_mask) {        // statistics of v * (mask > 0): the SE / BN2 backward sums of the block below
-                            bool kx, ky, kz, kw;
-                            if (mask_bits & 2) {
-                                mask_bits4(reinterpret_cast<const unsigned long long *>(stat_mask), o >> 2, kx, ky, kz, kw);
-                            } else {
-                                const float4 mk = *reinterpret_cast<const float4 *>(stat_mask + o);
-                                kx = mk.x > 0.f; ky = mk.y > 0.f; kz = mk.z > 0.f; kw = mk.w > 0.f;
-                            }
-                            v = make_float4(kx ? v.x : 0.f, ky ? v.y : 0.f, kz ? v.z : 0.f, kw ? v.w : 0.f);
-                        }
-                        ssum = f4_add(ssum, v);
-                        if (stat_aux) {
-                            const float4 ax = *reinterpret_cast<const float4 *>(stat_aux + o);
-                            ssq.x += v.x * (ax.x - smean.x) * sinv.x;
-                            ssq.y += v.y * (ax.y - smean.y) * sinv.y;
-                            ssq.z += v.z * (ax.z - smean.z) * sinv.z;
-                            ssq.w += v.w * (ax.w - smean.w) * sinv.w;
-                        } else {
-                            ssq.x += v.x * v.x;
-                            ssq.y += v.y * v.y;
-                            ssq.z += v.z * v.z;
-                            ssq.w += v.w * v.w;
-                        }
-                    }
+                    for (int q = 0; q < 4; ++q) amk[q] = keep4(addend_mask, bits, off[q]);
                 }
             }
+            if (has_smk) {
+                const bool bits = (mask_bits & 2) != 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) smk[q] = keep4(stat_mask, bits, off[q]);
+            }
+            if (has_aux) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    ax[q] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(stat_aux + sbase) + off[q]);
+            }
+            float4 P[4][2];
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    P[w][b] = *reinterpret_cast<const float4 *>(&Pb[((w * 2 + b) * 32 + m) * CBP + c4 * 4]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int a = q >> 1, b = q & 1;
+                float4 v = a == 0 ? f4_add(f4_add(P[0][b], P[1][b]), P[2][b]) : f4_sub(f4_sub(P[1][b], P[2][b]), P[3][b]);
+                v = f4_add(v, bv);
+                if (AD) {
+                    float4 a_ = ad[q];
+                    if (MK) {
+                        const unsigned k = amk[q];
+                        a_ = make_float4((k & 1u) ? a_.x : 0.f, (k & 2u) ? a_.y : 0.f, (k & 4u) ? a_.z : 0.f, (k & 8u) ? a_.w : 0.f);
+                    }
+                    v = f4_add(v, a_);
+                }
+                v = make_float4(fmaxf(v.x, rl), fmaxf(v.y, rl), fmaxf(v.z, rl), fmaxf(v.w, rl));
+                // (non-temporal loads/stores here: measured 1 % slower)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t_, v), yrs, ok[q] ? off[q] : (int)0x80000000, 0, 0);
+                if (ST) {
+                    unsigned k = ok[q] ? 15u : 0u;        // out-of-image pixels and masked-out components count 0
+                    if (has_smk) k &= smk[q];
+                    v = make_float4((k & 1u) ? v.x : 0.f, (k & 2u) ? v.y : 0.f, (k & 4u) ? v.z : 0.f, (k & 8u) ? v.w : 0.f);
+                    ssum = f4_add(ssum, v);
+                    float4 w_ = v;
+                    if (has_aux)
+                        w_ = make_float4((ax[q].x - smean.x) * sinv.x, (ax[q].y - smean.y) * sinv.y, (ax[q].z - smean.z) * sinv.z,
+                                         (ax[q].w - smean.w) * sinv.w);
+                    ssq.x = fmaf(v.x, w_.x, ssq.x);
+                    ssq.y = fmaf(v.y, w_.y, ssq.y);
+                    ssq.z = fmaf(v.z, w_.z, ssq.z);
+                    ssq.w = fmaf(v.w, w_.w, ssq.w);
+                }
+            }
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (stats) {
+        if (addend) {
+            if (addend_mask) body(T_{}, T_{}, T_{}); else body(T_{}, T_{}, F_{});
+        } else {
+            body(T_{}, F_{}, F_{});
+        }
+    } else {
+        if (addend) {
+            if (addend_mask) body(F_{}, T_{}, T_{}); else body(F_{}, T_{}, F_{});
+        } else {
+            body(F_{}, F_{}, F_{});
+        }
     }
     if (stats) {
         // per-patch, per-channel sums of the stored output, layout [2][patches][Cout] (see conv.hip)
