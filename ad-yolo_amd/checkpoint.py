@@ -87,33 +87,48 @@ def load_optimizer_state_dict(optimizer, model, sd):
     optimizer.step_count = steps.pop() if steps else 0
 
 
-def _sync_for_save(optimizer):
-    """Data parallelism: BatchNorm running statistics are per-rank (each rank sees its own shard), so before a checkpoint
-    is written EVERY rank averages them over the ranks (``FlatParameters.average_buffers``, a collective: all ranks must
-    call ``save_checkpoint`` / ``save_best``); only rank 0 then writes the file.  -> True when this process writes."""
+def _state_dict_for_save(model, group=None):
+    """-> (this process writes?, the state_dict to write).
+
+    Data parallelism: BatchNorm running statistics are per-rank (each rank sees its own shard).  The file holds their AVERAGE
+    over the ranks, formed in temporary copies: the live buffers are not touched (round 4, ADVICE: averaging them in place
+    made a run that saves follow another trajectory than one that does not).  THE ALL-RANKS CONTRACT: with a process group of
+    more than one rank, ``save_checkpoint`` / ``save_best`` are COLLECTIVES -- every rank must call them (an
+    ``if rank == 0: save_checkpoint(...)`` would leave rank 0 waiting in all_reduce for ever); only rank 0 writes the file.
+    ``group``: the trainer's process group (``TrainStep.reducer.group``; None = the default group)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        flat = getattr(optimizer, "flat", None)
-        if flat is not None:
-            flat.average_buffers()
-        return dist.get_rank() == 0
-    return True
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    writes = True
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
+        for name, buf in model.named_buffers():
+            if name in sd and buf.is_floating_point():          # running_mean / running_var (num_batches_tracked is equal)
+                t = buf.detach().clone()
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                sd[name] = t / world
+        writes = dist.get_rank(group) == 0
+    return writes, {k: v.cpu() for k, v in sd.items()}
 
 
-def save_checkpoint(path, model, optimizer, start_epoch_nb, conf_thresh, best_log, train_remaining_file, device):
-    if not _sync_for_save(optimizer):
+def save_checkpoint(path, model, optimizer, start_epoch_nb, conf_thresh, best_log, train_remaining_file, device, group=None):
+    """``model_ckpt.h5`` in the reference's format (train.py:241-248).  A collective under data parallelism: see
+    ``_state_dict_for_save``."""
+    writes, sd = _state_dict_for_save(model, group)
+    if not writes:
         return
     torch.save({"start_epoch_nb": start_epoch_nb,
-                "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                "model_state_dict": sd,
                 "optim_state_dict": optimizer_state_dict(optimizer, model),
                 "confidence_thresh": float(conf_thresh), "rng_state": get_rng_state(device, model), "best_log": best_log,
                 "train_remaining_file": train_remaining_file}, path)
 
 
-def save_best(path, model, optimizer, epoch_nb, conf_thresh):
-    if not _sync_for_save(optimizer):
+def save_best(path, model, optimizer, epoch_nb, conf_thresh, group=None):
+    """``model_best.h5`` (train.py:234-238).  A collective under data parallelism: see ``_state_dict_for_save``."""
+    writes, sd = _state_dict_for_save(model, group)
+    if not writes:
         return
-    torch.save({"epoch_nb": epoch_nb, "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+    torch.save({"epoch_nb": epoch_nb, "model_state_dict": sd,
                 "optim_state_dict": optimizer_state_dict(optimizer, model), "confidence_thresh": float(conf_thresh)}, path)
 
 

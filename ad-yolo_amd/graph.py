@@ -58,6 +58,7 @@ class StepGraphs:
         self.warm_calls = warm_calls
         self.entries = {}
         self.seen = {}
+        self.eager_only = set()        # input shapes whose step could not be recorded (host-computed values inside it)
         self.streams = _rng.streams(trainer.model)
         self.captures = self.replays = self.eager_steps = 0
 
@@ -75,7 +76,8 @@ class StepGraphs:
     def static_inputs(self, audio_shape, target_like):
         """(audio, target) buffers of the graph for this shape once it exists (else None): a producer may write the next
         batch straight into them and pass them to ``step`` (no copy then)."""
-        ent = self.entries.get((tuple(audio_shape), self._capacity(target_like) or tuple(target_like.shape)))
+        cap = self._capacity(target_like)
+        ent = self.entries.get((tuple(audio_shape), cap if cap is not None else tuple(target_like.shape)))
         return (ent.audio, ent.target) if ent is not None else None
 
     def _load(self, ent, audio, target):
@@ -129,6 +131,9 @@ class StepGraphs:
         tr = self.trainer
         target = target.to(torch.float32)
         key = self._key(audio, target)
+        if key in self.eager_only:
+            self.eager_steps += 1
+            return tr.step_eager(audio, target)
         ent = self.entries.get(key)
         if ent is None:
             n = self.seen.get(key, 0)
@@ -136,7 +141,17 @@ class StepGraphs:
             if n < self.warm_calls:
                 self.eager_steps += 1
                 return tr.step_eager(audio, target)
-            ent = self._capture(key, audio, target)
+            try:
+                ent = self._capture(key, audio, target)
+            except NotImplementedError as e:
+                # a step with host-computed per-step values (the ResNet-Conformer's attention-dropout seeds, a dropout mask
+                # override, ...) cannot be replayed: run this shape eagerly from now on (round 4, ADVICE: it used to raise out
+                # of the capture on every call)
+                import warnings
+                warnings.warn("adyolo: train step not hipGraph-capturable (%s); running it eagerly" % e)
+                self.eager_only.add(key)
+                self.eager_steps += 1
+                return tr.step_eager(audio, target)
         else:
             self._load(ent, audio, target)
         tr.optimizer.sync_device_step()
@@ -161,7 +176,15 @@ class ForwardGraphs:
         self.warm_calls = warm_calls
         self.entries, self.seen = {}, {}
         self.captures = self.replays = 0
-        self.epoch = ops.PARAMS_EPOCH[0]
+        self.epoch = self._stamp()
+
+    def _stamp(self):
+        """What the recorded graphs depend on besides the input shape: the parameter / buffer epoch of in-place kernels
+        (``ops.PARAMS_EPOCH``), the version counters of every parameter and buffer (``p.copy_()``, a torch optimizer step or an
+        EMA swap in evaluation mode bump these, not the epoch -- the eager caches honour them, a recorded graph would replay
+        stale affines and packed filters; round 4, ADVICE) and the arithmetic switches read at pack time."""
+        ver = sum(t._version for t in self.model.parameters()) + sum(t._version for t in self.model.buffers())
+        return (ops.PARAMS_EPOCH[0], ver, ops.math_mode(), ops.conv_algo())
 
     def _run(self, audio):
         out = self.model(self.features(audio, channels_last8=True), channels_last8=True)
@@ -174,10 +197,11 @@ class ForwardGraphs:
     def __call__(self, audio):
         if self.model.training:
             raise RuntimeError("ForwardGraphs records the evaluation forward: call model.eval() first")
-        if self.epoch != ops.PARAMS_EPOCH[0]:          # parameters / buffers were written since the graphs were recorded: the
+        stamp = self._stamp()
+        if self.epoch != stamp:                        # parameters / buffers were written since the graphs were recorded: the
             self.entries.clear()                      # evaluation-mode BatchNorm affines inside them are stale -- record again
             self.seen.clear()
-            self.epoch = ops.PARAMS_EPOCH[0]
+            self.epoch = stamp
         key = tuple(audio.shape)
         ent = self.entries.get(key)
         with torch.no_grad():

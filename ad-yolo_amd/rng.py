@@ -92,16 +92,23 @@ class DropoutStream:
 
     def state(self):
         """What goes into the checkpoint's rng_state: the RANK-INDEPENDENT base seed and the offset (the one rank-0
-        checkpoint is restored on every rank; each re-applies its own rank, so resumed ranks keep drawing different masks)."""
+        checkpoint is restored on every rank; each re-applies its own rank, so resumed ranks keep drawing different masks).
+        A stream restored from a round-2 checkpoint (which stored the rank-mixed seed of the rank that wrote it) has no base
+        yet: it is recovered by taking this process's rank back out (round 4, ADVICE: it used to write base_seed = None, which
+        the next resume could not load)."""
+        if self._base is None and self._seed is not None:
+            self._base = (self._seed ^ ((self._rank() * 0xD1B54A32D192ED03) & _MASK64)) & _MASK64
         _ = self.seed
         return {"base_seed": self._base, "offset": self.offset}
 
     def set_state(self, st):
         self.offset = int(st["offset"])
-        if "base_seed" in st:
+        if st.get("base_seed") is not None:
             self._base, self._seed = int(st["base_seed"]), None          # rank mixed in again at the next use
-        else:                                                            # round-2 checkpoints stored the rank-mixed seed
-            self._base, self._seed = None, int(st["seed"])
+        else:
+            # round-2 checkpoints stored the rank-mixed seed of the WRITING rank (rank 0: the mix is the identity there, so the
+            # stored value is the base); treat it as the base so that every resumed rank mixes its own rank in again
+            self._base, self._seed = int(st["seed"]), None
 
 
 def streams(model):

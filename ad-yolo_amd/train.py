@@ -131,7 +131,14 @@ class TrainStep:
         finally:
             ops.EXACT.disable()
         scale = self.reducer.finish()
-        self.optimizer.step(grad_scale=1.0 if exact else scale)       # exact: the ranks' gradients ADD UP to the batch's
+        # exact + AD-YOLO: the loss kernel normalises by the counts of ALL ranks, so the ranks' gradients ADD UP to the batch's.
+        # The class-wise losses (seddoa / masked-seddoa / accdoa / adpit: means over the local rows, ops.*_loss) keep their
+        # local normaliser: with equal shards the batch mean is the mean of the ranks' means, i.e. gradients are AVERAGED and
+        # the reported loss is the ranks' average (round 4, ADVICE: they used to be summed -- world times too large)
+        summed = exact and getattr(self.criterion, "loss_nm", "adyolo") == "adyolo"
+        self.optimizer.step(grad_scale=1.0 if summed else scale)
+        if exact and not summed:
+            loss = ops.EXACT_world_mean(loss.detach().clone(), self.reducer.group)
         return loss.detach()
 
 

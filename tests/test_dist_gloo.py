@@ -191,6 +191,7 @@ def _worker_resume(rank, world, port, path, out):
     model.bn.running_mean.fill_(float(rank + 1))
     # every rank calls save_checkpoint (it averages the BatchNorm buffers over the ranks: a collective); rank 0 writes
     checkpoint.save_checkpoint(path, model, opt, 7, 0.5, {}, [], "cpu")
+    assert float(model.bn.running_mean[0]) == float(rank + 1)  # saving has no side effect on the live statistics (round 4)
     dist.barrier()
     assert os.path.exists(path)
     torch.manual_seed(12345)                                   # a resumed process starts from some other seed
@@ -236,6 +237,26 @@ def test_dropout_stream_accepts_round2_state():
     a.draw(16)
     b.set_state(a.state())
     assert b.seed == a.seed and b.offset == 16
+
+
+def test_dropout_stream_round2_state_survives_a_second_checkpoint(monkeypatch):
+    """a stream restored from a round-2 state ({'seed', 'offset'}) used to write base_seed = None into the
+    NEXT checkpoint, which could not be loaded, and every resumed rank kept rank 0's seed.  Now: the legacy seed (written by
+    rank 0, where the rank mix is the identity) is the base, state() round-trips, and ranks draw different masks again."""
+    from adyolo_amd.rng import DropoutStream
+    s = DropoutStream(1)
+    s.set_state({"seed": 1234567, "offset": 8})
+    st = s.state()                                        # what the next checkpoint stores
+    assert st["base_seed"] == 1234567 and st["offset"] == 8
+    t = DropoutStream(1)
+    t.set_state(st)                                       # ... and the resume after that
+    assert t.seed == s.seed == 1234567 and t.offset == 8
+    t.set_state({"base_seed": None, "seed": 99, "offset": 3})      # a file written by the broken version: base_seed None
+    assert t.seed == 99 and t.offset == 3
+    monkeypatch.setenv("RANK", "1")                       # the same legacy state restored on rank 1: another seed
+    r1 = DropoutStream(1)
+    r1.set_state({"seed": 1234567, "offset": 8})
+    assert r1.seed != 1234567 and r1.state()["base_seed"] == 1234567
 
 
 class _SinkLinear(torch.autograd.Function):

@@ -251,6 +251,44 @@ def test_evaluation_caches_expire_when_parameters_change(ops):
             loaded = fg(clip)[0].clone()
             assert torch.equal(loaded, uncached()) and not torch.equal(loaded, after_step)
         assert fg.captures == caps + 1
+        # a parameter written in evaluation mode WITHOUT ops.params_changed() (p.copy_(): an EMA swap, a torch optimizer step)
+        # only bumps the tensor's version counter: the recorded graph must expire as well (round 4, ADVICE)
+        caps = fg.captures
+        with torch.no_grad():
+            w = model.encoder.layer4[0].conv1.weight
+            w.copy_(w * 1.25)
+        for _ in range(3):
+            swapped = fg(clip)[0].clone()
+            assert torch.equal(swapped, uncached()) and not torch.equal(swapped, loaded)
+        assert fg.captures == caps + 1
     finally:
         ops.bn_eval_stats = real
     assert Fn is not None
+
+
+def test_uncapturable_step_falls_back_to_eager(ops):
+    """``TrainStep(graph=True)`` on a model whose step draws host-computed values (the ResNet-Conformer's attention-dropout
+    seeds, ``rng.DropoutStream.seed32``): the capture fails, the shape is marked eager-only with ONE warning and every step
+    runs eagerly -- same losses as a trainer built with graph=False (round 4, ADVICE: it used to raise on every call)."""
+    import warnings
+    from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
+    from adyolo_amd.features import FeatureExtractor
+    from adyolo_amd.datasets import synthetic_audio, synthetic_targets
+    from adyolo_amd.train import TrainStep
+    n = 24000 * 2
+    audio = synthetic_audio(2, n, seed=9).to("cuda:0")
+    target = synthetic_targets(2, n // 2400, 12, seed=9).to("cuda:0")
+    losses = {}
+    for graph in (False, True):
+        torch.manual_seed(100)
+        prm = _params()
+        prm["args"]["encoder"] = "resnet-conformer"
+        model = WrapperModel((1, 7, n // 600, 64), (), prm).to("cuda:0")
+        tr = TrainStep(model, WrapperCriterion(prm), FeatureExtractor(None, "cuda:0"), prm, graph=graph)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            losses[graph] = [float(tr.step(audio, target)) for _ in range(4)]
+        if graph:
+            assert tr.graphs.captures == 0 and len(tr.graphs.eager_only) == 1 and tr.graphs.eager_steps == 4
+            assert sum("not hipGraph-capturable" in str(w.message) for w in caught) == 1
+    assert losses[True] == losses[False], losses

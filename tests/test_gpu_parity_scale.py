@@ -850,7 +850,21 @@ mode = os.environ["ADYOLO_DPX_MODE"]                    # "rank": one of two exa
 b, n = 2, 24000 * 4                                     # clips per rank
 
 
+loss_nm = os.environ.get("ADYOLO_DPX_LOSS", "adyolo")
+
+
 def data(r):
+    if loss_nm == "adpit":                              # dense (B, T', 6, 4, C) activity / direction targets
+        import numpy as np
+        rng = np.random.default_rng(60 + r)
+        tp = n // 2400
+        tgt = np.zeros((b, tp, 6, 4, 12), dtype=np.float32)
+        act = rng.random((b, tp, 12)) < 0.2
+        xyz = rng.normal(size=(b, tp, 3, 12)).astype(np.float32)
+        xyz /= np.linalg.norm(xyz, axis=2, keepdims=True)
+        tgt[:, :, 0, 0, :] = act
+        tgt[:, :, 0, 1:, :] = xyz * act[:, :, None, :]
+        return synthetic_audio(b, n, seed=50 + r), torch.from_numpy(tgt)
     return synthetic_audio(b, n, seed=50 + r), synthetic_targets(b, n // 2400, 12, seed=60 + r)
 
 
@@ -861,10 +875,12 @@ else:
     rank, world = 0, 1
     (a0, t0), (a1, t1) = data(0), data(1)
     t1 = t1.clone()
-    t1[:, 0] += b                                       # rank 1's clips are samples b .. 2b-1 of the concatenated batch
+    if loss_nm == "adyolo":
+        t1[:, 0] += b                                   # rank 1's clips are samples b .. 2b-1 of the concatenated batch
     audio, target = torch.cat([a0, a1]), torch.cat([t0, t1])
 torch.manual_seed(100)
 prm = bench.params("cuda:0")
+prm["args"]["loss"] = loss_nm
 model = WrapperModel((1, 7, n // 600, 64), (), prm).to("cuda:0")
 model.encoder.lstm.dropout = 0.0
 tr = TrainStep(model, WrapperCriterion(prm), FeatureExtractor(None, "cuda:0"), prm, exact=True)
@@ -876,7 +892,9 @@ opt_step = tr.optimizer.step
 
 def spy(grad_scale=1.0):
     grads.append(tr.flat.flat_grad.clone())
-    assert grad_scale == 1.0                            # exact mode (and one device): gradients are sums, never averaged
+    # exact mode + AD-YOLO (and one device): gradients are sums, never averaged; the class-wise losses normalise over the local
+    # rows, so their rank gradients are AVERAGED (ADVICE round 3: they used to be summed)
+    assert grad_scale == (1.0 if loss_nm == "adyolo" or world == 1 else 1.0 / world), grad_scale
     opt_step(grad_scale=grad_scale)
 tr.optimizer.step = spy
 bn_first = None
@@ -896,14 +914,16 @@ if dist.is_initialized():
 """
 
 
-def test_exact_data_parallel_equals_one_device_on_the_concatenated_batch(ops, tmp_path):
+@pytest.mark.parametrize("loss_nm", ["adyolo", "adpit"])
+def test_exact_data_parallel_equals_one_device_on_the_concatenated_batch(ops, tmp_path, loss_nm):
     """``TrainStep(exact=True)`` (ops.ExactDP; SURVEY 8e "optional"): two ranks on two different 2-clip shards (two processes
     on this one GPU, gloo) against ONE process on the 4-clip concatenation, real SE-ResNet34 + AD-YOLO model, 3 Adam steps.
     BatchNorm statistics are formed over all ranks' samples by the same finishing kernel on the gathered per-sample sums
     -> running statistics BIT-identical after the first step (the whole forward pass is) and within 1e-3 after 3 Adam steps; the loss counts are all-reduced -> the first loss value agrees to
     1e-6 (measured 7e-8), the later ones to 1e-4 (measured 3e-6); the gradients Adam sees in step 0 (summed over the ranks, not averaged) agree per parameter tensor
     to 2e-5 of its absmax (only summation orders differ); both ranks hold the same parameters, and their 3-step update is
-    the one-device update (cosine >= 0.999)."""
+    the one-device update (cosine >= 0.999).  loss_nm = adpit (round 4): a class-wise loss, whose normaliser is the local row
+    count -- there the exact step averages the ranks' gradients and reports the ranks' mean loss."""
     import json
     import socket
     import subprocess
@@ -912,7 +932,8 @@ def test_exact_data_parallel_equals_one_device_on_the_concatenated_batch(ops, tm
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    base = dict(os.environ, ADYOLO_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = dict(os.environ, ADYOLO_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                ADYOLO_DPX_LOSS=loss_nm)
     base.pop("ADYOLO_FORCE_DP_HOOKS", None)
     outs = [str(tmp_path / ("r%d.pt" % r)) for r in range(2)] + [str(tmp_path / "single.pt")]
     procs = [subprocess.Popen([sys.executable, "-c", _DPX_CHILD],
