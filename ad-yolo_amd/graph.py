@@ -127,6 +127,11 @@ class StepGraphs:
         self.captures += 1
         return ent
 
+    def _mark_eager(self, key, why):
+        import warnings
+        warnings.warn("adyolo: train step not hipGraph-capturable (%s); running it eagerly" % why)
+        self.eager_only.add(key)
+
     def step(self, audio, target):
         tr = self.trainer
         target = target.to(torch.float32)
@@ -140,16 +145,18 @@ class StepGraphs:
             self.seen[key] = n + 1
             if n < self.warm_calls:
                 self.eager_steps += 1
-                return tr.step_eager(audio, target)
+                before = sum(s.host_draws for s in self.streams)
+                loss = tr.step_eager(audio, target)
+                if sum(s.host_draws for s in self.streams) != before:
+                    # the step drew host-computed values (the ResNet-Conformer's attention-dropout seeds, a dropout mask
+                    # override): it cannot be replayed -- decided here, on the warm-up step, without attempting a capture
+                    self._mark_eager(key, "its dropout draws host-computed values")
+                return loss
             try:
                 ent = self._capture(key, audio, target)
             except NotImplementedError as e:
-                # a step with host-computed per-step values (the ResNet-Conformer's attention-dropout seeds, a dropout mask
-                # override, ...) cannot be replayed: run this shape eagerly from now on (round 4, ADVICE: it used to raise out
-                # of the capture on every call)
-                import warnings
-                warnings.warn("adyolo: train step not hipGraph-capturable (%s); running it eagerly" % e)
-                self.eager_only.add(key)
+                # second line of defence (round 4, ADVICE: this used to raise out of the capture on every call)
+                self._mark_eager(key, str(e))
                 self.eager_steps += 1
                 return tr.step_eager(audio, target)
         else:

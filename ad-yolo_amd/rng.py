@@ -22,6 +22,7 @@ class DropoutStream:
         self.dev = None
         self.dev_value = None      # what the host knows `dev` to hold
         self.capture_base = None
+        self.host_draws = 0        # mask() / seed32() calls: values computed on the host, which a recorded step cannot replay
 
     @staticmethod
     def _rank():
@@ -67,6 +68,7 @@ class DropoutStream:
     def mask(self, like, p):
         from . import ops
         self._no_capture("mask")
+        self.host_draws += 1
         m = ops.dropout_mask(like, p, self.seed, self.offset)
         self.offset += like.numel()
         return m
@@ -84,6 +86,7 @@ class DropoutStream:
     def seed32(self, n):
         """A 32-bit seed for a kernel that draws ``n`` values from its own stateless hash; advances the stream by n."""
         self._no_capture("seed32")
+        self.host_draws += 1
         x = (self.seed ^ ((self.offset * 0x9E3779B97F4A7C15) & _MASK64)) & _MASK64
         x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _MASK64
         x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _MASK64
