@@ -184,6 +184,7 @@ class ForwardGraphs:
         self.entries, self.seen = {}, {}
         self.captures = self.replays = 0
         self.epoch = self._stamp()
+        self.primed = None
 
     def _stamp(self):
         """What the recorded graphs depend on besides the input shape: the parameter / buffer epoch of in-place kernels
@@ -216,7 +217,11 @@ class ForwardGraphs:
                 n = self.seen.get(key, 0)
                 self.seen[key] = n + 1
                 if n < self.warm_calls:
+                    self.primed = stamp
                     return self._run(audio)
+                if self.primed != stamp:               # nothing has run eagerly under these parameters yet: the packed filters
+                    self._run(audio)                   # and evaluation affines are built on first use with host->device copies,
+                    self.primed = stamp                # which a capturing stream refuses -- build them outside the capture
                 static = audio.clone()
                 graph = torch.cuda.CUDAGraph()
                 with _quiet_collector(), torch.cuda.graph(graph):

@@ -1,5 +1,6 @@
 """CPU: the oracle (oracle/*.py) against the golden vectors generated from the real reference."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -367,3 +368,66 @@ def test_postprocess_decode_and_nms_match_reference(nms):
     assert rows.shape == ref.shape
     np.testing.assert_array_equal(rows[:, :2], ref[:, :2])          # frame, class: exact
     np.testing.assert_allclose(rows[:, 2:], ref[:, 2:], rtol=0, atol=2e-5)
+
+
+# ---- whole evaluation chain -------------------------------------------------------------
+def _chain_rows(det):
+    return np.asarray(sorted([fr, int(d[0]), float(d[1]), float(d[2]), float(d[3])] for fr, dets in det.items() for d in dets),
+                      dtype=np.float64).reshape(-1, 5)
+
+
+def test_seld_chain_oracle_reproduces_the_reference_run(tmp_path):
+    """``seld_chain.npz`` = the REAL reference run end to end on three synthetic clips (WAV -> datasets.Dataset('test') ->
+    WrapperModel.eval -> loss -> LabelPostProcessor -> CSV rows -> ComputeSELDResults; make_golden.py::gen_seld_chain).
+    Here the CPU side: the clips regenerate bit for bit from their seeds; the oracle chain (features -> float64 encoder +
+    head -> label encoder -> loss -> decode) plus the host NMS give the same rows (frame / class exact, xyz 1e-3) and loss; the host SELD metrics on the stored rows give the stored scores."""
+    sys.path.insert(0, G)
+    from seld_chain_inputs import CLIPS, chain_clip, crc
+    from oracle import postprocess as opp
+    from oracle import labels as olab
+    from adyolo_amd.postprocess import nms_decoded, write_seld_output_file
+    from adyolo_amd.features import load_scaler_npz
+    from adyolo_amd.seld_metrics import ComputeSELDResults
+    g = np.load(os.path.join(G, "seld_chain.npz"))
+    scaler = load_scaler_npz(os.path.join(G, "scaler_DCASE2021.npz"))
+    enc, head = _filled_sd()
+    enc = {k: (v.double() if v.is_floating_point() else v) for k, v in enc.items()}
+    head = {k: (v.double() if v.is_floating_point() else v) for k, v in head.items()}
+    ct, kt, ut = float(g["conf_thresh"]), float(g["clss_thresh"]), float(g["unify_thresh"])
+    ref_dir, out_dir = tmp_path / "ref", tmp_path / "out"
+    ref_dir.mkdir(), out_dir.mkdir()
+    for i, (name, seed, n) in enumerate(CLIPS):
+        pcm = chain_clip(seed, n)
+        assert crc(pcm) == int(g["crc32"][i]) and str(g["names"][i]) == name
+        with open(ref_dir / (name + ".csv"), "w") as f:
+            for r in g["ref_" + name]:
+                f.write("%d,%d,%d,%d,%d\n" % tuple(int(v) for v in r))
+        pred = g["pred_" + name]
+        write_seld_output_file(str(out_dir / (name + ".csv")),
+                               {int(fr): [list(r[[1, 3, 4, 5]]) for r in pred[pred[:, 0] == fr]] for fr in np.unique(pred[:, 0])})
+        feat, nb_label = ofeat.get_feature(ofeat.int16_to_audio(pcm), scaler)
+        idx = np.arange(0, feat.size, max(1, feat.size // 4096))[:4096]
+        np.testing.assert_allclose(feat.reshape(-1)[idx], g["feat_sample_" + name], rtol=0, atol=2e-4)
+        with torch.no_grad():
+            logit = onet.adyolo_head(head, onet.encoder_forward(enc, torch.from_numpy(feat)[None].double(), training=False))
+        idx = np.arange(0, logit.numel(), max(1, logit.numel() // 4096))[:4096]
+        np.testing.assert_allclose(logit.reshape(-1)[idx].numpy(), g["logit_sample_" + name], rtol=0,
+                                   atol=1e-3 * float(g["logit_absmax_" + name]))
+        events = {}
+        for fr, cls, src, az, el in g["ref_" + name]:
+            events.setdefault(int(fr), []).append([int(cls), int(src), float(az), float(el)])
+        rows = olab.yolo_label(events, int(nb_label))
+        _, target = olab.collate([torch.zeros(1)], [rows])
+        target = torch.as_tensor(np.asarray(target, dtype=np.float32))
+        np.testing.assert_allclose(target.numpy(), g["target_" + name], rtol=0, atol=1e-5)
+        loss = oloss.adyolo_loss(logit.float(), target, 12)
+        np.testing.assert_allclose(float(loss), float(g["losses"][i]), rtol=1e-4)
+        got = _chain_rows(nms_decoded(opp.decode(logit.float().numpy(), 12), 12, ct, kt, ut, "conn-merge"))
+        ref = np.asarray(sorted(pred[:, [0, 1, 3, 4, 5]].tolist()))
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        np.testing.assert_array_equal(got[:, :2], ref[:, :2])
+        np.testing.assert_allclose(got[:, 2:], ref[:, 2:], rtol=0, atol=1e-3)
+    prm = {"data_config": {"nb_classes": 12, "sr": 24000, "label_hop_len_s": 0.1}}
+    res = ComputeSELDResults(prm, str(ref_dir)).get_SELD_Results(str(out_dir))
+    np.testing.assert_allclose([float(v) for v in res[:5]], g["scores"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(np.asarray(res[5], dtype=np.float64), g["classwise"], rtol=0, atol=1e-6)
