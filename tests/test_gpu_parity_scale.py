@@ -1000,3 +1000,14 @@ def test_bench_two_ranks_functional_run_on_one_device(ops):
     assert d["config"]["global_batch"] == 4 and "dp2" in d["config"]["parallelism"]
     assert abs(d["value"] - 2 * 2 * 4 / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]     # whole-job audio-seconds per second
     assert np.isfinite(d["final_loss"]) and d["roofline"]["launches"] > 0 and "cpu_baseline" not in d
+    # the N > 1 evidence block (round 4): the process group's own view of the job and what the gradient reducer did per step
+    rc = d["rccl"]
+    assert rc["backend"] == "gloo" and rc["world_size"] == 2 and rc["all_reduce_of_ones"] == 2.0 and rc["all_reduce_ok"] is True
+    assert rc["buckets"] >= 2 and len(rc["bucket_MB"]) == rc["buckets"] and abs(sum(rc["bucket_MB"]) - 26.73) < 0.1
+    assert rc["buckets_fired_from_hooks_per_step"] + rc["buckets_fired_from_finish_per_step"] == rc["buckets"]
+    assert rc["buckets_fired_from_hooks_per_step"] >= rc["buckets"] - 1           # at most the last bucket waits for finish()
+    assert rc["ms_per_step_reducer_off"] > 0 and abs(rc["exposed_allreduce_ms"] - (d["ms_per_step"] - rc["ms_per_step_reducer_off"])) < 0.01
+    # the host-fed variant of the same step (int16 clips through AudioStager)
+    pl = d["pipeline"]
+    assert pl["ms_per_step"] > 0 and abs(pl["value"] - 2 * 2 * 4 / (pl["ms_per_step"] * 1e-3)) <= 0.01 * pl["value"]
+    assert abs(pl["h2d_MB_per_step_per_gpu"] - 2 * 96000 * 4 * 2 / 1e6) < 0.11
