@@ -421,7 +421,7 @@ namespace adyolo {
 // end; waves 0 and 3 read one dy row instead of two.  Each workgroup writes one slab of dU; slabs are summed in a
 // fixed order and G^T . G is applied by two small kernels (deterministic).
 
-template <int NT>
+template <int NT, bool RAGGED>
 __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
     const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ in_scale,
     const float *__restrict__ in_shift, float *__restrict__ slabs, int H, int W, int Cin, int Cout, int tilesW,
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
     const int xsw = (xci >> 3) & 1, dsw = (dco >> 3) & 1;
     float *xdst = Xs + (xj * 32 + xci) * 8;
     float *ddst = Dsh + (dj * CB + dco) * 8;
-    const bool ragged = (W & 15) != 0 || (H & 1) != 0;              // uniform: the general masking path
+    constexpr bool ragged = RAGGED;                                 // (W & 15) != 0 || (H & 1) != 0: the general masking path
     const int xrowb = W * Cin * 4, drowb = W * Cout * 4, xpixb = Cin * 4, dpixb = Cout * 4;
 
     for (int item = split; item < nitems; item += nsplit) {
@@ -487,6 +487,24 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
         const int xgx0 = tx0 - 1 + xj, dgx0 = tx0 + dj + 2 * dk0;     // image column of tile 0 of this thread's run
 
         float xraw[2][8], draw[2][DK];            // (never live together: see the step loop)
+        // Round 4: the fetches go through buffer descriptors of the sample (base = this block's first channel).  The fp32 MFMA
+        // shares its issue port with the vector ALU (tools/micro/mfma32_coissue.hip: every VALU instruction between two MFMAs
+        // costs its full issue time), and the old form spent ~100 VALU instructions per step on addresses: a clamp pair and a
+        // quarter-rate integer multiply per pixel, then a 64-bit add per load.  Now the thread holds three byte offsets per
+        // item (tiles 1..6 / tile 0 / tile 7 of its run), a step adds the uniform row offset to them (6 adds per 16 loads)
+        // and tile k is selected by the SCALAR offset operand (2 k pixels; no VALU).  Rows above / below the image give a
+        // negative / too large vector offset, which the range check answers with 0 (the hardware checks the vector offset
+        // only -- which is also why tile 0 and tile 7, the two that can leave the image sideways in the non-ragged case, keep
+        // clamped offsets of their own instead of relying on it).  Ragged images (W % 16, H % 2) keep the general path.
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(x + (size_t)n * H * W * Cin + c0), 0, (H * W * Cin - c0) * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(dy + (size_t)n * H * W * Cout + co0), 0, (H * W * Cout - co0) * 4, 0x00020000);
+        const int xthr = xr * xrowb + xci * 4;
+        const int xcolA = xthr + (xgx0 + 2) * xpixb;
+        const int xcol0 = xthr + max(xgx0, 0) * xpixb;
+        const int xcol7 = xthr + min(xgx0 + 14, W - 1) * xpixb;
+        const int dcol = dr * drowb + dco * 4 + dgx0 * dpixb;
         // (column offsets are recomputed per call from an opaque zero: hoisted out of the step loop they would hold
         //  16 more registers and this kernel would spill)
         auto opaque_zero = [&]() {
@@ -494,9 +512,21 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
             asm volatile("v_mov_b32 %0, 0" : "=v"(z));
             return z;
         };
-        // rows rr0 + xr and rr0 + xr + 2 (relative to image row 2 tr0 - 1); offsets clamped into the sample, the
-        // loads are unconditional
+        // rows rr0 + xr and rr0 + xr + 2 (relative to image row 2 tr0 - 1); the loads are unconditional
         auto load_x_into = [&](float (&xr_)[2][8], int rr0) {
+            if (!ragged) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int so = (2 * tr0 - 1 + rr0 + 2 * p) * xrowb;         // uniform
+                    const int vA = xcolA + so, v0 = xcol0 + so, v7 = xcol7 + so;
+                    xr_[p][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, v0, 0, 0));
+#pragma unroll
+                    for (int k = 1; k < 7; ++k)
+                        xr_[p][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vA, (2 * k - 2) * xpixb, 0));
+                    xr_[p][7] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, v7, 0, 0));
+                }
+                return;
+            }
             const int gxz = xgx0 + opaque_zero();
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
@@ -529,12 +559,23 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
                         t[k] = (rowok && gx >= 0 && gx < W) ? fmaf(xr_[p][k], xsc, xsh) : 0.f;
                     }
                 }
-                float *q = xdst + (rr % XSLOTS) * XROW;
+                // ring slot (rr mod 10): rr0 + 2 p is even and uniform, xr is 0 or 1 -- no per-thread division
+                float *q = xdst + (((rr0 + 2 * p) % XSLOTS) + xr) * XROW;
                 *reinterpret_cast<float4 *>(q + (xsw << 2)) = make_float4(t[0], t[1], t[2], t[3]);
                 *reinterpret_cast<float4 *>(q + ((xsw ^ 1) << 2)) = make_float4(t[4], t[5], t[6], t[7]);
             }
         };
         auto load_d = [&](int rd0) {              // dy rows rd0 + dr, rd0 + dr + 2 (relative to image row 2 tr0)
+            if (!ragged) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int vd = dcol + (2 * tr0 + rd0 + 2 * p) * drowb;
+#pragma unroll
+                    for (int k = 0; k < DK; ++k)
+                        draw[p][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, vd, 2 * k * dpixb, 0));
+                }
+                return;
+            }
             const int gxz = dgx0 + opaque_zero();
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
@@ -559,7 +600,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
 #pragma unroll
                     for (int k = 0; k < DK; ++k) t[k] = (rowok && dgx0 + 2 * k < W) ? t[k] : 0.f;
                 }
-                float *q = ddst + (rd & (DSLOTS - 1)) * DROW;
+                float *q = ddst + (((rd0 + 2 * p) & (DSLOTS - 1)) + dr) * DROW;     // (rd0 + 2 p is even and uniform, dr is 0 or 1)
                 if (NT == 2) {
                     *reinterpret_cast<float4 *>(q + (dsw << 2)) = make_float4(t[0], t[1], t[2], t[3]);
                     *reinterpret_cast<float4 *>(q + ((dsw ^ 1) << 2)) = make_float4(t[DK - 4], t[DK - 3], t[DK - 2], t[DK - 1]);
@@ -774,12 +815,16 @@ extern "C" int adyolo_wino_wgrad(const float *x, const float *dy, const float *i
     const int nsplit = wino_wgrad_geometry(N, H, W, Cin, Cout, &nt, &nseg, &seg_rows, &nitems);
     const int tilesH = cdiv(H, 2), tilesW = cdiv(W, 16), ciBlocks = Cin / 32;
     dim3 grid((unsigned)nsplit, (unsigned)((Cout / (32 * nt)) * ciBlocks));
-    if (nt == 2)
-        hipLaunchKernelGGL((wino_wgrad_kernel<2>), grid, dim3(256), 0, st, x, dy, in_scale, in_shift, slabs, H, W, Cin,
-                           Cout, tilesW, tilesH, nseg, seg_rows, nitems, nsplit, ciBlocks);
-    else
-        hipLaunchKernelGGL((wino_wgrad_kernel<1>), grid, dim3(256), 0, st, x, dy, in_scale, in_shift, slabs, H, W, Cin,
-                           Cout, tilesW, tilesH, nseg, seg_rows, nitems, nsplit, ciBlocks);
+    const bool ragged = (W & 15) != 0 || (H & 1) != 0;
+#define ADYOLO_WINO_WGRAD(NT_, RG_)                                                                                     \
+    hipLaunchKernelGGL((wino_wgrad_kernel<NT_, RG_>), grid, dim3(256), 0, st, x, dy, in_scale, in_shift, slabs, H, W, Cin, \
+                       Cout, tilesW, tilesH, nseg, seg_rows, nitems, nsplit, ciBlocks)
+    if (nt == 2) {
+        if (ragged) ADYOLO_WINO_WGRAD(2, true); else ADYOLO_WINO_WGRAD(2, false);
+    } else {
+        if (ragged) ADYOLO_WINO_WGRAD(1, true); else ADYOLO_WINO_WGRAD(1, false);
+    }
+#undef ADYOLO_WINO_WGRAD
     int rc = check_launch("wino_wgrad");
     if (rc) return rc;
     const int total = 16 * Cin * Cout;
