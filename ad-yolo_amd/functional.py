@@ -296,8 +296,9 @@ class SEBlockFn(torch.autograd.Function):
         c = w1.shape[0]
         if packs is not None:
             # (ops.DualPack -> the form this launch size runs on: F(4x4) when the grid fills the chip, else F(2x2))
-            wpk1, wpk1d, wpk2, wpk2d = [pk.pick(n, h, w_, co) if isinstance(pk, ops.DualPack) else pk
-                                        for pk, co in zip(packs, (c, cin, c, c))]
+            # (the data-gradient of conv1 always carries an addend -- the shortcut's gradient -- in its epilogue)
+            wpk1, wpk1d, wpk2, wpk2d = [pk.pick(n, h, w_, co, ad) if isinstance(pk, ops.DualPack) else pk
+                                        for pk, co, ad in zip(packs, (c, cin, c, c), (False, True, False, False))]
         else:
             wpk1, wpk1d = ops.pack_w3x3(w1, cin)
             wpk2, wpk2d = ops.pack_w3x3(w2, c)

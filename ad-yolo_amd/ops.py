@@ -138,12 +138,13 @@ def conv_algo():
 
 
 def _w4_eligible(k_gemm, n_gemm):
-    """Does this GEMM direction (contraction over k_gemm channels, n_gemm output channels) run on the F(4x4,3x3) kernel
-    (csrc/wino4.hip)?  The kernel needs 64 output channels per workgroup and 16-channel pairs of the contraction; it beats
-    the F(2x2) kernel from 128 contraction channels on (its per-workgroup prologue / epilogue is not overlapped: one workgroup
-    per CU) -- 1.30-1.47 x per plain launch at 128 / 256 channels, 1.2 x at 64 but below 1 with the fused operands there
-    ("F(4x4,3x3), round 4"); ADYOLO_W4_MIN_K moves the threshold."""
-    return n_gemm % 64 == 0 and k_gemm % 32 == 0 and int(os.environ.get("ADYOLO_W4_MIN_K", "128")) <= k_gemm <= 512
+    """Does this GEMM direction (contraction over k_gemm channels, n_gemm output channels) get the F(4x4,3x3) form
+    (csrc/wino4.hip) packed beside the F(2x2) one?  The kernel needs 64 output channels per workgroup and 16-channel pairs of
+    the contraction.  One workgroup per CU: its prologue / epilogue is not overlapped, so it wins by more the longer the
+    contraction -- per launch at the bench shapes 1.26-1.46 x at 256 channels, 1.11-1.28 x at 128, 1.08-1.15 x at 64 except
+    with an addend in the epilogue (0.94-0.97 x: ``DualPack.pick`` keeps the F(2x2) kernel there); DESIGN.md, "F(4x4,3x3),
+    round 4".  ADYOLO_W4_MIN_K moves the threshold."""
+    return n_gemm % 64 == 0 and k_gemm % 32 == 0 and int(os.environ.get("ADYOLO_W4_MIN_K", "64")) <= k_gemm <= 512
 
 
 def math_mode():
@@ -213,9 +214,15 @@ class DualPack:
     def __init__(self, f4, f2):
         self.f4, self.f2 = f4, f2
 
-    def pick(self, n, h, w, cout):
+    def pick(self, n, h, w, cout, addend=False):
+        """addend: the launch adds a tensor in its epilogue (the data-gradient of a block's first convolution) -- with a
+        contraction of fewer than 128 channels the F(2x2) kernel is the faster one then (ADYOLO_W4_MIN_K_ADDEND)"""
         wgs = _lib.load().adyolo_wino4_tiles(n, h, w) * (cout // 64)
-        return self.f4 if wgs >= int(os.environ.get("ADYOLO_W4_MIN_WGS", "200")) else self.f2
+        if wgs < int(os.environ.get("ADYOLO_W4_MIN_WGS", "200")):
+            return self.f2
+        if addend and self.f4.shape[2] * 8 < int(os.environ.get("ADYOLO_W4_MIN_K_ADDEND", "128")):
+            return self.f2
+        return self.f4
 
 
 class WinoPackSet:
@@ -292,7 +299,7 @@ def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, 
         mbits |= 2
     n, h, w, cin = x.shape
     if isinstance(wpk, DualPack):
-        wpk = wpk.pick(n, h, w, cout)
+        wpk = wpk.pick(n, h, w, cout, addend is not None)
     _chk(x, wpk, bias, addend, None if mbits & 1 else addend_mask, None if mbits & 2 else stat_mask)
     wino = wpk.dim() == 4
     wino4 = wino and wpk.shape[0] == 36

@@ -128,8 +128,49 @@ def bench(batch, iters, stages, fused):
         print(line, flush=True)
 
 
+def bench_variants(batch, iters, stages):
+    """The four operand combinations the SE-ResNet block actually launches (functional.py): forward conv1 / conv2, data-gradient
+    of conv2 and of conv1 (identity shortcut, ReLU-mask bits)."""
+    for st in stages:
+        h, w, cin, cout = SHAPES[st]
+        g = lambda *shape: torch.randn(*shape, device="cuda:0")                                         # noqa: E731
+        x, dy, aux = g(batch, h, w, cin), g(batch, h, w, cout), g(batch, h, w, cout)
+        wt = g(cout, cin, 3, 3) * 0.05
+        aff = (torch.rand(cin, device="cuda:0") + 0.5, g(cin))
+        mean, invstd = g(cout) * 0.1, torch.rand(cout, device="cuda:0") + 0.5
+        bits = torch.randint(-2 ** 62, 2 ** 62, (batch * h * w * cout // 64,), dtype=torch.int64, device="cuda:0")
+        combos = {
+            "fwd conv1 (affine, relu, stats)": dict(relu=True, in_affine=aff, want_stats=True),
+            "fwd conv2 (affine, stats)": dict(in_affine=aff, want_stats=True),
+            "dgrad conv2 (stats vs bn aux)": dict(want_stats=True, stat_bn=(aux, mean, invstd)),
+            "dgrad conv1 (addend+mask bits, stats vs aux, stat mask bits)": dict(addend=dy, addend_mask=bits, want_stats=True,
+                                                                                 stat_bn=(aux, mean, invstd), stat_mask=bits),
+            "plain": dict(),
+        }
+        for name, kw in combos.items():
+            times = {}
+            for rep in range(2):
+                for algo in ("winograd", "winograd4"):
+                    wpk, _ = ops.pack_w3x3(wt, cin, want_dgrad=False, algo=algo)
+                    if algo == "winograd4" and wpk.shape[0] != 36:
+                        continue
+                    fn = lambda: ops.conv3x3(x, wpk, cout, **kw)                                       # noqa: E731
+                    fn()
+                    torch.cuda.synchronize()
+                    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s.record()
+                    for _ in range(iters):
+                        fn()
+                    e.record()
+                    torch.cuda.synchronize()
+                    times.setdefault(algo, []).append(s.elapsed_time(e) / iters)
+            f2, f4 = min(times["winograd"]), min(times.get("winograd4", [float("nan")]))
+            print("stage %2d %-62s F2 %.3f ms  F4 %.3f ms  speed-up %.2fx" % (st, name, f2, f4, f2 / f4), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--variants", action="store_true", help="time the operand combinations of the real network instead")
     ap.add_argument("--skip-check", action="store_true")
     ap.add_argument("--skip-bench", action="store_true")
     ap.add_argument("--batch", type=int, default=64)
@@ -151,6 +192,9 @@ def main():
                 worst = max(worst, v)
                 print("fused %-24s %-40s %.2e" % (shp, k, v), flush=True)
         print("WORST relative error %.3e %s" % (worst, "OK" if worst < 2e-5 else "FAIL"), flush=True)
+    if a.variants:
+        bench_variants(a.batch, a.iters, [int(s) for s in a.stages.split(",")])
+        return
     if not a.skip_bench:
         stages = [int(s) for s in a.stages.split(",")]
         bench(a.batch, a.iters, stages, fused=False)
