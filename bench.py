@@ -454,6 +454,8 @@ def main():
     ap.add_argument("--only-extra", default=None, help="run ONE extra config by name and print its entry (profiling)")
     ap.add_argument("--extra-mode", default="both", choices=["both", "hipgraph", "eager"],
                     help="with --only-extra: run only the graph or only the eager variant (profiling: a known step count)")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the parity gate (profiling: its 8-clip launches would enter the per-kernel averages of the trace)")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
                     help="skip the host-fed variant of the step (int16 clips through AudioStager), reported as `pipeline`")
     ap.add_argument("--graph", action="store_true", help="replay the headline step from a hipGraph too (no per-kernel events)")
@@ -507,7 +509,7 @@ def main():
     # allocator churn before the timed region): the first forward loss with the benchmarked (Winograd) convolutions must equal
     # the direct implicit-GEMM path within 1e-3 (both are checked against torch / the oracle in tests/)
     parity = None
-    if args.encoder == "se-resnet34" and wino and world == 1:      # (N > 1: a rank-0-only assert would strand the other ranks)
+    if args.encoder == "se-resnet34" and wino and world == 1 and not args.no_parity:      # (N > 1: a rank-0-only assert would strand the other ranks)
         model.train()
         vals, outs = {}, {}
         nb = min(B, 8)
