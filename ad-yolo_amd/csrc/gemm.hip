@@ -26,20 +26,27 @@ struct ConvGather {
     int Hs, Ws, Cs, Hm, Wm, KH, KW, SH, SW, PH, PW, dgrad, kreal;
 };
 
-template <bool TA, bool TB, int G = 0>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ A, const float *__restrict__ B,
+// Tile shape (round 4): WM x WN waves, each SM x SN accumulator tiles of 32 x 32: BM = 32 WM SM rows x BN = 32 WN SN columns.
+//   4 x 1 x 1 x 2 = 128 x 64 on 256 threads (the form of rounds 1-3; skinny and split-K calls),
+//   4 x 2 x 2 x 2 = 256 x 128 on 512 threads: per MFMA half the global loads (each costs 12-20 ns of the issue port the fp32
+//   MFMA shares) and two thirds of the LDS reads.  Every thread stages 4 + 2 float4 per K tile in both.
+template <bool TA, bool TB, int G = 0, int WM = 4, int WN = 1, int SM = 1, int SN = 2>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void gemm_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                       const float *__restrict__ bias, float *__restrict__ C,
                                                       int M, int N, int K, int lda, int ldb, int ldc, int klen,
                                                       size_t slab_stride, int slab_ld, int accumulate, GemmBatch bt,
                                                       ConvGather cg) {
     static_assert(G == 0 || (G == 1 && !TA) || (G == 2 && TB), "gathered operand: k-major A or transposed B");
-    constexpr int A_LD = TA ? (GBM + 4) : (GBK + 4);
-    constexpr int B_LD = TB ? (GBN + 4) : (GBK + 4);
-    __shared__ __attribute__((aligned(16))) float As[TA ? GBK * (GBM + 4) : GBM * (GBK + 4)];
-    __shared__ __attribute__((aligned(16))) float Bs[TB ? GBK * (GBN + 4) : GBN * (GBK + 4)];
+    constexpr int BM = 32 * WM * SM, BN = 32 * WN * SN, NTHR = 64 * WM * WN;
+    static_assert(BM * 8 == 4 * NTHR && BN * 8 == 2 * NTHR, "staging: 4 + 2 float4 per thread and K tile");
+    constexpr int A_LD = TA ? (BM + 4) : (GBK + 4);
+    constexpr int B_LD = TB ? (BN + 4) : (GBK + 4);
+    __shared__ __attribute__((aligned(16))) float As[TA ? GBK * (BM + 4) : BM * (GBK + 4)];
+    __shared__ __attribute__((aligned(16))) float Bs[TB ? GBK * (BN + 4) : BN * (GBK + 4)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
     const int li = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     int z = blockIdx.z;
     if (bt.inner > 0) {
         const long zo = z / bt.inner, zi = z - zo * bt.inner;
@@ -51,18 +58,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ 
     const int kbeg = z * klen;
     const int kend = min(K, kbeg + klen);
 
-    f32x16 acc[2];
+    f32x16 acc[SM][SN];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int sm = 0; sm < SM; ++sm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        for (int nt = 0; nt < SN; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[sm][nt][r] = 0.f;
 
     // gathered A (G == 1): the pixel of each of this thread's four rows is fixed over the K loop
     int gy[4] = {0, 0, 0, 0}, gx[4] = {0, 0, 0, 0}, gb[4] = {-1, -1, -1, -1};
     if (G == 1) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = m0 + ((tid + i * 256) >> 3);
+            const int m = m0 + ((tid + i * NTHR) >> 3);
             if (m < M) {
                 const int x_ = m % cg.Wm, t_ = m / cg.Wm;
                 const int y_ = t_ % cg.Hm, n_ = t_ / cg.Hm;
@@ -75,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ 
     // gathered B (G == 2): the (kh, kw, c) of this thread's columns is fixed over the K loop
     int bkh = 0, bkw = 0, bc = -1;
     if (G == 2) {
-        const int nn = n0 + (tid & 15) * 4;
+        const int nn = n0 + (tid % (BN / 4)) * 4;
         if (nn < cg.kreal) {
             const int tap = nn / cg.Cs;
             bc = nn - tap * cg.Cs;
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ 
     if (fastp) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int k = kbeg + ((tid + i * 256) >> 4);
+            const int k = kbeg + ((tid + i * NTHR) / (BN / 4));
             px[i] = k % cg.Wm;
             const int t_ = k / cg.Wm;
             py[i] = t_ % cg.Hm;
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ 
         } else if (!TA) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int idx = tid + i * 256;
+                const int idx = tid + i * NTHR;
                 const int row = idx >> 3, q = idx & 7;
                 const int m = m0 + row, k = k0 + q * 4;
                 ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -164,8 +173,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ 
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int idx = tid + i * 256;
-                const int kk = idx >> 5, q = idx & 31;
+                const int idx = tid + i * NTHR;
+                const int kk = idx / (BM / 4), q = idx % (BM / 4);
                 const int k = k0 + kk, m = m0 + q * 4;
                 ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (k < kend && m < M) ra[i] = *reinterpret_cast<const float4 *>(A + (size_t)k * lda + m);
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ 
         if (G == 2) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int k = k0 + ((tid + i * 256) >> 4);
+                const int k = k0 + ((tid + i * NTHR) / (BN / 4));
                 int x_, y_, n_;
                 if (fastp) {                     // the pixel of this thread's K row, advanced by one K tile per fetch
                     x_ = px[i]; y_ = py[i]; n_ = pn[i];
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ 
         } else if (!TB) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int idx = tid + i * 256;
+                const int idx = tid + i * NTHR;
                 const int row = idx >> 3, q = idx & 7;
                 const int nn = n0 + row, k = k0 + q * 4;
                 rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -206,8 +215,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ 
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int idx = tid + i * 256;
-                const int kk = idx >> 4, q = idx & 15;
+                const int idx = tid + i * NTHR;
+                const int kk = idx / (BN / 4), q = idx % (BN / 4);
                 const int k = k0 + kk, nn = n0 + q * 4;
                 rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (k < kend && nn < N) rb[i] = *reinterpret_cast<const float4 *>(B + (size_t)k * ldb + nn);
@@ -219,64 +228,73 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float *__restrict__ 
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NTHR;
             if (!TA) *reinterpret_cast<float4 *>(&As[(idx >> 3) * A_LD + (idx & 7) * 4]) = ra[i];
-            else *reinterpret_cast<float4 *>(&As[(idx >> 5) * A_LD + (idx & 31) * 4]) = ra[i];
+            else *reinterpret_cast<float4 *>(&As[(idx / (BM / 4)) * A_LD + (idx % (BM / 4)) * 4]) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NTHR;
             if (!TB) *reinterpret_cast<float4 *>(&Bs[(idx >> 3) * B_LD + (idx & 7) * 4]) = rb[i];
-            else *reinterpret_cast<float4 *>(&Bs[(idx >> 4) * B_LD + (idx & 15) * 4]) = rb[i];
+            else *reinterpret_cast<float4 *>(&Bs[(idx / (BN / 4)) * B_LD + (idx % (BN / 4)) * 4]) = rb[i];
         }
         __syncthreads();
         if (k0 + GBK < kend) fetch(k0 + GBK);
 #pragma unroll
         for (int s = 0; s < GBK / 8; ++s) {
-            float a[4], b[2][4];
+            float a[SM][4], b[SN][4];
             const int kk = s * 8 + lh * 4;
-            if (!TA) {
-                const float4 v = *reinterpret_cast<const float4 *>(&As[(wave * 32 + li) * A_LD + kk]);
-                a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
-            } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) a[q] = As[(kk + q) * A_LD + wave * 32 + li];
+            for (int sm = 0; sm < SM; ++sm) {
+                const int row = (wm * SM + sm) * 32 + li;
+                if (!TA) {
+                    const float4 v = *reinterpret_cast<const float4 *>(&As[row * A_LD + kk]);
+                    a[sm][0] = v.x; a[sm][1] = v.y; a[sm][2] = v.z; a[sm][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[sm][q] = As[(kk + q) * A_LD + row];
+                }
             }
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < SN; ++nt) {
+                const int col = (wn * SN + nt) * 32 + li;
                 if (!TB) {
-                    const float4 v = *reinterpret_cast<const float4 *>(&Bs[(nt * 32 + li) * B_LD + kk]);
+                    const float4 v = *reinterpret_cast<const float4 *>(&Bs[col * B_LD + kk]);
                     b[nt][0] = v.x; b[nt][1] = v.y; b[nt][2] = v.z; b[nt][3] = v.w;
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) b[nt][q] = Bs[(kk + q) * B_LD + nt * 32 + li];
+                    for (int q = 0; q < 4; ++q) b[nt][q] = Bs[(kk + q) * B_LD + col];
                 }
             }
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int sm = 0; sm < SM; ++sm)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[nt] = mfma32(a[q], b[nt][q], acc[nt]);
+                for (int nt = 0; nt < SN; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[sm][nt] = mfma32(a[sm][q], b[nt][q], acc[sm][nt]);
         }
     }
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int nn = n0 + nt * 32 + li;
+    for (int sm = 0; sm < SM; ++sm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wave * 32 + mfma_row(r, lane);
-            if (m < M && nn < N) {
-                if (slab_stride) {
-                    C[(size_t)z * slab_stride + (size_t)m * slab_ld + nn] = acc[nt][r];
-                } else {
-                    float v = acc[nt][r] * bt.alpha;
-                    if (bias) v += bias[nn];
-                    const size_t o = (size_t)m * ldc + nn;
-                    if (accumulate) v += C[o];
-                    C[o] = v;
+        for (int nt = 0; nt < SN; ++nt) {
+            const int nn = n0 + (wn * SN + nt) * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * SM + sm) * 32 + mfma_row(r, lane);
+                if (m < M && nn < N) {
+                    if (slab_stride) {
+                        C[(size_t)z * slab_stride + (size_t)m * slab_ld + nn] = acc[sm][nt][r];
+                    } else {
+                        float v = acc[sm][nt][r] * bt.alpha;
+                        if (bias) v += bias[nn];
+                        const size_t o = (size_t)m * ldc + nn;
+                        if (accumulate) v += C[o];
+                        C[o] = v;
+                    }
                 }
             }
         }
-    }
 }
 
 __global__ void gemm_slab_reduce_kernel(const float *__restrict__ slabs, const float *__restrict__ bias,
@@ -345,6 +363,19 @@ __global__ void scale_dev_kernel(const float4 *__restrict__ a, const float *__re
 
 using namespace adyolo;
 
+// 256 x 128 tiles: built and measured in round 4 -- NOT faster: plain GEMMs 0.85-1.04 x of the
+// 128 x 64 form (head dX 0.72 x), implicit-GEMM convolutions 0.89-1.0 x, only the split-K weight-gradient shapes gain 2-4 %
+// (profiles/r04_gemm_tile_ab.txt).  One 8-wave workgroup per CU is the same two waves per SIMD as two 4-wave workgroups, but
+// all eight meet at every barrier.  Kept as an opt-in for that A/B: ADYOLO_GEMM_TILE=big (auto = where >= 256 such tiles
+// exist); the default is the 128 x 64 form everywhere.
+static bool gemm_big_tile(int M, int N, int splits, int batch) {
+    static const char *env = getenv("ADYOLO_GEMM_TILE");
+    if (!env || env[0] == 's') return false;
+    if (env[0] == 'b') return M >= 32 && N >= 32;
+    if (M < 256 || N < 128) return false;
+    return (long)cdiv(M, 256) * cdiv(N, 128) * splits * batch >= 256;
+}
+
 extern "C" int adyolo_scale_dev(const float *a, const float *scalar_dev, float *y, long n, void *stream) {
     ADYOLO_REQUIRE(a && scalar_dev && y && n > 0 && n % 4 == 0, ADYOLO_EINVAL, "scale_dev: n must be a positive multiple of 4");
     const long n4 = n / 4;
@@ -368,14 +399,21 @@ extern "C" int adyolo_gemm(const float *A, const float *B, const float *bias, fl
     hipStream_t st = as_stream(stream);
     int klen = cdiv(cdiv(K, splits), GBK) * GBK;
     splits = cdiv(K, klen);
-    dim3 grid((unsigned)cdiv(N, GBN), (unsigned)cdiv(M, GBM), (unsigned)splits);
+    const bool big = gemm_big_tile(M, N, splits, 1);
+    dim3 grid((unsigned)cdiv(N, big ? 128 : GBN), (unsigned)cdiv(M, big ? 256 : GBM), (unsigned)splits);
     const size_t slab_stride = splits > 1 ? (size_t)M * N : 0;
     float *out = splits > 1 ? slabs : C;
     GemmBatch bt{0, 0, 0, 0, 0, 0, 0, 1.0f};
     ConvGather cg{};
-#define LAUNCH(TA_, TB_)                                                                                       \
-    hipLaunchKernelGGL((gemm_kernel<TA_, TB_>), grid, dim3(256), 0, st, A, B, bias, out, M, N, K, lda, ldb, ldc, \
-                       klen, slab_stride, N, accumulate, bt, cg)
+#define LAUNCH(TA_, TB_)                                                                                                     \
+    do {                                                                                                                     \
+        if (big)                                                                                                             \
+            hipLaunchKernelGGL((gemm_kernel<TA_, TB_, 0, 4, 2, 2, 2>), grid, dim3(512), 0, st, A, B, bias, out, M, N, K, lda, ldb, \
+                               ldc, klen, slab_stride, N, accumulate, bt, cg);                                               \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((gemm_kernel<TA_, TB_>), grid, dim3(256), 0, st, A, B, bias, out, M, N, K, lda, ldb, ldc,       \
+                               klen, slab_stride, N, accumulate, bt, cg);                                                    \
+    } while (0)
     if (transA && transB) LAUNCH(true, true);
     else if (transA) LAUNCH(true, false);
     else if (transB) LAUNCH(false, true);
@@ -454,15 +492,25 @@ extern "C" int adyolo_conv_gemm(const float *src, const float *other, float *out
     ADYOLO_REQUIRE(splits == 1 || slabs, ADYOLO_EINVAL, "conv_gemm: splits > 1 needs a slab workspace");
     const int klen = cdiv(cdiv(K, splits), GBK) * GBK;
     splits = cdiv(K, klen);
-    dim3 grid((unsigned)cdiv(Nn, GBN), (unsigned)cdiv(M, GBM), (unsigned)splits);
+    const bool big = gemm_big_tile(M, Nn, splits, 1);
+    dim3 grid((unsigned)cdiv(Nn, big ? 128 : GBN), (unsigned)cdiv(M, big ? 256 : GBM), (unsigned)splits);
     const size_t slab_stride = splits > 1 ? (size_t)M * Nn : 0;
     float *dst = splits > 1 ? slabs : out;
-    if (mode == 2)
-        hipLaunchKernelGGL((gemm_kernel<true, true, 2>), grid, dim3(256), 0, st, other, src, bias, dst, M, Nn, K, Cout, 0,
-                           Nn, klen, slab_stride, Nn, 0, bt, cg);
-    else
-        hipLaunchKernelGGL((gemm_kernel<false, false, 1>), grid, dim3(256), 0, st, src, other, bias, dst, M, Nn, K, 0,
-                           mode == 0 ? Kp : Kq, Nn, klen, slab_stride, Nn, 0, bt, cg);
+    if (mode == 2) {
+        if (big)
+            hipLaunchKernelGGL((gemm_kernel<true, true, 2, 4, 2, 2, 2>), grid, dim3(512), 0, st, other, src, bias, dst, M, Nn, K,
+                               Cout, 0, Nn, klen, slab_stride, Nn, 0, bt, cg);
+        else
+            hipLaunchKernelGGL((gemm_kernel<true, true, 2>), grid, dim3(256), 0, st, other, src, bias, dst, M, Nn, K, Cout, 0,
+                               Nn, klen, slab_stride, Nn, 0, bt, cg);
+    } else {
+        if (big)
+            hipLaunchKernelGGL((gemm_kernel<false, false, 1, 4, 2, 2, 2>), grid, dim3(512), 0, st, src, other, bias, dst, M, Nn, K,
+                               0, mode == 0 ? Kp : Kq, Nn, klen, slab_stride, Nn, 0, bt, cg);
+        else
+            hipLaunchKernelGGL((gemm_kernel<false, false, 1>), grid, dim3(256), 0, st, src, other, bias, dst, M, Nn, K, 0,
+                               mode == 0 ? Kp : Kq, Nn, klen, slab_stride, Nn, 0, bt, cg);
+    }
     int rc = check_launch("conv_gemm");
     if (rc || splits == 1) return rc;
     const size_t total = (size_t)M * Nn;
