@@ -10,7 +10,10 @@ OUT = os.path.join(HERE, "libadyolo_hip.so")
 SOURCES = ["conv.hip", "wino.hip", "wino4.hip", "wino_b3.hip", "gemm.hip", "norm.hip", "seq.hip", "loss.hip", "losses.hip", "features.hip", "features_mic.hip", "conformer.hip", "attention.hip", "aug.hip", "optim.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # per-file additions.  wino4.hip: the depth of its B-fragment register ring (9, 12 or 18; 9 = 2304 matrix cycles ahead; 12 measured the same)
-EXTRA_FLAGS = {"wino4.hip": ["-DW4_BRING=9"]}
+# wino.hip: no SLP vectoriser -- it pairs the float4 transform arithmetic into v_pk_fma_f32 across DIFFERENT ds_read results and gathers
+# the operands with four v_mov per packed instruction (the weight-gradient loop: 223 vector instructions per 64 MFMAs with it, 159
+# without; every one of them costs MFMA issue time, DESIGN section 5 "Round 4")
+EXTRA_FLAGS = {"wino4.hip": ["-DW4_BRING=9"], "wino.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():

@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
     constexpr int DROW = 2 * CB * 8;              // floats per dy row slot
     constexpr int XSLOTS = 10, DSLOTS = 8;
     __shared__ __attribute__((aligned(16))) float Xs[XSLOTS * XROW];
-    __shared__ __attribute__((aligned(16))) float Dsh[DSLOTS * DROW];
+    __shared__ __attribute__((aligned(16))) float Dsh[(DSLOTS + 1) * DROW];          // + one row of zeros (see substep)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -452,7 +452,9 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
     const int ia = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
     const int ib = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float sg = wave == 1 ? 1.f : -1.f;
+    const float sgd = wave == 2 ? -1.f : 1.f;
     const int aoff = li * 8 + ((lh ^ ((li >> 3) & 1)) << 2);        // channel li, tile quad lh (swizzled)
+    for (int i = tid; i < DROW; i += 256) Dsh[DSLOTS * DROW + i] = 0.f;      // (made visible by the first barrier below)
 
     // staging roles.  x: channel xci, column phase xj, rows xr and xr + 2 of the step's four, all 8 tiles.
     // dy: channel dco, column phase dj, rows dr and dr + 2, DK tiles starting at tile dk0
@@ -630,8 +632,9 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
             __builtin_amdgcn_s_setprio(1);
             const float *xa = Xs + ((rb + ia) % XSLOTS) * XROW + aoff;
             const float *xb = Xs + ((rb + ib) % XSLOTS) * XROW + aoff;
-            const float *e0 = Dsh + (rb & (DSLOTS - 1)) * DROW + aoff;
-            const float *e1 = Dsh + ((rb + 1) & (DSLOTS - 1)) * DROW + aoff;
+            // dy side, row xi of A e A^T up to sign: wave 0: e0, wave 1: e0 + e1, wave 2: e0 - e1, wave 3: e1 (negated at the end)
+            const float *eP = Dsh + (wave == 3 ? DSLOTS : (rb & (DSLOTS - 1))) * DROW + aoff;
+            const float *eQ = Dsh + (wave == 0 ? DSLOTS : ((rb + 1) & (DSLOTS - 1))) * DROW + aoff;
             float4 r0, r1, r2, r3;
             {
                 const float4 a0 = *reinterpret_cast<const float4 *>(xa);
@@ -649,23 +652,18 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
             }
             // dy side, row xi of A e A^T up to sign: wave 0: e0, wave 1: e0 + e1, wave 2: e0 - e1, wave 3: e1 (negated
             // at the end); columns: nu 0: s0, 1: s0 + s1, 2: s0 - s1, 3: s1 (negated at the end)
+            // (round 4: branch-free.  Waves 0 and 3 used to read one dy row and the others two, under wave-uniform branches:
+            //  twelve scalar branches and ~60 register moves per tile row to merge the paths.  Now every wave reads two rows --
+            //  the missing one is a row of zeros kept behind the ring -- and forms P + sgd Q.)
             float4 s0[NT], s1[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                if (wave == 0) {
-                    s0[nt] = *reinterpret_cast<const float4 *>(e0 + nt * 32 * 8);
-                    s1[nt] = *reinterpret_cast<const float4 *>(e0 + (CB + nt * 32) * 8);
-                } else if (wave == 3) {
-                    s0[nt] = *reinterpret_cast<const float4 *>(e1 + nt * 32 * 8);
-                    s1[nt] = *reinterpret_cast<const float4 *>(e1 + (CB + nt * 32) * 8);
-                } else {
-                    const float4 p0 = *reinterpret_cast<const float4 *>(e0 + nt * 32 * 8);
-                    const float4 p1 = *reinterpret_cast<const float4 *>(e0 + (CB + nt * 32) * 8);
-                    const float4 q0 = *reinterpret_cast<const float4 *>(e1 + nt * 32 * 8);
-                    const float4 q1 = *reinterpret_cast<const float4 *>(e1 + (CB + nt * 32) * 8);
-                    s0[nt] = f4_fma(q0, sg, p0);          // sg = +1 for wave 1, -1 for wave 2
-                    s1[nt] = f4_fma(q1, sg, p1);
-                }
+                const float4 p0 = *reinterpret_cast<const float4 *>(eP + nt * 32 * 8);
+                const float4 p1 = *reinterpret_cast<const float4 *>(eP + (CB + nt * 32) * 8);
+                const float4 q0 = *reinterpret_cast<const float4 *>(eQ + nt * 32 * 8);
+                const float4 q1 = *reinterpret_cast<const float4 *>(eQ + (CB + nt * 32) * 8);
+                s0[nt] = f4_fma(q0, sgd, p0);
+                s1[nt] = f4_fma(q1, sgd, p1);
             }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(3);
