@@ -35,7 +35,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void gemm_kern
                                                       const float *__restrict__ bias, float *__restrict__ C,
                                                       int M, int N, int K, int lda, int ldb, int ldc, int klen,
                                                       size_t slab_stride, int slab_ld, int accumulate, GemmBatch bt,
-                                                      ConvGather cg) {
+                                                      ConvGather cg, int fastg) {
     static_assert(G == 0 || (G == 1 && !TA) || (G == 2 && TB), "gathered operand: k-major A or transposed B");
     constexpr int BM = 32 * WM * SM, BN = 32 * WN * SN, NTHR = 64 * WM * WN;
     static_assert(BM * 8 == 4 * NTHR && BN * 8 == 2 * NTHR, "staging: 4 + 2 float4 per thread and K tile");
@@ -118,9 +118,56 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void gemm_kern
             pn[i] = t_ / cg.Hm;
         }
     }
+    // Round 4, plain operands (G == 0) whose K range is whole tiles and whose extent fits a 31-bit byte offset (fastg, decided
+    // by the host): fetched through buffer descriptors.  A thread keeps one byte offset per staged float4 (rows beyond M / N: an
+    // out-of-range offset, answered with zeros), the K tile moves in the SCALAR offset: no vector address arithmetic, no bounds
+    // branches, no zero-fill per tile -- the old form spent ~110 vector instructions and 6 branches per tile beside 32 MFMAs,
+    // all of it on the issue port the fp32 MFMA uses ("Round 4").
+    int offA[4] = {0, 0, 0, 0}, offB[2] = {0, 0};
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    if (G == 0 && fastg) {
+        rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, (TA ? ((K - 1) * lda + M) : ((M - 1) * lda + K)) * 4, 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, (TB ? ((K - 1) * ldb + N) : ((N - 1) * ldb + K)) * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * NTHR;
+            if (!TA) {
+                const int m = m0 + (idx >> 3);
+                offA[i] = m < M ? (m * lda + (idx & 7) * 4) * 4 : (int)0x80000000;
+            } else {
+                const int m = m0 + (idx % (BM / 4)) * 4;
+                offA[i] = m < M ? ((idx / (BM / 4)) * lda + m) * 4 : (int)0x80000000;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * NTHR;
+            if (!TB) {
+                const int nn = n0 + (idx >> 3);
+                offB[i] = nn < N ? (nn * ldb + (idx & 7) * 4) * 4 : (int)0x80000000;
+            } else {
+                const int nn = n0 + (idx % (BN / 4)) * 4;
+                offB[i] = nn < N ? ((idx / (BN / 4)) * ldb + nn) * 4 : (int)0x80000000;
+            }
+        }
+    }
     // software pipeline: the next K tile is fetched into registers while the current one feeds the matrix cores
     float4 ra[4], rb[2];
     auto fetch = [&](int k0) {
+        if (G == 0 && fastg) {
+            const int sa = TA ? k0 * lda * 4 : k0 * 4, sb = TB ? k0 * ldb * 4 : k0 * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, offA[i], sa, 0));
+                ra[i] = make_float4(v.x, v.y, v.z, v.w);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, offB[i], sb, 0));
+                rb[i] = make_float4(v.x, v.y, v.z, v.w);
+            }
+            return;
+        }
         if (G == 1) {
             const int k = k0 + (tid & 7) * 4;
             int c, kh, kw;
@@ -368,6 +415,17 @@ using namespace adyolo;
 // (profiles/r04_gemm_tile_ab.txt).  One 8-wave workgroup per CU is the same two waves per SIMD as two 4-wave workgroups, but
 // all eight meet at every barrier.  Kept as an opt-in for that A/B: ADYOLO_GEMM_TILE=big (auto = where >= 256 such tiles
 // exist); the default is the 128 x 64 form everywhere.
+// plain operands through buffer descriptors: whole K tiles per split and both operands addressable with 31-bit byte offsets
+static int gemm_fast_fetch(int M, int N, int K, int lda, int ldb, int transA, int transB, int klen) {
+    static const char *env = getenv("ADYOLO_GEMM_FETCH");             // "old": the round-3 fetch (A/B measurements)
+    if (env && env[0] == 'o') return 0;
+    if (K % GBK != 0 || klen % GBK != 0) return 0;
+    const long ea = transA ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K);
+    const long eb = transB ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K);
+    const long lim = ((long)1 << 29) - 64;                            // floats: byte offsets (and scalar K offsets) stay below 2^31
+    return ea < lim && eb < lim ? 1 : 0;
+}
+
 static bool gemm_big_tile(int M, int N, int splits, int batch) {
     static const char *env = getenv("ADYOLO_GEMM_TILE");
     if (!env || env[0] == 's') return false;
@@ -400,6 +458,7 @@ extern "C" int adyolo_gemm(const float *A, const float *B, const float *bias, fl
     int klen = cdiv(cdiv(K, splits), GBK) * GBK;
     splits = cdiv(K, klen);
     const bool big = gemm_big_tile(M, N, splits, 1);
+    const int fastg = gemm_fast_fetch(M, N, K, lda, ldb, transA, transB, klen);
     dim3 grid((unsigned)cdiv(N, big ? 128 : GBN), (unsigned)cdiv(M, big ? 256 : GBM), (unsigned)splits);
     const size_t slab_stride = splits > 1 ? (size_t)M * N : 0;
     float *out = splits > 1 ? slabs : C;
@@ -409,10 +468,10 @@ extern "C" int adyolo_gemm(const float *A, const float *B, const float *bias, fl
     do {                                                                                                                     \
         if (big)                                                                                                             \
             hipLaunchKernelGGL((gemm_kernel<TA_, TB_, 0, 4, 2, 2, 2>), grid, dim3(512), 0, st, A, B, bias, out, M, N, K, lda, ldb, \
-                               ldc, klen, slab_stride, N, accumulate, bt, cg);                                               \
+                               ldc, klen, slab_stride, N, accumulate, bt, cg, fastg);                                        \
         else                                                                                                                 \
             hipLaunchKernelGGL((gemm_kernel<TA_, TB_>), grid, dim3(256), 0, st, A, B, bias, out, M, N, K, lda, ldb, ldc,       \
-                               klen, slab_stride, N, accumulate, bt, cg);                                                    \
+                               klen, slab_stride, N, accumulate, bt, cg, fastg);                                             \
     } while (0)
     if (transA && transB) LAUNCH(true, true);
     else if (transA) LAUNCH(true, false);
@@ -446,7 +505,7 @@ extern "C" int adyolo_gemm_batched(const float *A, const float *B, float *C, int
     ConvGather cg{};
 #define LAUNCHB(TA_, TB_)                                                                                     \
     hipLaunchKernelGGL((gemm_kernel<TA_, TB_>), grid, dim3(256), 0, st, A, B, bias, C, M, N, K, lda, ldb, ldc, \
-                       klen, slab_stride, N, accumulate, bt, cg)
+                       klen, slab_stride, N, accumulate, bt, cg, 0)
     if (transA && transB) LAUNCHB(true, true);
     else if (transA) LAUNCHB(true, false);
     else if (transB) LAUNCHB(false, true);
@@ -499,17 +558,17 @@ extern "C" int adyolo_conv_gemm(const float *src, const float *other, float *out
     if (mode == 2) {
         if (big)
             hipLaunchKernelGGL((gemm_kernel<true, true, 2, 4, 2, 2, 2>), grid, dim3(512), 0, st, other, src, bias, dst, M, Nn, K,
-                               Cout, 0, Nn, klen, slab_stride, Nn, 0, bt, cg);
+                               Cout, 0, Nn, klen, slab_stride, Nn, 0, bt, cg, 0);
         else
             hipLaunchKernelGGL((gemm_kernel<true, true, 2>), grid, dim3(256), 0, st, other, src, bias, dst, M, Nn, K, Cout, 0,
-                               Nn, klen, slab_stride, Nn, 0, bt, cg);
+                               Nn, klen, slab_stride, Nn, 0, bt, cg, 0);
     } else {
         if (big)
             hipLaunchKernelGGL((gemm_kernel<false, false, 1, 4, 2, 2, 2>), grid, dim3(512), 0, st, src, other, bias, dst, M, Nn, K,
-                               0, mode == 0 ? Kp : Kq, Nn, klen, slab_stride, Nn, 0, bt, cg);
+                               0, mode == 0 ? Kp : Kq, Nn, klen, slab_stride, Nn, 0, bt, cg, 0);
         else
             hipLaunchKernelGGL((gemm_kernel<false, false, 1>), grid, dim3(256), 0, st, src, other, bias, dst, M, Nn, K, 0,
-                               mode == 0 ? Kp : Kq, Nn, klen, slab_stride, Nn, 0, bt, cg);
+                               mode == 0 ? Kp : Kq, Nn, klen, slab_stride, Nn, 0, bt, cg, 0);
     }
     int rc = check_launch("conv_gemm");
     if (rc || splits == 1) return rc;
