@@ -125,9 +125,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void gemm_kern
     // all of it on the issue port the fp32 MFMA uses ("Round 4").
     int offA[4] = {0, 0, 0, 0}, offB[2] = {0, 0};
     __amdgpu_buffer_rsrc_t rsA, rsB;
-    if (G == 0 && fastg) {
+    const bool fastA = G != 1 && (fastg & 1), fastB = G != 2 && (fastg & 2);        // (the gathered operand keeps its own path)
+    if (fastA) {
         rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, (TA ? ((K - 1) * lda + M) : ((M - 1) * lda + K)) * 4, 0x00020000);
-        rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, (TB ? ((K - 1) * ldb + N) : ((N - 1) * ldb + K)) * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + i * NTHR;
@@ -139,6 +139,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void gemm_kern
                 offA[i] = m < M ? ((idx / (BM / 4)) * lda + m) * 4 : (int)0x80000000;
             }
         }
+    }
+    if (fastB) {
+        rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, (TB ? ((K - 1) * ldb + N) : ((N - 1) * ldb + K)) * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + i * NTHR;
@@ -154,21 +157,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void gemm_kern
     // software pipeline: the next K tile is fetched into registers while the current one feeds the matrix cores
     float4 ra[4], rb[2];
     auto fetch = [&](int k0) {
-        if (G == 0 && fastg) {
-            const int sa = TA ? k0 * lda * 4 : k0 * 4, sb = TB ? k0 * ldb * 4 : k0 * 4;
+        if (fastA) {
+            const int sa = TA ? k0 * lda * 4 : k0 * 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, offA[i], sa, 0));
                 ra[i] = make_float4(v.x, v.y, v.z, v.w);
             }
+        }
+        if (fastB) {
+            const int sb = TB ? k0 * ldb * 4 : k0 * 4;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, offB[i], sb, 0));
                 rb[i] = make_float4(v.x, v.y, v.z, v.w);
             }
-            return;
         }
-        if (G == 1) {
+        if (fastA) {
+        } else if (G == 1) {
             const int k = k0 + (tid & 7) * 4;
             int c, kh, kw;
             if (fastk) {
@@ -227,7 +233,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void gemm_kern
                 if (k < kend && m < M) ra[i] = *reinterpret_cast<const float4 *>(A + (size_t)k * lda + m);
             }
         }
-        if (G == 2) {
+        if (fastB) {
+        } else if (G == 2) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int k = k0 + ((tid + i * NTHR) / (BN / 4));
@@ -423,7 +430,7 @@ static int gemm_fast_fetch(int M, int N, int K, int lda, int ldb, int transA, in
     const long ea = transA ? ((long)(K - 1) * lda + M) : ((long)(M - 1) * lda + K);
     const long eb = transB ? ((long)(K - 1) * ldb + N) : ((long)(N - 1) * ldb + K);
     const long lim = ((long)1 << 29) - 64;                            // floats: byte offsets (and scalar K offsets) stay below 2^31
-    return ea < lim && eb < lim ? 1 : 0;
+    return ea < lim && eb < lim ? 3 : 0;                              // bit 0: operand A, bit 1: operand B
 }
 
 static bool gemm_big_tile(int M, int N, int splits, int batch) {
@@ -552,23 +559,27 @@ extern "C" int adyolo_conv_gemm(const float *src, const float *other, float *out
     const int klen = cdiv(cdiv(K, splits), GBK) * GBK;
     splits = cdiv(K, klen);
     const bool big = gemm_big_tile(M, Nn, splits, 1);
+    // the operand that is NOT gathered goes through the buffer-descriptor fetch: mode 2: A = dy [pixels][Cout] (transposed,
+    // lda = Cout); modes 0 / 1: B = the packed filter [Nn][K] (k-major, ldb = K)
+    const int fastg = mode == 2 ? (gemm_fast_fetch(M, 4, K, Cout, 4, 1, 1, klen) & 1)
+                                : (gemm_fast_fetch(4, Nn, K, 4, mode == 0 ? Kp : Kq, 0, 0, klen) & 2);
     dim3 grid((unsigned)cdiv(Nn, big ? 128 : GBN), (unsigned)cdiv(M, big ? 256 : GBM), (unsigned)splits);
     const size_t slab_stride = splits > 1 ? (size_t)M * Nn : 0;
     float *dst = splits > 1 ? slabs : out;
     if (mode == 2) {
         if (big)
             hipLaunchKernelGGL((gemm_kernel<true, true, 2, 4, 2, 2, 2>), grid, dim3(512), 0, st, other, src, bias, dst, M, Nn, K,
-                               Cout, 0, Nn, klen, slab_stride, Nn, 0, bt, cg, 0);
+                               Cout, 0, Nn, klen, slab_stride, Nn, 0, bt, cg, fastg);
         else
             hipLaunchKernelGGL((gemm_kernel<true, true, 2>), grid, dim3(256), 0, st, other, src, bias, dst, M, Nn, K, Cout, 0,
-                               Nn, klen, slab_stride, Nn, 0, bt, cg, 0);
+                               Nn, klen, slab_stride, Nn, 0, bt, cg, fastg);
     } else {
         if (big)
             hipLaunchKernelGGL((gemm_kernel<false, false, 1, 4, 2, 2, 2>), grid, dim3(512), 0, st, src, other, bias, dst, M, Nn, K,
-                               0, mode == 0 ? Kp : Kq, Nn, klen, slab_stride, Nn, 0, bt, cg, 0);
+                               0, mode == 0 ? Kp : Kq, Nn, klen, slab_stride, Nn, 0, bt, cg, fastg);
         else
             hipLaunchKernelGGL((gemm_kernel<false, false, 1>), grid, dim3(256), 0, st, src, other, bias, dst, M, Nn, K, 0,
-                               mode == 0 ? Kp : Kq, Nn, klen, slab_stride, Nn, 0, bt, cg, 0);
+                               mode == 0 ? Kp : Kq, Nn, klen, slab_stride, Nn, 0, bt, cg, fastg);
     }
     int rc = check_launch("conv_gemm");
     if (rc || splits == 1) return rc;

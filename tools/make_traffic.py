@@ -29,7 +29,7 @@ def main():
                  "FETCH_SIZE_KiB_mean": round(fetch, 1), "WRITE_SIZE_KiB_mean": round(write, 1),
                  "hbm_bytes_per_launch": int((2.0 * fetch + write) * 1024.0),
                  "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 2 --warmup 1 "
-                           "--no-cpu-baseline`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE halving correction)"}
+                           "--no-cpu-baseline --no-extra --no-pipeline --no-parity`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE halving correction)"}
     with open(out, "w") as f:
         json.dump(doc, f, indent=1, sort_keys=True)
     print(json.dumps(doc[algo]))
