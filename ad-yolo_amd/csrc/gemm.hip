@@ -154,6 +154,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void gemm_kern
             }
         }
     }
+    // Gathered A through a buffer descriptor too (fastg bit 2; forward, or data-gradient with unit strides; channel count a
+    // multiple of the K tile so that (kh, kw) is uniform per tile): the thread keeps the byte offset of its four pixels at tap
+    // (0, 0) -- biased by the largest negative tap displacement so that it is never negative: the range check looks at the vector
+    // offset alone -- the tap and channel of the tile go into the scalar offset, and a pixel / tap pair outside the source gets
+    // an out-of-range offset (zeros).  6 vector instructions per load instead of ~20 and no branch.
+    const bool fastGA = G == 1 && fastk && (fastg & 4);
+    int rowoff[4] = {0, 0, 0, 0};
+    __amdgpu_buffer_rsrc_t rsG;
+    if (fastGA) {
+        const int bias = cg.dgrad ? ((cg.KH - 1) * cg.Ws + (cg.KW - 1)) * cg.Cs : (cg.PH * cg.Ws + cg.PW) * cg.Cs;       // floats
+        rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A) - bias, 0, (cg.Hs * cg.Ws * cg.Cs * (M / (cg.Hm * cg.Wm)) + bias) * 4,
+                                                0x00020000);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pix = cg.dgrad ? gb[i] + (gy[i] - (cg.KH - 1)) * cg.Ws + gx[i] - (cg.KW - 1) : gb[i] + gy[i] * cg.Ws + gx[i];
+            rowoff[i] = gb[i] >= 0 ? (pix * cg.Cs + (tid & 7) * 4 + bias) * 4 : (int)0x80000000;
+        }
+    }
     // software pipeline: the next K tile is fetched into registers while the current one feeds the matrix cores
     float4 ra[4], rb[2];
     auto fetch = [&](int k0) {
@@ -174,6 +192,25 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void gemm_kern
             }
         }
         if (fastA) {
+        } else if (fastGA) {
+            const int kh = kh_run, kw = kw_run;
+            const int so = cg.dgrad ? (((cg.KH - 1 - kh) * cg.Ws + (cg.KW - 1 - kw)) * cg.Cs + c_run) * 4
+                                    : ((kh * cg.Ws + kw) * cg.Cs + c_run) * 4;
+            c_run += GBK;
+            if (c_run >= cg.Cs) {
+                c_run = 0;
+                if (++kw_run == cg.KW) {
+                    kw_run = 0;
+                    ++kh_run;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sy = cg.dgrad ? gy[i] - kh : gy[i] + kh, sx = cg.dgrad ? gx[i] - kw : gx[i] + kw;
+                const bool ok = (unsigned)sy < (unsigned)cg.Hs && (unsigned)sx < (unsigned)cg.Ws;
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, ok ? rowoff[i] : (int)0x80000000, so, 0));
+                ra[i] = make_float4(v.x, v.y, v.z, v.w);
+            }
         } else if (G == 1) {
             const int k = k0 + (tid & 7) * 4;
             int c, kh, kw;
@@ -561,8 +598,13 @@ extern "C" int adyolo_conv_gemm(const float *src, const float *other, float *out
     const bool big = gemm_big_tile(M, Nn, splits, 1);
     // the operand that is NOT gathered goes through the buffer-descriptor fetch: mode 2: A = dy [pixels][Cout] (transposed,
     // lda = Cout); modes 0 / 1: B = the packed filter [Nn][K] (k-major, ldb = K)
-    const int fastg = mode == 2 ? (gemm_fast_fetch(M, 4, K, Cout, 4, 1, 1, klen) & 1)
-                                : (gemm_fast_fetch(4, Nn, K, 4, mode == 0 ? Kp : Kq, 0, 0, klen) & 2);
+    int fastg = mode == 2 ? (gemm_fast_fetch(M, 4, K, Cout, 4, 1, 1, klen) & 1)
+                          : (gemm_fast_fetch(4, Nn, K, 4, mode == 0 ? Kp : Kq, 0, 0, klen) & 2);
+    // bit 2: the gathered operand of a forward / unit-stride data-gradient launch through a descriptor as well (whole K tiles
+    // inside one tap: source channels a multiple of the K tile; source below 2^29 floats incl. the tap bias)
+    if (fastg && mode != 2 && cg.Cs % GBK == 0 && (mode == 0 || (SH == 1 && SW == 1)) &&
+        (long)N * cg.Hs * cg.Ws * cg.Cs + (long)(KH * cg.Ws + KW) * cg.Cs < ((long)1 << 29))
+        fastg |= 4;
     dim3 grid((unsigned)cdiv(Nn, big ? 128 : GBN), (unsigned)cdiv(M, big ? 256 : GBM), (unsigned)splits);
     const size_t slab_stride = splits > 1 ? (size_t)M * Nn : 0;
     float *dst = splits > 1 ? slabs : out;
