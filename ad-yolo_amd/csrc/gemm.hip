@@ -125,7 +125,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void gemm_kern
     // all of it on the issue port the fp32 MFMA uses ("Round 4").
     int offA[4] = {0, 0, 0, 0}, offB[2] = {0, 0};
     __amdgpu_buffer_rsrc_t rsA, rsB;
-    const bool fastA = G != 1 && (fastg & 1), fastB = G != 2 && (fastg & 2);        // (the gathered operand keeps its own path)
+    // (k-major operands only: against the round-3 object the descriptor form of a TRANSPOSED operand measured 0-10 % slower --
+    //  profiles/r04_gemm_fetch_ab.txt -- so those keep the old fetch; the gathered operand has its own path below)
+    const bool fastA = G != 1 && !TA && (fastg & 1), fastB = G != 2 && !TB && (fastg & 2);
     if (fastA) {
         rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, (TA ? ((K - 1) * lda + M) : ((M - 1) * lda + K)) * 4, 0x00020000);
 #pragma unroll

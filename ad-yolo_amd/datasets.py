@@ -176,7 +176,9 @@ class AudioStager:
         self.consumed = [None, None]                                  # conversion kernel that read dev[i] (compute stream)
         self.cur = 0
 
-    def stage(self, clips):
+    def stage(self, clips, workers=1):
+        """workers > 1: the copy of the clips into the page-locked buffer is split over that many threads (tensor copies release the
+        GIL) -- one thread moves 3-5 GB/s of pageable memory, a 64 x 60 s batch is 737 MB: 0.15-0.25 s, longer than the step it feeds."""
         if len(clips) != self.shape[0]:
             raise ValueError("AudioStager: %d clips staged into a buffer of batch %d (a short final batch would leave "
                              "stale audio in the tail rows; use drop_last or a stager of that size)" % (len(clips), self.shape[0]))
@@ -187,8 +189,21 @@ class AudioStager:
         h = self.host[i]
         if self.consumed[i] is not None:
             self.events[i].synchronize()          # the previous copy out of this pinned buffer is done
-        for b, clip in enumerate(clips):
-            h[b].copy_(torch.as_tensor(np.asarray(clip), dtype=torch.int16))
+        def fill(lo, hi):
+            for b in range(lo, hi):
+                h[b].copy_(torch.as_tensor(np.asarray(clips[b]), dtype=torch.int16))
+        nb = len(clips)
+        workers = max(1, min(int(workers), nb))
+        if workers == 1:
+            fill(0, nb)
+        else:
+            import threading
+            step = (nb + workers - 1) // workers
+            ths = [threading.Thread(target=fill, args=(lo, min(nb, lo + step))) for lo in range(0, nb, step)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
         with torch.cuda.stream(self.stream):
             if self.consumed[i] is not None:
                 self.stream.wait_event(self.consumed[i])              # dev[i] has been converted by the compute stream

@@ -663,13 +663,13 @@ def main():
 
         def piped(i):
             a = stager.get()
-            th = threading.Thread(target=stager.stage, args=(host[(i + 1) & 1],))
+            th = threading.Thread(target=stager.stage, args=(host[(i + 1) & 1], 4))
             th.start()
             out = trainer.step(a, target)
             th.join()
             return out
         pipe_ms = timed_steps(piped, args.steps, max(1, args.warmup))
-        pipeline = {"input": "int16 clips in host memory -> pinned staging buffer (worker thread) -> H2D on a side stream -> "
+        pipeline = {"input": "int16 clips in host memory -> pinned staging buffer (4 worker threads) -> H2D on a side stream -> "
                              "adyolo_pcm16_to_f32 -> step; copy of batch k+1 overlaps step k",
                     "ms_per_step": round(pipe_ms, 3), "value": round(world * B * args.seconds / (pipe_ms * 1e-3), 2), "unit": "audio-s/s",
                     "h2d_MB_per_step_per_gpu": round(B * n_samples * 4 * 2 / 1e6, 1), "vs_resident": round(step_ms / pipe_ms, 4)}

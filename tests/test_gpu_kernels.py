@@ -1225,3 +1225,33 @@ def test_fused_dropout_residual_equals_the_two_separate_ops(ops):
         keep = (outs[0][1] != 0).float().mean().item()
         assert abs(keep - (1.0 - p)) < 0.02                      # the mask really is a dropout mask
         assert torch.equal(outs[0][2], dy)                        # b = 1: the residual gradient is the incoming one
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,kh,kw,sh,sw,ph,pw", [
+    (2, 37, 4, 64, 96, 3, 3, 1, 1, 1, 1),        # descriptor fetch of the gathered operand (channels % 32 == 0), ragged M / N tiles
+    (3, 50, 1, 128, 64, 3, 1, 1, 1, 1, 0),       # 3 x 1 taps on a width-1 map (the Conformer's narrow stages)
+    (2, 21, 6, 32, 32, 1, 1, 1, 1, 0, 0),        # 1 x 1
+    (2, 40, 8, 64, 128, 3, 3, 1, 2, 1, 1),       # strided: forward on the fast path, data-gradient on the general one
+    (2, 19, 5, 32, 64, 5, 3, 1, 1, 2, 1),        # wide taps: negative tap displacements up to 2 rows
+    (1, 33, 16, 8, 64, 7, 7, 1, 2, 3, 3),        # 8 input channels: the general path everywhere
+    (2, 16, 4, 48, 40, 3, 3, 1, 1, 1, 1),        # channels not a multiple of the K tile
+])
+def test_conv_gemm_all_modes_match_torch(ops, n, h, w, cin, cout, kh, kw, sh, sw, ph, pw):
+    """adyolo_conv_gemm (implicit GEMM, no column buffer) forward / data-gradient / weight-gradient against torch's convolution
+    in float64, over shapes that take the buffer-descriptor fetch (round 4) and shapes that take the general path."""
+    g = torch.Generator().manual_seed(n * 100 + h + cin + kh)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, kh, kw, generator=g) / np.sqrt(cin * kh * kw)
+    xo, wo = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    yo = F.conv2d(xo, wo, None, stride=(sh, sw), padding=(ph, pw))
+    dy = torch.randn(yo.shape, generator=g)
+    (yo * dy.double()).sum().backward()
+    geom = (n, h, w, cin, cout, kh, kw, sh, sw, ph, pw)
+    x8, dy8 = dev(x.permute(0, 2, 3, 1)), dev(dy.permute(0, 2, 3, 1))
+    y = ops.conv_gemm(0, x8, ops.pack_wk(dev(wt)), *geom)
+    dx = ops.conv_gemm(1, dy8, ops.pack_wk(dev(wt.transpose(0, 1))), *geom)
+    dw = ops.unpack_wk(ops.conv_gemm(2, x8, dy8, *geom), cout, cin, kh, kw)
+    torch.cuda.synchronize()
+    assert_close(y.permute(0, 3, 1, 2), yo.detach().float(), 2e-5, "conv_gemm forward")
+    assert_close(dx.permute(0, 3, 1, 2), xo.grad.float(), 2e-5, "conv_gemm data-gradient")
+    assert_close(dw, wo.grad.float(), 5e-5, "conv_gemm weight-gradient")
