@@ -174,12 +174,47 @@ __global__ __launch_bounds__(256, (WinoCfg<NT, ONE>::WG_PER_CU)) void wino_fwd_k
             }
 
     __syncthreads();                                      // affine table visible
-    {                                                     // first patch: both halves in flight together
-        float4 pw[APT / 2];
-        load_patch_into(pv, 0, 0);
-        load_patch_into(pw, 1, 0);
-        store_patch_from(pv, 0, lds, 0);
-        store_patch_from(pw, 1, lds, 0);
+    {
+        // First patch, all six pixels of the thread in flight together.  Round 4: its own code instead of the loop's
+        // load_patch / store_patch pair -- those recompute every index from scratch on both sides (the loop has no registers to
+        // keep them) and cost ~73 vector instructions per pixel incl. five quarter-rate integer multiplies; here the patch
+        // coordinates advance by increments (32 pixels = one row + 14 columns of the 18-wide patch), the source offset is one
+        // 24-bit multiply, out-of-image pixels are an out-of-range offset of a buffer descriptor (zeros) and offsets are kept
+        // for the store: ~26 per pixel.  The stage-1 kernel executed 15 vector instructions per MFMA, 44 % of them here
+        // (profiles/r04_pmc_stage1_vs_stage4.txt), and every one costs matrix-pipe time.
+        const __amdgpu_buffer_rsrc_t xrs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (size_t)n * H * W * Cin), 0, H * W * Cin * 4, 0x00020000);
+        const float4 isc = *reinterpret_cast<const float4 *>(&aff[sq * 4]);
+        const float4 ish = *reinterpret_cast<const float4 *>(&aff[AFFC + sq * 4]);
+        int hy = (spix0 * 3641) >> 16, hx = spix0 - hy * 18;
+        const int lds_first = ((hy * 2 + (hx & 1)) * WHALF + (hx >> 1)) * WAS;
+        f32x4 pf[APT];
+        int voff[APT], loff[APT];
+#pragma unroll
+        for (int ii = 0; ii < APT; ++ii) {
+            const bool real = ii < APT - 1 || spix0 + 32 * ii < 180;          // (only the sixth pixel can lie beyond the 180)
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            const bool ok = real && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            voff[ii] = ok ? (__mul24(__mul24(gy, W) + gx, Cin) + sq * 4) * 4 : (int)0x80000000;
+            loff[ii] = real ? ((hy * 2 + (hx & 1)) * WHALF + (hx >> 1)) * WAS + sq * 4 : lds_first + 32;   // (else: its first pixel's pad)
+            pf[ii] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff[ii], 0, 0));
+            hx += 14;
+            hy += 1;
+            if (hx >= 18) {
+                hx -= 18;
+                hy += 1;
+            }
+        }
+#pragma unroll
+        for (int ii = 0; ii < APT; ++ii) {
+            const bool ok = voff[ii] >= 0;
+            float4 o;
+            o.x = fmaf(pf[ii].x, isc.x, ok ? ish.x : 0.f);
+            o.y = fmaf(pf[ii].y, isc.y, ok ? ish.y : 0.f);
+            o.z = fmaf(pf[ii].z, isc.z, ok ? ish.z : 0.f);
+            o.w = fmaf(pf[ii].w, isc.w, ok ? ish.w : 0.f);
+            *reinterpret_cast<float4 *>(&lds[loff[ii]]) = o;
+        }
     }
     __syncthreads();
 
