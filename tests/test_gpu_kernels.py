@@ -914,9 +914,9 @@ def test_audio_stager_double_buffers(ops):
     from adyolo_amd.datasets import AudioStager
     rs = np.random.RandomState(0)
     st = AudioStager(3, 2400, "cuda:0")
-    batches = [rs.randint(-32768, 32768, size=(3, 2400, 4)).astype(np.int16) for _ in range(3)]
-    for pcm in batches:
-        st.stage(list(pcm))
+    batches = [rs.randint(-32768, 32768, size=(3, 2400, 4)).astype(np.int16) for _ in range(4)]
+    for i, pcm in enumerate(batches):
+        st.stage(list(pcm), workers=1 + i)            # (1, 2, 3 staging threads; 4 > batch: clamped)
         a = st.get()
         torch.cuda.synchronize()
         assert a.shape == (3, 2400, 4) and a.dtype == torch.float32
