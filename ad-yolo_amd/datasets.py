@@ -182,14 +182,23 @@ class AudioStager:
         if len(clips) != self.shape[0]:
             raise ValueError("AudioStager: %d clips staged into a buffer of batch %d (a short final batch would leave "
                              "stale audio in the tail rows; use drop_last or a stager of that size)" % (len(clips), self.shape[0]))
-        for clip in clips:
-            if tuple(clip.shape) != self.shape[1:]:
-                raise ValueError("AudioStager: clip of shape %s, expected %s" % (tuple(clip.shape), self.shape[1:]))
+        if isinstance(clips, torch.Tensor):
+            if tuple(clips.shape) != tuple(self.shape):
+                raise ValueError("AudioStager: batch of shape %s, expected %s" % (tuple(clips.shape), tuple(self.shape)))
+        else:
+            for clip in clips:
+                if tuple(clip.shape) != self.shape[1:]:
+                    raise ValueError("AudioStager: clip of shape %s, expected %s" % (tuple(clip.shape), self.shape[1:]))
         i = self.cur ^ 1
         h = self.host[i]
         if self.consumed[i] is not None:
             self.events[i].synchronize()          # the previous copy out of this pinned buffer is done
+        whole = isinstance(clips, torch.Tensor) and clips.dtype == torch.int16 and not clips.is_cuda
+
         def fill(lo, hi):
+            if whole:                              # one copy call per thread: one GIL round trip instead of one per clip (the
+                h[lo:hi].copy_(clips[lo:hi])       # launching thread holds the GIL almost all the time in a launch-bound step)
+                return
             for b in range(lo, hi):
                 h[b].copy_(torch.as_tensor(np.asarray(clips[b]), dtype=torch.int16))
         nb = len(clips)

@@ -654,25 +654,36 @@ def main():
     # with the step on the previous batch -> int16 -> float32 on the device -> the step.  `value` stays the resident-input rate.
     pipeline = None
     if args.pipeline:
-        import threading
         from adyolo_amd.datasets import AudioStager
         host = [torch.clamp(torch.round((audio.double() - 1e-8) * 32768.0), -32768, 32767).to(torch.int16).cpu()]   # the int16 the clips came from
         host.append(torch.flip(host[0], dims=[0]).contiguous())                    # a second batch: the same clips in reverse order
         stager = AudioStager(B, n_samples, device)
         stager.stage(host[0])
 
+        # ONE long-lived staging thread (a thread's first HIP call binds it to the device: ~0.1 s, which a thread per step
+        # would pay every step -- invisible behind a 133 ms step, 4 x a 23 ms one); the page-locked copy inside is split over 4 more
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=1)
+
         def piped(i):
             a = stager.get()
-            th = threading.Thread(target=stager.stage, args=(host[(i + 1) & 1], 4))
-            th.start()
+            fut = pool.submit(stager.stage, host[(i + 1) & 1], 4)
             out = trainer.step(a, target)
-            th.join()
+            fut.result()
             return out
-        pipe_ms = timed_steps(piped, args.steps, max(1, args.warmup))
+        # (a launch-bound step keeps the GIL busy: with the default 5 ms switch interval every Python-level operation of the staging
+        #  thread waits that long for it -- 20-50 ms per step at small shapes; 0.2 ms here, as a threaded input pipeline would set it)
+        old_si = sys.getswitchinterval()
+        sys.setswitchinterval(2e-4)
+        try:
+            pipe_ms = timed_steps(piped, args.steps, max(1, args.warmup))
+        finally:
+            sys.setswitchinterval(old_si)
         pipeline = {"input": "int16 clips in host memory -> pinned staging buffer (4 worker threads) -> H2D on a side stream -> "
                              "adyolo_pcm16_to_f32 -> step; copy of batch k+1 overlaps step k",
                     "ms_per_step": round(pipe_ms, 3), "value": round(world * B * args.seconds / (pipe_ms * 1e-3), 2), "unit": "audio-s/s",
                     "h2d_MB_per_step_per_gpu": round(B * n_samples * 4 * 2 / 1e6, 1), "vs_resident": round(step_ms / pipe_ms, 4)}
+        pool.shutdown()
         del stager, host
 
     stages = {}
