@@ -537,26 +537,45 @@ __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
                     for (int b = 0; b < 4; ++b) {
                         const int gx = tx0 + 4 * etc0 + b;
                         ok[it][b] = gy < H && gx < W;
-                        off[it][b] = ((min(gy, H - 1) * W + min(gx, W - 1)) * Cout + co) * 4;
+                        off[it][b] = (__mul24(__mul24(min(gy, H - 1), W) + min(gx, W - 1), Cout) + co) * 4;   // (full-rate 24-bit multiplies)
                     }
                 }
+                // Fused operands through buffer descriptors of the sample (round 4): a 32-bit offset per load instead of a 64-bit
+                // multiply-add (quarter rate) per pixel and operand.  ReLU-mask bits: the float4 with index i inside the tensor owns bit
+                // (i & 63) of the four 64-bit words at word (i >> 6) * 4; a sample starts on a word boundary (checked by the host:
+                // H W Cout / 4 % 64 == 0), so inside the sample's descriptor the words sit at byte (q >> 6) * 32 for quad q of the sample
+                // and the bit is fetched with 32-bit field extracts (the 64-bit variable shifts of mask_bits4 are two instructions each).
                 const size_t sbase = (size_t)n * H * W * Cout;    // floats
+                const int sbytes = H * W * Cout * 4;
+                auto rsrc_of = [&](const float *ptr, int bytes) {
+                    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ptr), 0, bytes, 0x00020000);
+                };
+                auto load4 = [&](const __amdgpu_buffer_rsrc_t &rs, int o_) {
+                    const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o_, 0, 0));
+                    return make_float4(t.x, t.y, t.z, t.w);
+                };
                 auto keep4 = [&](const float *mptr, bool bits, int o_) {
-                    bool kx, ky, kz, kw;
                     if (bits) {
-                        mask_bits4(reinterpret_cast<const unsigned long long *>(mptr), (sbase + (size_t)(o_ >> 2)) >> 2, kx, ky, kz, kw);
-                    } else {
-                        const float4 mk = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(mptr + sbase) + o_);
-                        kx = mk.x > 0.f; ky = mk.y > 0.f; kz = mk.z > 0.f; kw = mk.w > 0.f;
+                        const __amdgpu_buffer_rsrc_t rs = rsrc_of(mptr + (sbase >> 8) * 8, sbytes >> 5);      // (sbase / 4 / 64) * 4 words of 8 bytes
+                        const int q = o_ >> 4;                                                            // float4 index inside the sample
+                        const int wb = (q >> 6) * 32 + ((q >> 5) & 1) * 4, sh = q & 31;                        // byte of the low / high dword, bit
+                        const u32x4_t lo = __builtin_amdgcn_raw_buffer_load_b128(rs, (q >> 6) * 32, 0, 0);   // words x, y
+                        const u32x4_t hi = __builtin_amdgcn_raw_buffer_load_b128(rs, (q >> 6) * 32 + 16, 0, 0);   // words z, w
+                        (void)wb;
+                        const bool up = (q & 32) != 0;
+                        const unsigned wx = up ? lo[1] : lo[0], wy = up ? lo[3] : lo[2], wz = up ? hi[1] : hi[0], ww = up ? hi[3] : hi[2];
+                        return ((wx >> sh) & 1u) | (((wy >> sh) & 1u) << 1) | (((wz >> sh) & 1u) << 2) | (((ww >> sh) & 1u) << 3);
                     }
-                    return (kx ? 1u : 0u) | (ky ? 2u : 0u) | (kz ? 4u : 0u) | (kw ? 8u : 0u);
+                    const float4 mk = load4(rsrc_of(mptr + sbase, sbytes), o_);
+                    return (mk.x > 0.f ? 1u : 0u) | (mk.y > 0.f ? 2u : 0u) | (mk.z > 0.f ? 4u : 0u) | (mk.w > 0.f ? 8u : 0u);
                 };
                 if (AD) {
+                    const __amdgpu_buffer_rsrc_t ars = rsrc_of(addend + sbase, sbytes);
 #pragma unroll
                     for (int it = 0; it < 2; ++it)
 #pragma unroll
                         for (int b = 0; b < 4; ++b)
-                            ad[it][b] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(addend + sbase) + off[it][b]);
+                            ad[it][b] = load4(ars, off[it][b]);
                     if (MK) {
                         const bool bits = (mask_bits & 1) != 0;
 #pragma unroll
@@ -574,11 +593,12 @@ __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
                         for (int b = 0; b < 4; ++b) smk[it][b] = keep4(stat_mask, bits, off[it][b]);
                 }
                 if (has_aux) {
+                    const __amdgpu_buffer_rsrc_t xrs_ = rsrc_of(stat_aux + sbase, sbytes);
 #pragma unroll
                     for (int it = 0; it < 2; ++it)
 #pragma unroll
                         for (int b = 0; b < 4; ++b)
-                            ax[it][b] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(stat_aux + sbase) + off[it][b]);
+                            ax[it][b] = load4(xrs_, off[it][b]);
                 }
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
