@@ -104,8 +104,9 @@ SIGNATURES = {
     "adyolo_avgpool1d_bwd": (I, [P, P, I, I, I, I, F, P]),
     "adyolo_ln_fwd": (I, [P] * 4 + [L, I, F, P]),
     "adyolo_ln_bwd": (I, [P] * 7 + [L, I, F, P]),
-    "adyolo_attn_fwd": (I, [P] * 5 + [I, I, I, I, F, F, ctypes.c_uint32, P]),
-    "adyolo_attn_bwd": (I, [P] * 10 + [I, I, I, I, F, F, ctypes.c_uint32, P]),
+    "adyolo_attn_fwd": (I, [P] * 5 + [I, I, I, I, F, F, ctypes.c_uint32, P, P]),
+    "adyolo_attn_bwd": (I, [P] * 10 + [I, I, I, I, F, F, ctypes.c_uint32, P, P]),
+    "adyolo_seed32_dev": (I, [ctypes.c_uint64, ctypes.c_uint64, P, P, P]),
     "adyolo_attn_dropout_mask": (I, [P, I, I, I, F, ctypes.c_uint32, P]),
     "adyolo_foa_rotate": (I, [P, P, P, I, L, P]),
     "adyolo_pcm16_to_f32": (I, [P, P, L, P]),

@@ -51,7 +51,8 @@ struct AttnTiles {                  // two double-buffered 32-row tiles (34.8 KB
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                           const float *__restrict__ v, float *__restrict__ ctx,
                                                           float *__restrict__ lse2, int T, int H, float scale_log2e,
-                                                          unsigned seed, unsigned drop_thr, float keep_scale) {
+                                                          unsigned seed, const unsigned *__restrict__ seed_dev, unsigned drop_thr, float keep_scale) {
+    if (seed_dev) seed = *seed_dev;                       // (uniform: the seed a recorded step derives on the device, adyolo_seed32_dev)
     __shared__ __attribute__((aligned(16))) AttnTiles tl;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, col = lane & 31;
     const int h = blockIdx.y, b = blockIdx.z, E = H * AD;
@@ -184,7 +185,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ dctx, const float *__restrict__ lse2, const float *__restrict__ delta,
     float *__restrict__ dk, float *__restrict__ dv, int T, int H, float scale, float scale_log2e, unsigned seed,
-    unsigned drop_thr, float keep_scale) {
+    const unsigned *__restrict__ seed_dev, unsigned drop_thr, float keep_scale) {
+    if (seed_dev) seed = *seed_dev;
     __shared__ __attribute__((aligned(16))) AttnTiles tl;          // .k = Q tile, .v = dO tile
     __shared__ float row_lse[2][32], row_delta[2][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, col = lane & 31;
@@ -299,8 +301,9 @@ __builtin_amdgcn_s_setprio(0);
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ dctx, const float *__restrict__ lse2, const float *__restrict__ delta,
-    float *__restrict__ dq, int T, int H, float scale, float scale_log2e, unsigned seed, unsigned drop_thr,
-    float keep_scale) {
+    float *__restrict__ dq, int T, int H, float scale, float scale_log2e, unsigned seed, const unsigned *__restrict__ seed_dev,
+    unsigned drop_thr, float keep_scale) {
+    if (seed_dev) seed = *seed_dev;
     __shared__ __attribute__((aligned(16))) float kt_[2][32 * AKS];
     __shared__ __attribute__((aligned(16))) float vt_[2][32 * AKS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, col = lane & 31;
@@ -403,20 +406,38 @@ static inline unsigned drop_threshold(float p) {
 
 using namespace adyolo;
 
+// The 32-bit seed rng.DropoutStream.seed32 computes on the host, derived on the device from (seed, offset + *offset_dev): a recorded
+// step (graph.StepGraphs) replays it with the stream's current offset, and the attention kernels read it through `seed_dev`.
+__global__ void seed32_dev_kernel(unsigned long long seed, unsigned long long offset, const long long *__restrict__ offset_dev,
+                                  unsigned *__restrict__ out) {
+    const unsigned long long off = offset + (offset_dev ? (unsigned long long)*offset_dev : 0ull);
+    unsigned long long x = seed ^ (off * 0x9E3779B97F4A7C15ull);
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    out[0] = (unsigned)((x ^ (x >> 31)) & 0xFFFFFFFFull);
+}
+
+extern "C" int adyolo_seed32_dev(uint64_t seed, uint64_t offset, const int64_t *offset_dev, uint32_t *out, void *stream) {
+    ADYOLO_REQUIRE(out, ADYOLO_EINVAL, "seed32_dev: bad arguments");
+    hipLaunchKernelGGL(seed32_dev_kernel, dim3(1), dim3(1), 0, as_stream(stream), (unsigned long long)seed, (unsigned long long)offset,
+                       reinterpret_cast<const long long *>(offset_dev), out);
+    return check_launch("seed32_dev");
+}
+
 extern "C" int adyolo_attn_fwd(const float *q, const float *k, const float *v, float *ctx, float *lse2, int B, int T, int H,
-                               int D, float scale, float dropout_p, uint32_t seed, void *stream) {
+                               int D, float scale, float dropout_p, uint32_t seed, const uint32_t *seed_dev, void *stream) {
     ADYOLO_REQUIRE(q && k && v && ctx && B > 0 && T > 0 && H > 0, ADYOLO_EINVAL, "attn_fwd: bad arguments");
     ADYOLO_REQUIRE(D == AD && dropout_p >= 0.f && dropout_p < 1.f, ADYOLO_ENOSUP, "attn_fwd: head dimension %d (needs 64)", D);
     ADYOLO_REQUIRE((double)B * H * T * T < 4294967296.0, ADYOLO_ENOSUP, "attn_fwd: B*H*T*T exceeds the 32-bit dropout index");
     const unsigned thr = drop_threshold(dropout_p);
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(T, 128), H, B), dim3(256), 0, as_stream(stream), q, k, v, ctx, lse2, T, H,
-                       scale * 1.4426950408889634f, seed, thr, 1.0f / (1.0f - dropout_p));
+                       scale * 1.4426950408889634f, seed, seed_dev, thr, 1.0f / (1.0f - dropout_p));
     return check_launch("attn_fwd");
 }
 
 extern "C" int adyolo_attn_bwd(const float *q, const float *k, const float *v, const float *ctx, const float *dctx,
                                const float *lse2, float *delta, float *dq, float *dk, float *dv, int B, int T, int H, int D,
-                               float scale, float dropout_p, uint32_t seed, void *stream) {
+                               float scale, float dropout_p, uint32_t seed, const uint32_t *seed_dev, void *stream) {
     ADYOLO_REQUIRE(q && k && v && ctx && dctx && lse2 && delta && dq && dk && dv && B > 0 && T > 0 && H > 0, ADYOLO_EINVAL,
                    "attn_bwd: bad arguments");
     ADYOLO_REQUIRE(D == AD && dropout_p >= 0.f && dropout_p < 1.f, ADYOLO_ENOSUP, "attn_bwd: head dimension %d (needs 64)", D);
@@ -428,11 +449,11 @@ extern "C" int adyolo_attn_bwd(const float *q, const float *k, const float *v, c
     int rc = check_launch("attn_delta");
     if (rc) return rc;
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(cdiv(T, 128), H, B), dim3(256), 0, st, q, k, v, dctx, lse2, delta, dk, dv, T,
-                       H, scale, sl, seed, thr, ks);
+                       H, scale, sl, seed, seed_dev, thr, ks);
     rc = check_launch("attn_bwd_dkv");
     if (rc) return rc;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(cdiv(T, 128), H, B), dim3(256), 0, st, q, k, v, dctx, lse2, delta, dq, T, H,
-                       scale, sl, seed, thr, ks);
+                       scale, sl, seed, seed_dev, thr, ks);
     return check_launch("attn_bwd_dq");
 }
 

@@ -60,19 +60,32 @@ __global__ __launch_bounds__(256) void maxpool3_fwd_kernel(const float *__restri
         arg[i] = (unsigned char)bi;
     }
 }
+// Gather form (round 4): every input element sums the (at most six) windows it can be the maximum of, in a fixed order -- the
+// scatter form with atomicAdd made the Conformer step differ from run to run (and from its hipGraph replay) in the last bits.
 __global__ __launch_bounds__(256) void maxpool3_bwd_kernel(const float *__restrict__ dy,
                                                            const unsigned char *__restrict__ arg, float *__restrict__ dx,
-                                                           int H, int W, int C, int Wo, long total) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+                                                           int H, int W, int C, int Wo, long total_in) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total_in; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         long p = i / C;
-        const int wo = (int)(p % Wo);
-        p /= Wo;
-        const int h = (int)(p % H);
+        const int ww = (int)(p % W);
+        p /= W;
+        const int hh = (int)(p % H);
         const long n = p / H;
-        const int bi = arg[i];
-        const int hh = h - 1 + bi / 3, ww = wo * 2 - 1 + bi % 3;
-        atomicAdd(&dx[(((size_t)n * H + hh) * W + ww) * C + c], dy[i]);
+        float s = 0.f;
+        for (int kh = 0; kh < 3; ++kh) {
+            const int h = hh + 1 - kh;                     // window row whose tap kh is this input row
+            if (h < 0 || h >= H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int t = ww + 1 - kw;                 // = 2 wo
+                if (t < 0 || (t & 1)) continue;
+                const int wo = t >> 1;
+                if (wo >= Wo) continue;
+                const size_t o = (((size_t)n * H + h) * Wo + wo) * C + c;
+                if (arg[o] == kh * 3 + kw) s += dy[o];
+            }
+        }
+        dx[i] = s;
     }
 }
 
@@ -267,9 +280,9 @@ extern "C" int adyolo_maxpool3_bwd(const float *dy, const unsigned char *arg, fl
                                    int C, void *stream) {
     ADYOLO_REQUIRE(dy && arg && dx_zeroed && N > 0 && H > 0 && W > 0 && C > 0, ADYOLO_EINVAL, "maxpool3_bwd: bad arguments");
     const int Wo = (W + 2 - 3) / 2 + 1;
-    const long total = (long)N * H * Wo * C;
-    hipLaunchKernelGGL(maxpool3_bwd_kernel, dim3(ew_grid_c(total)), dim3(256), 0, as_stream(stream), dy, arg, dx_zeroed, H,
-                       W, C, Wo, total);
+    const long total_in = (long)N * H * W * C;
+    hipLaunchKernelGGL(maxpool3_bwd_kernel, dim3(ew_grid_c(total_in)), dim3(256), 0, as_stream(stream), dy, arg, dx_zeroed, H,
+                       W, C, Wo, total_in);
     return check_launch("maxpool3_bwd");
 }
 

@@ -859,7 +859,7 @@ def maxpool3_fwd(x):
 def maxpool3_bwd(dy, arg, w):
     _chk(dy)
     n, h, _, c = dy.shape
-    dx = _zeros(dy, n, h, w, c)
+    dx = _new(dy, n, h, w, c)                   # (gather form: every element is written)
     _c("adyolo_maxpool3_bwd", _p(dy), _p(arg), _p(dx), n, h, w, c, _stream())
     return dx
 
@@ -1001,14 +1001,31 @@ def gemm_batched(a, b, c, m, n, k, lda, ldb, ldc, trans_a, trans_b, outer, inner
 
 
 # ---------------------------------------------------------------------------------------------- attention (flash style)
+def _seed_args(seed):
+    """seed: an int, or a one-element int32 tensor on the device holding the 32-bit seed (``seed32_dev``: hipGraph replays)"""
+    if isinstance(seed, torch.Tensor):
+        return ctypes.c_uint32(0), _p(seed)
+    return ctypes.c_uint32(seed & 0xFFFFFFFF), None
+
+
+def seed32_dev(seed, offset, offset_dev):
+    """The value ``rng.DropoutStream.seed32`` computes on the host, computed on the device from (seed, offset + *offset_dev) into a
+    one-element int32 tensor: a recorded step replays it with the stream's current offset."""
+    out = torch.empty(1, dtype=torch.int32, device=offset_dev.device)
+    _c("adyolo_seed32_dev", ctypes.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), ctypes.c_uint64(offset & 0xFFFFFFFFFFFFFFFF), _p(offset_dev),
+       _p(out), _stream())
+    return out
+
+
 def attn_fwd(q, k, v, heads, scale, dropout_p=0.0, seed=0, want_lse=True):
     """q, k, v [B][T][heads*64] -> ctx [B][T][heads*64], lse2 [B][heads][T] (or None); scores never reach HBM."""
     _chk(q, k, v)
     b, t, e = q.shape
     ctxv = torch.empty_like(q)
     lse = _new(q, b, heads, t) if want_lse else None
+    sv, sp = _seed_args(seed)
     _c("adyolo_attn_fwd", _p(q), _p(k), _p(v), _p(ctxv), _p(lse), b, t, heads, e // heads, float(scale), float(dropout_p),
-       ctypes.c_uint32(seed & 0xFFFFFFFF), _stream())
+       sv, sp, _stream())
     return ctxv, lse
 
 
@@ -1017,8 +1034,9 @@ def attn_bwd(q, k, v, ctxv, dctx, lse, heads, scale, dropout_p=0.0, seed=0):
     b, t, e = q.shape
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     delta = _new(q, b, heads, t)
+    sv, sp = _seed_args(seed)
     _c("adyolo_attn_bwd", _p(q), _p(k), _p(v), _p(ctxv), _p(dctx), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), b, t, heads,
-       e // heads, float(scale), float(dropout_p), ctypes.c_uint32(seed & 0xFFFFFFFF), _stream())
+       e // heads, float(scale), float(dropout_p), sv, sp, _stream())
     return dq, dk, dv
 
 

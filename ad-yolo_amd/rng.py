@@ -22,7 +22,7 @@ class DropoutStream:
         self.dev = None
         self.dev_value = None      # what the host knows `dev` to hold
         self.capture_base = None
-        self.host_draws = 0        # mask() / seed32() calls: values computed on the host, which a recorded step cannot replay
+        self.host_draws = 0        # mask() calls: values computed on the host, which a recorded step cannot replay
 
     @staticmethod
     def _rank():
@@ -84,9 +84,15 @@ class DropoutStream:
         return key
 
     def seed32(self, n):
-        """A 32-bit seed for a kernel that draws ``n`` values from its own stateless hash; advances the stream by n."""
-        self._no_capture("seed32")
-        self.host_draws += 1
+        """A 32-bit seed for a kernel that draws ``n`` values from its own stateless hash; advances the stream by n.
+        Eager: an int computed here.  While a step is being captured (round 4): a one-element device tensor that
+        ``ops.seed32_dev`` fills with the same value derived from the device-side counter, so a replay draws what the eager
+        step at that offset would."""
+        if self.capture_base is not None:
+            from . import ops
+            t = ops.seed32_dev(self.seed, self.offset - self.capture_base, self.dev)
+            self.offset += int(n)
+            return t
         x = (self.seed ^ ((self.offset * 0x9E3779B97F4A7C15) & _MASK64)) & _MASK64
         x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _MASK64
         x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _MASK64

@@ -461,11 +461,15 @@ int adyolo_adam_step_dev(float *param, const float *grad, float *exp_avg, float 
  *   seed: 32-bit seed of the stateless dropout hash keep(b, h, query, key); forward and backward of one call must use
  *         the same (dropout_p, seed).  adyolo_attn_dropout_mask writes that mask ([B][H][T][T], values 0 or 1/(1-p)).
  * ---------------------------------------------------------------------------------------------- */
+/*   seed_dev (round 4; may be NULL): when non-NULL the kernels read the seed from this device word instead of `seed` -- a recorded
+ *         step replays with a seed derived on the device by adyolo_seed32_dev(seed64, offset, offset_dev, out): out[0] = the 32-bit
+ *         value the host-side stream (rng.DropoutStream.seed32) computes for (seed64, offset + *offset_dev). */
 int adyolo_attn_fwd(const float *q, const float *k, const float *v, float *ctx, float *lse2, int B, int T, int H, int D,
-                    float scale, float dropout_p, uint32_t seed, void *stream);
+                    float scale, float dropout_p, uint32_t seed, const uint32_t *seed_dev, void *stream);
 int adyolo_attn_bwd(const float *q, const float *k, const float *v, const float *ctx, const float *dctx,
                     const float *lse2, float *delta, float *dq, float *dk, float *dv, int B, int T, int H, int D,
-                    float scale, float dropout_p, uint32_t seed, void *stream);
+                    float scale, float dropout_p, uint32_t seed, const uint32_t *seed_dev, void *stream);
+int adyolo_seed32_dev(uint64_t seed, uint64_t offset, const int64_t *offset_dev /*or NULL*/, uint32_t *out, void *stream);
 int adyolo_attn_dropout_mask(float *mask, int B, int T, int H, float dropout_p, uint32_t seed, void *stream);
 
 #ifdef __cplusplus
