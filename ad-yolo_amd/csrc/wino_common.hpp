@@ -103,7 +103,7 @@ __device__ __forceinline__ void wino_epilogue(f32x16 (&acc)[4][NT], float *lds, 
             for (int q = 0; q < 4; ++q) {
                 const int gy = ty0 + 2 * mr + (q >> 1), gx = tx0 + 2 * mc + (q & 1);
                 ok[q] = gy < H && gx < W;
-                off[q] = ((min(gy, H - 1) * W + min(gx, W - 1)) * Cout + co) * 4;
+                off[q] = (__mul24(__mul24(min(gy, H - 1), W) + min(gx, W - 1), Cout) + co) * 4;      // (full-rate 24-bit multiplies)
             }
             if (AD) {
 #pragma unroll
