@@ -197,7 +197,10 @@ __global__ __launch_bounds__(256) void affine_kernel(const float *__restrict__ x
 // float4 index tid + 256 j, so when C/4 divides 256 (INV) its channel quad never changes -- the per-channel operands are
 // loaded once into registers (no 64-bit modulo, no L1 traffic per element) and EW_U independent float4 loads per tensor
 // are in flight before the first use.
-constexpr int EW_U = 4;
+#ifndef ADYOLO_EW_U
+#define ADYOLO_EW_U 4
+#endif
+constexpr int EW_U = ADYOLO_EW_U;
 
 template <bool INV>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
