@@ -24,112 +24,11 @@
 // a nine-slot register ring (half a group = 2304 matrix cycles ahead).  Epilogue: the xi-sum of A^T . A in registers, the
 // nu-sum through LDS in four rounds (one output row of the tiles per round), then bias / masked addend / ReLU / per-patch
 // BatchNorm sums as in conv.hip.
-#include <type_traits>
-#include "wino_common.hpp"
+#include "wino4_common.hpp"
+#include "wino4p_launch.hpp"
 
 namespace adyolo {
 namespace w4 {
-
-constexpr float PA = 0.75f, PB = 1.5f;                 // interpolation points +-PA, +-PB (besides 0 and infinity)
-constexpr float A2 = PA * PA, B2 = PB * PB, S2 = A2 + B2, P2 = A2 * B2;
-constexpr float A3 = PA * PA * PA, B3 = PB * PB * PB;
-
-typedef unsigned int u32x4_t __attribute__((__vector_size__(16)));
-
-template <int TC>
-struct Cfg {
-    static constexpr int TR = 32 / TC;                  // tile rows of a workgroup
-    static constexpr int LOG_TC = TC == 4 ? 2 : 3;
-    static constexpr int PR = 4 * TR + 2;               // patch rows
-    static constexpr int PS = PR * TC + 2;              // plane stride in 16-byte slots (== 2 mod 8: conflict-free writes)
-    static constexpr int CBS = 12 * PS + 4;             // slots per 8-channel buffer: 6 nu x 2 channel quads (== 4 mod 8)
-    static constexpr int CBUF = CBS * 4;                // floats per buffer
-    static constexpr int RS = 256 / (4 * TC);           // patch rows per full staging round (16 channels = 4 quads per pixel)
-    static constexpr int CBP = 72;                      // epilogue exchange row (64 channels + pad)
-    static constexpr int EXCH = 8 * 32 * CBP;
-    static constexpr int LDS_FLOATS = 4 * CBUF > 2 * EXCH ? 4 * CBUF : 2 * EXCH;   // the epilogue exchanges two output rows per round
-};
-
-
-// six-point data transform B^T along one direction, per component
-#define ADYOLO_W4_BT(F)                                                                   \
-    {                                                                                     \
-        const float e12 = fmaf(-B2, c[2].F, c[4].F), o12 = fmaf(-B2, c[1].F, c[3].F);      \
-        const float e34 = fmaf(-A2, c[2].F, c[4].F), o34 = fmaf(-A2, c[1].F, c[3].F);      \
-        const float t0 = fmaf(P2, c[0].F, fmaf(-S2, c[2].F, c[4].F));                     \
-        const float t5 = fmaf(P2, c[1].F, fmaf(-S2, c[3].F, c[5].F));                     \
-        t[0].F = t0;                                                                      \
-        t[1].F = fmaf(PA, o12, e12);                                                      \
-        t[2].F = fmaf(-PA, o12, e12);                                                     \
-        t[3].F = fmaf(PB, o34, e34);                                                      \
-        t[4].F = fmaf(-PB, o34, e34);                                                     \
-        t[5].F = t5;                                                                      \
-    }
-// (t may alias c)
-__device__ __forceinline__ void bt6(const float4 (&c)[6], float4 (&t)[6]) {
-    ADYOLO_W4_BT(x) ADYOLO_W4_BT(y) ADYOLO_W4_BT(z) ADYOLO_W4_BT(w)
-}
-__device__ __forceinline__ void bt6s(const float (&c)[6], float (&t)[6]) {      // the same on scalars
-    const float e12 = fmaf(-B2, c[2], c[4]), o12 = fmaf(-B2, c[1], c[3]);
-    const float e34 = fmaf(-A2, c[2], c[4]), o34 = fmaf(-A2, c[1], c[3]);
-    t[0] = fmaf(P2, c[0], fmaf(-S2, c[2], c[4]));
-    t[1] = fmaf(PA, o12, e12);
-    t[2] = fmaf(-PA, o12, e12);
-    t[3] = fmaf(PB, o34, e34);
-    t[4] = fmaf(-PB, o34, e34);
-    t[5] = fmaf(P2, c[1], fmaf(-S2, c[3], c[5]));
-}
-#undef ADYOLO_W4_BT
-// half of it for a half column: xi = 0, 1, 2 (hh = 0) or xi = 5, 3, 4 (hh = 1), in that order.  The pair terms use rows 1..4 in
-// both cases (K2 = B2, KP = PA or A2, PB: wave-uniform scalars), the single term rows z = (0, 2, 4) or (1, 3, 5): the caller
-// reads z through wave-uniform addresses, so there is no select and no branch here (two of the seven rows are read twice)
-__device__ __forceinline__ void bt3(const float4 (&c)[4], const float4 (&z)[3], float4 (&t)[3], float K2, float KP) {
-#define ADYOLO_W4_BT3(F)                                                                  \
-    {                                                                                     \
-        const float e = fmaf(-K2, c[1].F, c[3].F), o = fmaf(-K2, c[0].F, c[2].F);          \
-        t[0].F = fmaf(P2, z[0].F, fmaf(-S2, z[1].F, z[2].F));                             \
-        t[1].F = fmaf(KP, o, e);                                                          \
-        t[2].F = fmaf(-KP, o, e);                                                         \
-    }
-    ADYOLO_W4_BT3(x) ADYOLO_W4_BT3(y) ADYOLO_W4_BT3(z) ADYOLO_W4_BT3(w)
-#undef ADYOLO_W4_BT3
-}
-
-// output transform A^T along one direction: y[p] = sum_k AT[p][k] m[k]
-__device__ __forceinline__ void at4(float m0, float m1, float m2, float m3, float m4, float m5, float &y0, float &y1,
-                                    float &y2, float &y3) {
-    const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-    y0 = m0 + s12 + s34;
-    y1 = fmaf(PA, d12, PB * d34);
-    y2 = fmaf(A2, s12, B2 * s34);
-    y3 = fmaf(A3, d12, fmaf(B3, d34, m5));
-}
-
-#ifndef W4_BRING
-#define W4_BRING 18      // B fragments in flight per wave (9: 2304 matrix cycles ahead, 18: 4608)
-#endif
-#ifndef W4_WHATIF
-#define W4_WHATIF 0       // timing-only builds (results invalid): bit 0 no staging in the loop, 1 no B refills, 2 no A reads / transforms,
-                          // 3 no epilogue (one store per lane), 4 no MFMAs, 5 no staging loads, 6 no staging transforms, 7 no staging writes,
-                          // 8 no leftover-row round, 9 epilogue without its register->LDS half, 10 epilogue without its stores
-#endif
-
-// Four chained MFMAs on an accumulator tile that lives in ARCHITECTURAL registers.  A wave owns 18 tiles = 288 registers, the
-// accumulator half of the file holds 256: hipcc keeps the other two tiles in VGPRs but issues every MFMA in the AccVGPR form,
-// copying the tile in and out around each use (32 v_accvgpr moves per use, each read waiting for the MFMA to drain).  The "+v"
-// constraint pins the VGPR form.  s_nop 1: a just-written VGPR operand needs two wait states before an MFMA reads it, and hipcc
-// pads nothing inside an asm statement (cdna_hip_programming.md 5.7 item 2); the chain on one accumulator needs none, and
-// the tile's next reader is the epilogue, thousands of cycles later.
-__device__ __forceinline__ void mfma32x4_vgpr(f32x16 &c, const float4 &a, const float4 &b) {
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %1, %5, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %2, %6, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %3, %7, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %4, %8, %0"
-        : "+v"(c)
-        : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
-}
 
 template <int TC, bool AFF>
 __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
@@ -810,6 +709,35 @@ extern "C" int adyolo_wino4_fwd(const float *x, const float *u, const float *bia
         blocks = cdiv(nsp, xcd_div) * 8;
     }
     hipStream_t st = as_stream(stream);
+    // Persistent form (round 5, wino4p.hpp): one workgroup per CU walks the patches of its XCD slot.  Needs the XCD dealing
+    // (Cout / 64 in {1, 2, 4, 8}), no bias, masks given as bits, and one of the operand combinations it is instantiated for (the
+    // ones the SE-ResNet block launches); everything else, and ADYOLO_W4_PERSIST=0, takes the one-patch-per-workgroup kernel below.
+    const char *pe = getenv("ADYOLO_W4_PERSIST");
+    const int epi = (stats ? 1 : 0) | (addend ? 2 : 0) | (addend_mask ? 4 : 0) | (stat_aux ? 8 : 0) | (stat_mask ? 16 : 0);
+    const bool bits_ok = (!addend_mask || (mask_bits & 1)) && (!stat_mask || (mask_bits & 2));
+    if (xcd_div > 0 && bits_ok && !bias && !(pe && pe[0] == '0') && (epi == 0 || epi == 1 || epi == 9 || epi == 27 || epi == 31) &&
+        (size_t)H * W * Cout * 4 < ((size_t)1 << 31) && (long)H * W < (1L << 23)) {
+        static int ncus = 0;
+        if (ncus == 0) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8)
+                v = 256;
+            ncus = v;
+        }
+        const int njs = cdiv(nsp, xcd_div);
+        const int slots = njs < ncus / 8 ? njs : ncus / 8;
+        w4::W4Launch a = {x, u, bias, addend, addend_mask, in_scale, in_shift, y, stats, stat_aux, stat_mean, stat_invstd, stat_mask,
+                          H, W, Cin, Cout, patchesW, patchesH, nsp, ncb, xcd_div, relu, mask_bits, tc, slots * 8, st};
+        switch (epi) {
+            case 0: w4::launch_wino4p<0>(a); break;
+            case 1: w4::launch_wino4p<1>(a); break;
+            case 9: w4::launch_wino4p<9>(a); break;
+            case 27: w4::launch_wino4p<27>(a); break;
+            default: w4::launch_wino4p<31>(a); break;
+        }
+        return check_launch("wino4_fwd (persistent)");
+    }
 #define ADYOLO_WINO4_FWD(TC_, AFF_)                                                                                    \
     hipLaunchKernelGGL((w4::wino4_fwd_kernel<TC_, AFF_>), dim3((unsigned)blocks), dim3(256), 0, st, x, u, bias, addend,    \
                        addend_mask, in_scale, in_shift, y, stats, stat_aux, stat_mean, stat_invstd, stat_mask, H, W, Cin, \

@@ -1,0 +1,646 @@
+// K2w4p: the PERSISTENT form of the F(4x4,3x3) forward / data-gradient kernel (see wino4.hip for the algorithm and the
+// one-patch-per-workgroup form; nn.Conv2d at /root/reference/src/models/backbones/resnet.py:16,18).  Round 5; the default
+// wherever it is instantiated (wino4p_launch.hpp), ADYOLO_W4_PERSIST=0 selects the one-patch form.
+// One workgroup per CU walks its share of the patches of ONE 64-channel block (the U slice, the B ring and the XCD's L2
+// contents stay what they are); with one workgroup per CU nothing else hides a workgroup's prologue and epilogue, so
+//   * the software pipeline of the pair loop simply continues across patches: during the LAST pair of a patch the staging
+//     half of the pipeline loads / transforms / writes pair 0 of the NEXT patch (the one-patch form staged a clamped copy of
+//     the last pair there), and pair 1 of the next patch and its first B fragments are requested from inside the epilogue --
+//     the global-memory latency, the W-transform and the LDS round trip of a patch's first pair, and the launch of a
+//     workgroup, are paid once per workgroup instead of once per patch;
+//   * the epilogue no longer transforms in the accumulator-owning wave: the RAW accumulators go to LDS straight from the
+//     AccVGPRs (ds_write_b32 takes an AGPR data operand: no v_accvgpr_read, no VALU at all on the writer side; the registers
+//     are zeroed for the next patch while the stores drain), four rounds of [36 positions][8 accumulator rows][64 lanes]
+//     (73.7 KB, beside the 56 KB image of the next patch's pair 0), and the reader does the whole separable output transform
+//     A^T M A for its (tile, channel quad, output-row parity): rows 0 / 2 of A^T need only the sums m1 + m2, m3 + m4, rows 1 / 3
+//     only the differences, so splitting a tile's work by row parity between two threads duplicates no arithmetic.  A thread
+//     reads 30 float4 (lanes of a 16-lane ds_read_b128 group cover one 256-byte row: conflict-free), does 240 transform
+//     instructions and finishes 8 pixels x 4 channels per round.  Old epilogue: 576 accumulator reads + ~1700 VALU + 256
+//     ds_write_b32 per lane on the writer side alone.
+#pragma once
+#include "wino4_common.hpp"
+#include "wino4p_launch.hpp"
+
+namespace adyolo {
+namespace w4 {
+
+template <int TC>
+struct CfgP {
+    using C = Cfg<TC>;
+    static constexpr int XOFF = 2 * C::CBUF;              // floats: the exchange region starts at image buffer 2
+    static constexpr int XCH = 36 * 8 * 64;               // floats per exchange round
+    static constexpr int LDS_FLOATS = (XOFF + XCH > 4 * C::CBUF) ? XOFF + XCH : 4 * C::CBUF;
+};
+
+template <int TC, bool AFF, int EPI>
+__global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
+    const float *__restrict__ x, const float *__restrict__ u, const float *__restrict__ bias,
+    const float *__restrict__ addend, const float *__restrict__ addend_mask, const float *__restrict__ in_scale,
+    const float *__restrict__ in_shift, float *__restrict__ y, float *__restrict__ stats,
+    const float *__restrict__ stat_aux, const float *__restrict__ stat_mean, const float *__restrict__ stat_invstd,
+    const float *__restrict__ stat_mask, int H, int W, int Cin, int Cout, int patchesW, int patchesH, int nsp, int ncb,
+    int xcd_div, int relu, int mask_bits) {
+    using C = Cfg<TC>;
+    using CP = CfgP<TC>;
+    constexpr int PS = C::PS, CBUF = C::CBUF, RS = C::RS, PR = C::PR;
+    __shared__ __attribute__((aligned(16))) float lds[CP::LDS_FLOATS + 2 * WMAXC];
+    float *aff = lds + CP::LDS_FLOATS;                    // producer BatchNorm scale | shift
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    if (AFF)
+        for (int c = tid; c < Cin; c += 256) {
+            aff[c] = in_scale[c];
+            aff[WMAXC + c] = in_shift[c];
+        }
+    // workgroup -> (XCD, slot): channel block cb = xcd % ncb as in the one-patch form; the workgroup walks the patches
+    // sp = (slot + k * slots) * xcd_div + xcd / ncb, k = 0, 1, ...
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int cb = xcd % ncb;
+    const int spstep = (int)(gridDim.x >> 3) * xcd_div;
+    int sp = slot * xcd_div + xcd / ncb;
+    if (sp >= nsp) return;
+    const int co0 = cb * 64;
+    auto decode = [&](int sp_, int &n_, int &ty_, int &tx_) {
+        int t = sp_;
+        const int pw = t % patchesW;
+        t /= patchesW;
+        const int ph = t % patchesH;
+        n_ = __builtin_amdgcn_readfirstlane(t / patchesH);
+        ty_ = __builtin_amdgcn_readfirstlane(ph * (4 * C::TR));
+        tx_ = __builtin_amdgcn_readfirstlane(pw * (4 * TC));
+    };
+
+    auto opaque0 = [&]() {
+        int z;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+        return z;
+    };
+    // ---- GEMM-side constants (as in wino4_fwd_kernel)
+    const int nuF = wave == 0 ? 0 : wave == 1 ? 2 : wave == 2 ? 3 : 5;
+    const int nuH = wave < 2 ? 1 : 4;
+    const int hh = wave & 1;
+    const float K2 = hh ? A2 : B2, KP = hh ? PB : PA;
+    constexpr int ROW4 = 4 * TC * 16;
+    // (made again after every epilogue, from an opaque copy of tid: nothing but the accumulators and a handful of registers is
+    // live across an epilogue, which then has the register file of the one-patch kernel's epilogue to itself)
+    int oF[4], oH[3], oZ[3];
+    auto make_o = [&](int t_) {
+        const int li_ = t_ & 31, lh_ = (t_ >> 5) & 1;
+        const int tr = li_ >> C::LOG_TC, tc = li_ & (TC - 1);
+        int o_[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o_[j] = ((lh_ * PS + (4 * tr + ((tr + j) & 3)) * TC + tc) * 16);
+        const int planeF = nuF * 2 * PS * 16, planeH = nuH * 2 * PS * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) oF[j] = planeF + o_[j];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) oH[j] = planeH + o_[j + 1];
+        oZ[0] = planeH + (hh ? o_[1] : o_[0]);
+        oZ[1] = planeH + (hh ? o_[3] : o_[2]);
+        oZ[2] = planeH + (hh ? o_[2] : o_[1]) + ROW4;
+    };
+    // ---- staging geometry.  The item of a thread (patch row, tile column, channel quad) is the same for every patch; its six
+    // byte offsets inside the sample are (patch origin) + (thread constant), out-of-image columns -> 0x80000000 (see above).
+    // Two offset sets: F for the full rounds, L for the leftover rows; they move to the next patch at different steps.
+    const int rowb = W * Cin * 4, pixb = Cin * 4;
+    const unsigned nrec = (unsigned)H * (unsigned)rowb;
+    const size_t xsample = (size_t)H * W * Cin;
+    // The thread constants of the offset arithmetic are NOT kept across the pair loop (the loop lives at the 256-register
+    // limit): they are rebuilt from an opaque copy of tid wherever a patch's offsets are made (twice per patch).
+    int wbF0, wbF1, wbL;
+    {
+        const int stcF = (tid >> 2) & (TC - 1), yyF = tid >> (2 + C::LOG_TC);
+        const int stcL = (lane >> 2) & (TC - 1), yyL = 2 * RS + (lane >> (2 + C::LOG_TC));
+        auto wbof = [&](int sq4, int stc, int yy) {
+            const int q = yy >> 2;
+            const int brow = 4 * q + (((yy & 3) + q) & 3);       // storage row: rotation inside 4-row blocks
+            return (sq4 >> 1) * (CBUF * 4) + ((sq4 & 1) * PS + brow * TC + stc) * 16;
+        };
+        wbF0 = wbof(tid & 3, stcF, yyF);
+        wbF1 = wbof(tid & 3, stcF, yyF + RS);
+        wbL = yyL < PR ? wbof(lane & 3, stcL, yyL) : -1;
+    }
+    int offF[6], offL[6];
+    const float *xbF, *xbL;                               // sample bases of the patches the F / L loads belong to
+    // Wv: the image width, or 0 when there is no such patch (every column out of range: the loads fetch nothing)
+    auto set_off = [&](int (&off)[6], bool leftover, int ty_, int tx_, int Wv) {
+        const int t_ = tid + opaque0();
+        const int i_ = leftover ? (t_ & 63) : t_;
+        const int stc = (i_ >> 2) & (TC - 1), yy = (leftover ? 2 * RS : 0) + (i_ >> (2 + C::LOG_TC));
+        const bool rowok = !leftover || yy < PR;
+        const int base = (ty_ + yy - 1) * rowb + (tx_ + 4 * stc - 1) * pixb + (i_ & 3) * 16;
+        const int gx0 = tx_ + 4 * stc - 1;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            off[j] = (rowok && (unsigned)(gx0 + j) < (unsigned)Wv) ? base + j * pixb : (int)0x80000000;
+    };
+    auto st_load = [&](f32x4 (&p)[6], int round, int pr, bool on) {
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(round == 2 ? xbL : xbF), 0,
+                                                                              (int)nrec, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int vo = round == 0 ? offF[j] : round == 1 ? offF[j] + RS * rowb : (on ? offL[j] : (int)0x80000000);
+            p[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, pr * 64, 0));
+        }
+    };
+    // (the pixels in flight are ext-vector values, not float4 structs: with the struct form the SLP vectoriser paired component
+    // stores ACROSS array elements in the AFF kernels and the arrays stayed in private memory)
+    auto st_xform = [&](f32x4 (&p)[6], int round, int pr) {
+        if (AFF) {
+            // x' = scale * x + shift on in-image pixels; out-of-image pixels were read as 0 and must stay 0
+            const int sq4 = (round == 2 ? lane : tid) & 3;
+            const f32x4 isc = *reinterpret_cast<const f32x4 *>(&aff[pr * 16 + sq4 * 4]);
+            const f32x4 ish = *reinterpret_cast<const f32x4 *>(&aff[WMAXC + pr * 16 + sq4 * 4]);
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int vo = round == 0 ? offF[j] : round == 1 ? offF[j] + RS * rowb : offL[j];
+                const bool ok = (unsigned)vo < nrec;
+                p[j] = __builtin_elementwise_fma(p[j], isc, ok ? ish : zero);
+            }
+        }
+        bt6v(p);
+    };
+    auto st_write = [&](const f32x4 (&tt)[6], int round, float *Cn) {
+        const int wb = round == 0 ? wbF0 : round == 1 ? wbF1 : wbL;
+        if (round < 2 || wb >= 0) {
+            char *dst = reinterpret_cast<char *>(Cn) + wb;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4 *>(dst + j * 2 * PS * 16) = tt[j];
+        }
+    };
+    auto st_store = [&](f32x4 (&p)[6], int round, float *Cn, int pr) {
+        st_xform(p, round, pr);
+        st_write(p, round, Cn);
+    };
+
+    const int nkg = Cin / 8, npairs = Cin / 16;           // (npairs is even: Cin % 32 == 0)
+    const size_t ustride_pos = (size_t)(Cout / 32) * nkg * 256;
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(u), 0, (int)(36 * ustride_pos * 4), 0x00020000);
+    const int ulane = lane * 16;
+    const int uwave = (int)((((size_t)(wave * 9) * (Cout / 32) + (size_t)cb * 2) * nkg * 256) * 4);
+    auto bload = [&](int uu, int kg) {
+        const int s = uu >> 1, nt = uu & 1;
+        const int so = uwave + (int)((s * ustride_pos + ((size_t)nt * nkg + kg) * 256) * 4);
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, ulane, so, 0));
+        return make_float4(v[0], v[1], v[2], v[3]);
+    };
+    constexpr int BR = W4_BRING;
+    float4 bq[BR];
+#pragma unroll
+    for (int uu = 0; uu < BR; ++uu) bq[uu] = bload(uu % 18, (uu / 18) % nkg);
+
+    int n, ty0, tx0;
+    decode(sp, n, ty0, tx0);
+    set_off(offF, false, ty0, tx0, W);
+    set_off(offL, true, ty0, tx0, W);
+    xbF = xbL = x + (size_t)n * xsample;
+
+    f32x16 acc[9][2];
+    f32x4 pvA[6], pvB[6];
+    __syncthreads();                                      // affine table visible
+    // pair 0 of the first patch: all staging rounds in flight together (the accumulators are zeroed while they are)
+    st_load(pvA, 0, 0, true);
+    st_load(pvB, 1, 0, true);
+#pragma unroll
+    for (int s = 0; s < 9; ++s)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][nt][r] = 0.f;
+    st_store(pvA, 0, lds, 0);
+    st_load(pvA, 2, 0, wave == 0);                        // leftover rows
+    st_store(pvB, 1, lds, 0);
+    if (wave == 0) st_store(pvA, 2, lds, 0);
+    st_load(pvA, 0, 1, true);                             // rounds 0 and 1 of pair 1 (npairs >= 2)
+    st_load(pvB, 1, 1, true);
+    __syncthreads();
+
+    float4 cF[6], cP[4], cZ[3];
+    float4 a[9];
+    int bF[4], bH[3], bZ[3];
+    const char *ldsb = reinterpret_cast<const char *>(lds);
+    auto a_reads_full = [&](int g) {
+        cF[0] = *reinterpret_cast<const float4 *>(ldsb + bF[0] + g * (CBUF * 4));
+        cF[1] = *reinterpret_cast<const float4 *>(ldsb + bF[1] + g * (CBUF * 4));
+        cF[2] = *reinterpret_cast<const float4 *>(ldsb + bF[2] + g * (CBUF * 4));
+        cF[3] = *reinterpret_cast<const float4 *>(ldsb + bF[3] + g * (CBUF * 4));
+        cF[4] = *reinterpret_cast<const float4 *>(ldsb + bF[1] + g * (CBUF * 4) + ROW4);
+        cF[5] = *reinterpret_cast<const float4 *>(ldsb + bF[2] + g * (CBUF * 4) + ROW4);
+    };
+    auto a_reads_half = [&](int g) {
+        cP[0] = *reinterpret_cast<const float4 *>(ldsb + bH[0] + g * (CBUF * 4));
+        cP[1] = *reinterpret_cast<const float4 *>(ldsb + bH[1] + g * (CBUF * 4));
+        cP[2] = *reinterpret_cast<const float4 *>(ldsb + bH[2] + g * (CBUF * 4));
+        cP[3] = *reinterpret_cast<const float4 *>(ldsb + bH[0] + g * (CBUF * 4) + ROW4);
+        cZ[0] = *reinterpret_cast<const float4 *>(ldsb + bZ[0] + g * (CBUF * 4));
+        cZ[1] = *reinterpret_cast<const float4 *>(ldsb + bZ[1] + g * (CBUF * 4));
+        cZ[2] = *reinterpret_cast<const float4 *>(ldsb + bZ[2] + g * (CBUF * 4));
+    };
+    auto a_xform_full = [&]() {
+        float4 tF[6];
+        bt6(cF, tF);
+#pragma unroll
+        for (int s = 0; s < 6; ++s) a[s] = tF[s];
+    };
+    auto a_xform_half = [&]() {
+        float4 tH[3];
+        bt3(cP, cZ, tH, K2, KP);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) a[6 + s] = tH[s];
+    };
+    auto pair_bases = [&](int pr) {
+        const int pboff = (pr & 1) * (2 * CBUF * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bF[j] = oF[j] + pboff;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            bH[j] = oH[j] + pboff;
+            bZ[j] = oZ[j] + pboff;
+        }
+    };
+
+    // next patch of this workgroup (decoded while the current one runs)
+    int spn, nn = 0, nty = 0, ntx = 0, Wn = 0;
+
+    // One pair of the pipeline (the 36 steps of wino4_fwd_kernel).  The same code runs for every pair of a patch, the last one
+    // included: there the image being staged is pair 0 of the next patch, and the requests for ITS pair 1, the first A fragments
+    // and the B fragments past the end are issued as always but never used -- the epilogue issues them again when their
+    // registers are free (by then they are L2 hits).  No run-time condition around a load or an LDS read (the compiler's
+    // vmcnt / lgkmcnt bookkeeping stays exact), and nothing of them is live across the epilogue.
+    auto pair_body = [&](int pr) {
+        float *Cn = lds + ((pr + 1) & 1) * (2 * CBUF);
+        const int prn = pr + 1 < npairs ? pr + 1 : 0;                          // pair being staged
+        const int prn2 = pr + 2 < npairs ? pr + 2 : pr + 2 - npairs;           // pair being requested
+        const bool lwave = wave == (pr & 3);                                   // this wave stages the leftover rows of the pair
+        const bool turn = pr == npairs - 2;                                    // the requests move on to the next patch in this pair
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int step = half * 18 + 2 * s + nt;
+                    const int slot_ = step % BR;
+                    // ---- side work of the step
+                    if (step == 2) a_xform_half();
+                    if (step == 12) a_xform_full();
+                    if (step == 18) a_xform_half();
+                    if (step == 30) a_xform_full();                            // the next pair's first group
+                    if (step == 4) st_xform(pvA, 0, prn);
+                    if (step == 12) st_xform(pvB, 1, prn);
+                    if (step == 6) st_write(pvA, 0, Cn);
+                    if (step == 14) st_write(pvB, 1, Cn);
+                    if (step == 22 && lwave) st_store(pvA, 2, Cn, prn);
+                    // full-round requests from step 16 on and leftover-row requests from the next pair's step 8 on belong to the
+                    // next patch (every transform of this patch's data that needs the old offsets is done by then)
+                    if (step == 13 && turn) {
+                        set_off(offF, false, nty, ntx, Wn);
+                        xbF = x + (size_t)nn * xsample;
+                    }
+                    if (step == 23 && turn) {
+                        set_off(offL, true, nty, ntx, Wn);
+                        xbL = x + (size_t)nn * xsample;
+                    }
+                    if (s < 8) {
+                        asm volatile("" : "+v"(a[s].x));
+                        acc[s][nt] = mfma32(a[s].x, bq[slot_].x, acc[s][nt]);
+                        acc[s][nt] = mfma32(a[s].y, bq[slot_].y, acc[s][nt]);
+                        acc[s][nt] = mfma32(a[s].z, bq[slot_].z, acc[s][nt]);
+                        acc[s][nt] = mfma32(a[s].w, bq[slot_].w, acc[s][nt]);
+                        asm volatile("" : "+a"(acc[s][nt]));
+                    } else {
+                        mfma32x4_vgpr(acc[s][nt], a[s], bq[slot_]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // ---- loads of the step
+                    {
+                        const int v = step + BR;
+                        const int kgv = 2 * pr + v / 18;
+                        bq[slot_] = bload(v % 18, kgv < nkg ? kgv : kgv - nkg);  // (wraps: the next patch uses the same U)
+                    }
+                    if (step == 24) {
+                        __syncthreads();                                       // the next pair's image is complete
+                        pair_bases(pr + 1);
+                    }
+                    if (step == 8) a_reads_full(1);
+                    if (step == 16) a_reads_half(1);
+                    if (step == 28) a_reads_full(0);                           // (bases: the next pair's already)
+                    if (step == 32) a_reads_half(0);
+                    if (step == 25) st_load(pvA, 0, prn2, true);
+                    if (step == 16) st_load(pvB, 1, prn2, true);
+                    if (step == 8) st_load(pvA, 2, prn, lwave);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    };
+
+    // ---- epilogue
+    constexpr int DPOS[6][6] = {{0, 1, 2, 3, 4, 5},       {6, 7, 8, 16, 17, 15},   {9, 10, 11, 12, 13, 14},
+                                {18, 19, 20, 21, 22, 23}, {24, 25, 26, 34, 35, 33}, {27, 28, 29, 30, 31, 32}};   // [nu][xi] -> position
+    const size_t ysample = (size_t)H * W * Cout;
+    const int sbytes = H * W * Cout * 4;
+    auto rsrc_of = [&](const float *ptr, int bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ptr), 0, bytes, 0x00020000);
+    };
+    auto load4 = [&](const __amdgpu_buffer_rsrc_t &rs, int o_) {
+        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o_, 0, 0));
+        return make_float4(t.x, t.y, t.z, t.w);
+    };
+
+    make_o(tid + opaque0());
+    pair_bases(0);
+    a_reads_full(0);
+    a_xform_full();
+    a_reads_half(0);
+    for (;;) {
+        spn = sp + spstep;
+        const bool more = spn < nsp;
+        Wn = 0;
+        if (more) {
+            decode(spn, nn, nty, ntx);
+            Wn = W;
+        }
+        for (int pr = 0; pr < npairs; ++pr) pair_body(pr);
+        __syncthreads();                                  // every wave is done with image buffers 2, 3
+
+        // ---- epilogue of patch sp (n, ty0, tx0).  Its per-lane constants are made here, from an opaque copy of tid, and its
+        // pointer arguments are read from the kernel-argument segment through an opaque copy of its address (offsets: the
+        // kernel's signature), so that neither occupies registers across the pair loop.
+        constexpr bool ST = (EPI & 1) != 0, AD = (EPI & 2) != 0, MK = (EPI & 4) != 0, AUX = (EPI & 8) != 0, SMK = (EPI & 16) != 0;
+        typedef const char __attribute__((address_space(4))) *kargp_t;
+        kargp_t kp = (kargp_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        auto karg = [&](int o_) {
+            return reinterpret_cast<float *>(*reinterpret_cast<const unsigned long long __attribute__((address_space(4))) *>(kp + o_));
+        };
+        const int te = tid + opaque0();
+        const int par = wave >> 1;                        // output-row parity this wave finishes (rows par, par + 2 of a tile)
+        const int rrd = ((te >> 4) & 3) + 4 * (wave & 1), idx = te & 15, lhr = idx >> 3, c4 = idx & 7;
+        const char *xrd = ldsb + CP::XOFF * 4 + rrd * 256 + idx * 16;
+        float *xwr = lds + CP::XOFF + (wave * 9 * 8) * 64 + (te & 63);
+        float4 ssum[2], ssq[2];
+        ssum[0] = ssum[1] = ssq[0] = ssq[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const size_t sbase = (size_t)n * ysample;         // floats
+        const __amdgpu_buffer_rsrc_t yrs = rsrc_of(karg(56) + sbase, sbytes);                    // y
+#pragma unroll
+        for (int rnd = 0; rnd < 4; ++rnd) {
+            const int nt = rnd >> 1, rh = rnd & 1;
+            // ---- the thread's 8 pixels of the round: tile m (rows rh * 16 ..), channel quad co, output rows par and par + 2.
+            // Byte offset of the channel quad inside the sample; out-of-image pixels get 0x80000000: loads give 0, stores are dropped
+            const int m = 16 * rh + (rrd >> 2) * 8 + lhr * 4 + (rrd & 3);
+            const int tr = m >> C::LOG_TC, tc = m & (TC - 1);
+            const int co = co0 + nt * 32 + c4 * 4;
+            int off[2][4];
+            {
+                const int gx0 = tx0 + 4 * tc;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int gy = ty0 + 4 * tr + par + 2 * e;
+                    const int rowo = (__mul24(__mul24(gy, W) + gx0, Cout) + co) * 4;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) off[e][b] = (gy < H && gx0 + b < W) ? rowo + b * Cout * 4 : (int)0x80000000;
+                }
+            }
+            // ---- fused operands, requested BEFORE the accumulators go to LDS: their latency hides under the writer half, the
+            // barrier and the xi pass.  ReLU-mask bits: the float4 with index q inside the sample owns bit (q & 63) of four 64-bit
+            // words at byte (q >> 6) * 32 of the sample's mask (a sample starts on a word boundary: checked by the host); one dword
+            // per component holds the bit.  The 32 dwords of a mask are squeezed into ONE register (bit 4 pixel + component) right
+            // after the barrier -- they are small and mostly L2 hits, the operand tensors are not -- and a v_bfe_i32 with constant
+            // offsets turns a bit into an and-mask where it is applied.
+            float4 ad[2][4], ax[2][4];
+            unsigned amk_raw[2][4][4], smk_raw[2][4][4], amk = 0, smk = 0;
+            auto keep = [&](const float *mptr, unsigned (&mk)[2][4][4]) {
+                const __amdgpu_buffer_rsrc_t rs = rsrc_of(mptr + (sbase >> 8) * 8, sbytes >> 5);
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int q = off[e][b] >> 4;
+                        const int wo = off[e][b] >= 0 ? (q >> 6) * 32 + ((q >> 5) & 1) * 4 : (int)0x80000000;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) mk[e][b][k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, wo, k * 8, 0);
+                    }
+            };
+            auto squeeze = [&](const unsigned (&mk)[2][4][4]) {
+                unsigned r = 0;
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const unsigned sh = (unsigned)(off[e][b] >> 4) & 31u;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) r |= __builtin_amdgcn_ubfe(mk[e][b][k], sh, 1u) << (16 * e + 4 * b + k);
+                    }
+                return r;
+            };
+            if (AD) {
+                const __amdgpu_buffer_rsrc_t ars = rsrc_of(karg(24) + sbase, sbytes);           // addend
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) ad[e][b] = load4(ars, off[e][b]);
+                if (MK) keep(karg(32), amk_raw);                                                  // addend_mask
+            }
+            if (SMK) keep(karg(96), smk_raw);                                                     // stat_mask
+            if (AUX) {
+                const __amdgpu_buffer_rsrc_t xrs_ = rsrc_of(karg(72) + sbase, sbytes);           // stat_aux
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) ax[e][b] = load4(xrs_, off[e][b]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- writer: raw accumulators (rows rh * 8 .. + 7 of the 32 x 32 tile) of the wave's nine positions, straight from
+            // the AccVGPRs; the registers are zeroed for the next patch while the stores drain
+#pragma unroll
+            for (int s = 0; s < 9; ++s)
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    xwr[(s * 8 + rr) * 64] = acc[s][nt][rh * 8 + rr];
+                    acc[s][nt][rh * 8 + rr] = 0.f;
+                }
+            __syncthreads();
+            if (MK) amk = squeeze(amk_raw);
+            if (SMK) smk = squeeze(smk_raw);
+            // ---- reader, xi direction: Q[row][nu] for the thread's two rows (rows 0, 2 take the sums m1 + m2, m3 + m4, rows 1, 3
+            // the differences: a wave-uniform branch), two nu columns of reads in flight
+            float4 qa[6], qb[6];
+            {
+                float4 mm[2][5];
+                auto rd5 = [&](float4 (&d)[5], int nu) {
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) d[k] = *reinterpret_cast<const float4 *>(xrd + DPOS[nu][k + (par ? 1 : 0)] * 2048);
+                };
+                if (par == 0) {
+                    rd5(mm[0], 0);
+                    rd5(mm[1], 1);
+#pragma unroll
+                    for (int nu = 0; nu < 6; ++nu) {
+                        const float4(&v)[5] = mm[nu & 1];                       // m0 .. m4
+                        const float4 s12 = f4_add(v[1], v[2]), s34 = f4_add(v[3], v[4]);
+                        qa[nu] = f4_add(f4_add(v[0], s12), s34);
+                        qb[nu] = make_float4(fmaf(A2, s12.x, B2 * s34.x), fmaf(A2, s12.y, B2 * s34.y), fmaf(A2, s12.z, B2 * s34.z),
+                                             fmaf(A2, s12.w, B2 * s34.w));
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (nu + 2 < 6) rd5(mm[nu & 1], nu + 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                    rd5(mm[0], 0);
+                    rd5(mm[1], 1);
+#pragma unroll
+                    for (int nu = 0; nu < 6; ++nu) {
+                        const float4(&v)[5] = mm[nu & 1];                       // m1 .. m5
+                        const float4 d12 = f4_sub(v[0], v[1]), d34 = f4_sub(v[2], v[3]);
+                        qa[nu] = make_float4(fmaf(PA, d12.x, PB * d34.x), fmaf(PA, d12.y, PB * d34.y), fmaf(PA, d12.z, PB * d34.z),
+                                             fmaf(PA, d12.w, PB * d34.w));
+                        qb[nu] = make_float4(fmaf(A3, d12.x, fmaf(B3, d34.x, v[4].x)), fmaf(A3, d12.y, fmaf(B3, d34.y, v[4].y)),
+                                             fmaf(A3, d12.z, fmaf(B3, d34.z, v[4].z)), fmaf(A3, d12.w, fmaf(B3, d34.w, v[4].w)));
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (nu + 2 < 6) rd5(mm[nu & 1], nu + 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            if (rnd == 3) {
+                // The next patch's first pixel requests, made here -- after the last LDS reads of the epilogue, when their registers
+                // are free -- so that they land under the rest of the round: rounds 0 / 1 of its pair 1 (its pair 0 was staged by the
+                // last pair above).  Without a next patch every offset is out of range.
+                __builtin_amdgcn_sched_barrier(0);
+                set_off(offF, false, nty, ntx, Wn);
+                xbF = x + (size_t)nn * xsample;
+                st_load(pvA, 0, 1, true);
+                st_load(pvB, 1, 1, true);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- nu direction and the pixels (ReLU: one wave-uniform branch per round around two copies of the loop)
+            float4 smean = make_float4(0.f, 0.f, 0.f, 0.f), sinv = smean;
+            if (AUX) {
+                smean = *reinterpret_cast<const float4 *>(karg(80) + co);                         // stat_mean, stat_invstd
+                sinv = *reinterpret_cast<const float4 *>(karg(88) + co);
+            }
+            auto andf = [](float v, unsigned k) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & k); };
+            auto pixels = [&](auto RL_) {
+                constexpr bool RL = decltype(RL_)::value;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float4(&q)[6] = e ? qb : qa;
+                    float4 Y[4];
+                    at4(q[0].x, q[1].x, q[2].x, q[3].x, q[4].x, q[5].x, Y[0].x, Y[1].x, Y[2].x, Y[3].x);
+                    at4(q[0].y, q[1].y, q[2].y, q[3].y, q[4].y, q[5].y, Y[0].y, Y[1].y, Y[2].y, Y[3].y);
+                    at4(q[0].z, q[1].z, q[2].z, q[3].z, q[4].z, q[5].z, Y[0].z, Y[1].z, Y[2].z, Y[3].z);
+                    at4(q[0].w, q[1].w, q[2].w, q[3].w, q[4].w, q[5].w, Y[0].w, Y[1].w, Y[2].w, Y[3].w);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        float4 v = Y[b];
+                        const unsigned bit0 = 16 * e + 4 * b;
+                        if (AD) {
+                            float4 a_ = ad[e][b];
+                            if (MK)
+                                a_ = make_float4(andf(a_.x, (unsigned)__builtin_amdgcn_sbfe((int)amk, bit0, 1u)),
+                                                 andf(a_.y, (unsigned)__builtin_amdgcn_sbfe((int)amk, bit0 + 1, 1u)),
+                                                 andf(a_.z, (unsigned)__builtin_amdgcn_sbfe((int)amk, bit0 + 2, 1u)),
+                                                 andf(a_.w, (unsigned)__builtin_amdgcn_sbfe((int)amk, bit0 + 3, 1u)));
+                            v = f4_add(v, a_);
+                        }
+                        if (RL) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yrs, off[e][b], 0, 0);
+                        if (ST) {
+                            // out-of-image pixels and masked-out components count 0
+                            const unsigned kin = ~(unsigned)(off[e][b] >> 31);
+                            if (SMK)
+                                v = make_float4(andf(v.x, kin & (unsigned)__builtin_amdgcn_sbfe((int)smk, bit0, 1u)),
+                                                andf(v.y, kin & (unsigned)__builtin_amdgcn_sbfe((int)smk, bit0 + 1, 1u)),
+                                                andf(v.z, kin & (unsigned)__builtin_amdgcn_sbfe((int)smk, bit0 + 2, 1u)),
+                                                andf(v.w, kin & (unsigned)__builtin_amdgcn_sbfe((int)smk, bit0 + 3, 1u)));
+                            else
+                                v = make_float4(andf(v.x, kin), andf(v.y, kin), andf(v.z, kin), andf(v.w, kin));
+                            ssum[nt] = f4_add(ssum[nt], v);
+                            float4 w_ = v;
+                            if (AUX) {
+                                const float4 x_ = ax[e][b];
+                                w_ = make_float4((x_.x - smean.x) * sinv.x, (x_.y - smean.y) * sinv.y, (x_.z - smean.z) * sinv.z,
+                                                 (x_.w - smean.w) * sinv.w);
+                            }
+                            ssq[nt].x = fmaf(v.x, w_.x, ssq[nt].x);
+                            ssq[nt].y = fmaf(v.y, w_.y, ssq[nt].y);
+                            ssq[nt].z = fmaf(v.z, w_.z, ssq[nt].z);
+                            ssq[nt].w = fmaf(v.w, w_.w, ssq[nt].w);
+                        }
+                    }
+                }
+            };
+            if (relu) pixels(std::true_type{}); else pixels(std::false_type{});
+            if (rnd == 3) {
+                // ... and its first B fragments (L2 hits: the last pair requested them once already)
+#pragma unroll
+                for (int uu = 0; uu < BR; ++uu) bq[uu] = bload(uu % 18, (uu / 18) % nkg);
+            }
+            __syncthreads();                              // the exchange region is free again
+        }
+        if (ST) {
+            // per-patch, per-channel sums of the stored output, layout [2][patches][Cout] (see conv.hip); 32 thread groups
+            float *red = lds + CP::XOFF;                  // [2][32 groups][64]
+            const int grp = (te >> 4) * 2 + lhr;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                *reinterpret_cast<float4 *>(&red[(0 * 32 + grp) * 64 + nt * 32 + c4 * 4]) = ssum[nt];
+                *reinterpret_cast<float4 *>(&red[(1 * 32 + grp) * 64 + nt * 32 + c4 * 4]) = ssq[nt];
+            }
+            __syncthreads();
+            if (te < 128) {
+                const int c = te & 63, which = te >> 6;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+                for (int gI = 0; gI < 32; gI += 4) {
+                    s0 += red[(which * 32 + gI) * 64 + c];
+                    s1 += red[(which * 32 + gI + 1) * 64 + c];
+                    s2 += red[(which * 32 + gI + 2) * 64 + c];
+                    s3 += red[(which * 32 + gI + 3) * 64 + c];
+                }
+                karg(64)[(size_t)which * nsp * Cout + (size_t)sp * Cout + co0 + c] = (s0 + s1) + (s2 + s3);     // stats
+            }
+            __syncthreads();
+        }
+        if (!more) break;
+        sp = spn;
+        n = nn;
+        ty0 = nty;
+        tx0 = ntx;
+        // the loop's per-lane state again (see make_o), the leftover-row offsets of the patch, and the first A fragments of its
+        // pair 0 (whose image was complete before the epilogue)
+        make_o(tid + opaque0());
+        set_off(offL, true, ty0, tx0, W);
+        xbL = xbF;
+        pair_bases(0);
+        a_reads_full(0);
+        a_xform_full();
+        a_reads_half(0);
+    }
+}
+
+
+
+template <int EPI>
+void launch_wino4p(const W4Launch &a) {
+#define ADYOLO_WINO4P_FWD(TC_, AFF_)                                                                                       \
+    hipLaunchKernelGGL((wino4p_fwd_kernel<TC_, AFF_, EPI>), dim3((unsigned)a.grid), dim3(256), 0, a.st, a.x, a.u, a.bias,     \
+                       a.addend, a.addend_mask, a.in_scale, a.in_shift, a.y, a.stats, a.stat_aux, a.stat_mean,             \
+                       a.stat_invstd, a.stat_mask, a.H, a.W, a.Cin, a.Cout, a.patchesW, a.patchesH, a.nsp, a.ncb,          \
+                       a.xcd_div, a.relu, a.mask_bits)
+    if (a.tc == 8) {
+        if (a.in_scale) ADYOLO_WINO4P_FWD(8, true); else ADYOLO_WINO4P_FWD(8, false);
+    } else {
+        if (a.in_scale) ADYOLO_WINO4P_FWD(4, true); else ADYOLO_WINO4P_FWD(4, false);
+    }
+#undef ADYOLO_WINO4P_FWD
+}
+
+}  // namespace w4
+}  // namespace adyolo
