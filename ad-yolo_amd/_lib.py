@@ -34,8 +34,7 @@ SIGNATURES = {
     "adyolo_wino4_pack_many": (I, [P, I, I, I, P]),
     "adyolo_wino4_tiles": (I, [I] * 3),
     "adyolo_wino4_fwd": (I, [P] * 13 + [I] * 7 + [P]),
-    "adyolo_wino_pack_w_b3": (I, [P, P, P, I, I, I, P]),
-    "adyolo_wino_fwd_b3": (I, [P] * 13 + [I] * 7 + [P]),
+    "adyolo_wino4_last_form": (I, []),
     "adyolo_wino_wgrad_slabs": (I, [I] * 5),
     "adyolo_wino_wgrad": (I, [P] * 7 + [I] * 6 + [P]),
     "adyolo_conv3x3_wgrad_slabs": (I, [I] * 5),

@@ -344,8 +344,7 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float *__restrict_
 
 // Every 3x3 filter of a model in ONE launch (64 pack launches per train step of SE-ResNet34 otherwise: the packed filters
 // change once per optimizer step, not per layer call).  table: [n][8] int64 = {w, u_fwd, u_dgrad (or 0), Cout, Cin_real, Cin,
-// fwd_b3, dgrad_b3}; a non-zero *_b3 flag selects the pre-split bf16x3 form of wino_b3.hip for that direction.
-// grid (ceil(largest total / 256), n)
+// unused, unused}.  grid (ceil(largest total / 256), n)
 __global__ __launch_bounds__(256) void wino_pack_many_kernel(const long long *__restrict__ table) {
     const long long *d = table + 8 * blockIdx.y;
     const float *w = reinterpret_cast<const float *>(d[0]);
@@ -354,14 +353,8 @@ __global__ __launch_bounds__(256) void wino_pack_many_kernel(const long long *__
     const long total = (long)(Cout / 32) * (Cin / 8) * 256;       // = Cout * Cin: one element per thread in every form
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    if (uf) {
-        if (d[6]) wino_pack_b3_one(w, reinterpret_cast<unsigned short *>(uf), Cin_real, Cin, Cout, 0, idx);
-        else wino_pack_one(w, uf, Cin_real, Cin, Cout, 0, idx, total);
-    }
-    if (ud) {
-        if (d[7]) wino_pack_b3_one(w, reinterpret_cast<unsigned short *>(ud), Cin_real, Cout, Cin, 1, idx);
-        else wino_pack_one(w, ud, Cin_real, Cout, Cin, 1, idx, total);
-    }
+    if (uf) wino_pack_one(w, uf, Cin_real, Cin, Cout, 0, idx, total);
+    if (ud) wino_pack_one(w, ud, Cin_real, Cout, Cin, 1, idx, total);
 }
 
 }  // namespace adyolo
@@ -408,7 +401,11 @@ extern "C" int adyolo_wino_fwd(const float *x, const float *u, const float *bias
                    "wino_fwd: mask bits need H*W*Cout/4 %% 64 == 0");
     ADYOLO_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0 && Cin > 0 && Cout > 0 && Cin <= WMAXC, ADYOLO_ENOSUP,
                    "wino_fwd: Cin=%d (<= 512) and Cout=%d must be multiples of 32", Cin, Cout);
-    ADYOLO_REQUIRE((size_t)H * W * Cin * 4 < ((size_t)1 << 31), ADYOLO_ENOSUP, "wino_fwd: one sample must stay below 2 GiB");
+    // 31-bit byte offsets inside a sample's buffer descriptor (input AND output side: the epilogue's dropped-store offset
+    // 0x80000000 must stay out of range) and 24-bit pixel indices (__mul24 in the staging / epilogue address arithmetic)
+    ADYOLO_REQUIRE((size_t)H * W * Cin * 4 < ((size_t)1 << 31) && (size_t)H * W * Cout * 4 < ((size_t)1 << 31) &&
+                       (long)H * W < (1L << 23),
+                   ADYOLO_ENOSUP, "wino_fwd: one sample (input and output) must stay below 2 GiB and 2^23 pixels");
     ADYOLO_REQUIRE((in_scale == nullptr) == (in_shift == nullptr) && (!addend_mask || addend), ADYOLO_EINVAL,
                    "wino_fwd: in_scale/in_shift come together; addend_mask needs addend");
     ADYOLO_REQUIRE(!stat_aux || (stats && stat_mean && stat_invstd), ADYOLO_EINVAL,

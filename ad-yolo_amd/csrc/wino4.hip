@@ -385,7 +385,8 @@ __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
         smean = *reinterpret_cast<const float4 *>(stat_mean + co);
         sinv = *reinterpret_cast<const float4 *>(stat_invstd + co);
     }
-    const float rl = relu ? 0.f : -__builtin_inff();      // ReLU as a maximum with a wave-uniform floor
+    const bool rl = relu != 0;                            // ReLU branch-free: maximum + wave-uniform select (a maximum against a
+                                                          // -inf floor, round 4, turned NaN results into -inf)
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(y + (size_t)n * H * W * Cout, 0, H * W * Cout * 4, 0x00020000);
     const float hc0 = hh ? 0.f : 1.f, hc3 = hh ? 1.f : 0.f, hk1 = hh ? PB : PA, hk2 = hh ? B2 : A2, hk3 = hh ? B3 : A3;
     // addresses / validity of the thread's pixels: tiles m0, m0 + 16 (it), output row p of the tile, columns b = 0..3
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
                             }
                             v = f4_add(v, a_);
                         }
-                        v = make_float4(fmaxf(v.x, rl), fmaxf(v.y, rl), fmaxf(v.z, rl), fmaxf(v.w, rl));
+                        v = make_float4(rl ? fmaxf(v.x, 0.f) : v.x, rl ? fmaxf(v.y, 0.f) : v.y, rl ? fmaxf(v.z, 0.f) : v.z, rl ? fmaxf(v.w, 0.f) : v.w);
                         if (!(W4_WHATIF & 1024))
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yrs,
                                                                    ok[it][b] ? off[it][b] : (int)0x80000000, 0, 0);
@@ -651,6 +652,9 @@ __global__ __launch_bounds__(256) void wino4_pack_many_kernel(const long long *_
 using namespace adyolo;
 
 static inline int wino4_tc(int W) { return W >= 32 ? 8 : 4; }
+static int g_wino4_last_form = 0;          // 1: the last adyolo_wino4_fwd launched the one-patch kernel, 2: the persistent one
+
+extern "C" int adyolo_wino4_last_form(void) { return g_wino4_last_form; }
 
 extern "C" int adyolo_wino4_tiles(int N, int H, int W) {
     if (N <= 0 || H <= 0 || W <= 0) return ADYOLO_EINVAL;
@@ -693,7 +697,10 @@ extern "C" int adyolo_wino4_fwd(const float *x, const float *u, const float *bia
                    "wino4_fwd: mask bits need H*W*Cout/4 %% 64 == 0");
     ADYOLO_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0 && Cin > 0 && Cout > 0 && Cin <= WMAXC, ADYOLO_ENOSUP,
                    "wino4_fwd: Cin=%d (<= 512) must be a multiple of 32 and Cout=%d of 64", Cin, Cout);
-    ADYOLO_REQUIRE((size_t)(H + 2) * W * Cin * 4 < ((size_t)1 << 31), ADYOLO_ENOSUP, "wino4_fwd: one sample must stay below 2 GiB");
+    // (31-bit byte offsets inside a sample's buffer descriptors, input and output side; 24-bit pixel indices: __mul24)
+    ADYOLO_REQUIRE((size_t)(H + 2) * W * Cin * 4 < ((size_t)1 << 31) && (size_t)H * W * Cout * 4 < ((size_t)1 << 31) &&
+                       (long)H * W < (1L << 23),
+                   ADYOLO_ENOSUP, "wino4_fwd: one sample (input and output) must stay below 2 GiB and 2^23 pixels");
     ADYOLO_REQUIRE((in_scale == nullptr) == (in_shift == nullptr) && (!addend_mask || addend), ADYOLO_EINVAL,
                    "wino4_fwd: in_scale/in_shift come together; addend_mask needs addend");
     ADYOLO_REQUIRE(!stat_aux || (stats && stat_mean && stat_invstd), ADYOLO_EINVAL,
@@ -715,8 +722,7 @@ extern "C" int adyolo_wino4_fwd(const float *x, const float *u, const float *bia
     const char *pe = getenv("ADYOLO_W4_PERSIST");
     const int epi = (stats ? 1 : 0) | (addend ? 2 : 0) | (addend_mask ? 4 : 0) | (stat_aux ? 8 : 0) | (stat_mask ? 16 : 0);
     const bool bits_ok = (!addend_mask || (mask_bits & 1)) && (!stat_mask || (mask_bits & 2));
-    if (xcd_div > 0 && bits_ok && !bias && !(pe && pe[0] == '0') && (epi == 0 || epi == 1 || epi == 9 || epi == 27 || epi == 31) &&
-        (size_t)H * W * Cout * 4 < ((size_t)1 << 31) && (long)H * W < (1L << 23)) {
+    if (xcd_div > 0 && bits_ok && !bias && !(pe && pe[0] == '0') && (epi == 0 || epi == 1 || epi == 9 || epi == 27 || epi == 31)) {
         static int ncus = 0;
         if (ncus == 0) {
             int dev = 0, v = 0;
@@ -729,6 +735,7 @@ extern "C" int adyolo_wino4_fwd(const float *x, const float *u, const float *bia
         const int slots = njs < ncus / 8 ? njs : ncus / 8;
         w4::W4Launch a = {x, u, bias, addend, addend_mask, in_scale, in_shift, y, stats, stat_aux, stat_mean, stat_invstd, stat_mask,
                           H, W, Cin, Cout, patchesW, patchesH, nsp, ncb, xcd_div, relu, mask_bits, tc, slots * 8, st};
+        g_wino4_last_form = 2;
         switch (epi) {
             case 0: w4::launch_wino4p<0>(a); break;
             case 1: w4::launch_wino4p<1>(a); break;
@@ -738,6 +745,7 @@ extern "C" int adyolo_wino4_fwd(const float *x, const float *u, const float *bia
         }
         return check_launch("wino4_fwd (persistent)");
     }
+    g_wino4_last_form = 1;
 #define ADYOLO_WINO4_FWD(TC_, AFF_)                                                                                    \
     hipLaunchKernelGGL((w4::wino4_fwd_kernel<TC_, AFF_>), dim3((unsigned)blocks), dim3(256), 0, st, x, u, bias, addend,    \
                        addend_mask, in_scale, in_shift, y, stats, stat_aux, stat_mean, stat_invstd, stat_mask, H, W, Cin, \

@@ -21,6 +21,11 @@
 #include "wino4_common.hpp"
 #include "wino4p_launch.hpp"
 
+#ifndef W4P_WHATIF
+#define W4P_WHATIF 0      // timing-only builds (results invalid): bit 0 no reader half of the epilogue rounds, 1 no writer half, 2 no
+                          // output stores, 3 no xi pass (LDS reads), 4 no MFMAs, 5 no nu pass
+#endif
+
 namespace adyolo {
 namespace w4 {
 
@@ -306,7 +311,10 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                         set_off(offL, true, nty, ntx, Wn);
                         xbL = x + (size_t)nn * xsample;
                     }
-                    if (s < 8) {
+                    if (W4P_WHATIF & 16) {
+                        asm volatile("" : "+v"(a[s].x), "+v"(a[s].y), "+v"(a[s].z), "+v"(a[s].w));
+                        asm volatile("" : "+v"(bq[slot_].x), "+v"(bq[slot_].y), "+v"(bq[slot_].z), "+v"(bq[slot_].w));
+                    } else if (s < 8) {
                         asm volatile("" : "+v"(a[s].x));
                         acc[s][nt] = mfma32(a[s].x, bq[slot_].x, acc[s][nt]);
                         acc[s][nt] = mfma32(a[s].y, bq[slot_].y, acc[s][nt]);
@@ -458,20 +466,25 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
             __builtin_amdgcn_sched_barrier(0);
             // ---- writer: raw accumulators (rows rh * 8 .. + 7 of the 32 x 32 tile) of the wave's nine positions, straight from
             // the AccVGPRs; the registers are zeroed for the next patch while the stores drain
+            if (!(W4P_WHATIF & 2)) {
 #pragma unroll
-            for (int s = 0; s < 9; ++s)
+                for (int s = 0; s < 9; ++s)
 #pragma unroll
-                for (int rr = 0; rr < 8; ++rr) {
-                    xwr[(s * 8 + rr) * 64] = acc[s][nt][rh * 8 + rr];
-                    acc[s][nt][rh * 8 + rr] = 0.f;
-                }
+                    for (int rr = 0; rr < 8; ++rr) {
+                        xwr[(s * 8 + rr) * 64] = acc[s][nt][rh * 8 + rr];
+                        acc[s][nt][rh * 8 + rr] = 0.f;
+                    }
+            }
             __syncthreads();
             if (MK) amk = squeeze(amk_raw);
             if (SMK) smk = squeeze(smk_raw);
             // ---- reader, xi direction: Q[row][nu] for the thread's two rows (rows 0, 2 take the sums m1 + m2, m3 + m4, rows 1, 3
             // the differences: a wave-uniform branch), two nu columns of reads in flight
             float4 qa[6], qb[6];
-            {
+            if (W4P_WHATIF & (1 | 8)) {
+#pragma unroll
+                for (int nu = 0; nu < 6; ++nu) qa[nu] = qb[nu] = make_float4(1.f + nu, 2.f, 3.f, 4.f);
+            } else {
                 float4 mm[2][5];
                 auto rd5 = [&](float4 (&d)[5], int nu) {
 #pragma unroll
@@ -532,10 +545,14 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                 for (int e = 0; e < 2; ++e) {
                     const float4(&q)[6] = e ? qb : qa;
                     float4 Y[4];
-                    at4(q[0].x, q[1].x, q[2].x, q[3].x, q[4].x, q[5].x, Y[0].x, Y[1].x, Y[2].x, Y[3].x);
-                    at4(q[0].y, q[1].y, q[2].y, q[3].y, q[4].y, q[5].y, Y[0].y, Y[1].y, Y[2].y, Y[3].y);
-                    at4(q[0].z, q[1].z, q[2].z, q[3].z, q[4].z, q[5].z, Y[0].z, Y[1].z, Y[2].z, Y[3].z);
-                    at4(q[0].w, q[1].w, q[2].w, q[3].w, q[4].w, q[5].w, Y[0].w, Y[1].w, Y[2].w, Y[3].w);
+                    if (W4P_WHATIF & 32) {
+                        Y[0] = q[0]; Y[1] = q[1]; Y[2] = q[2]; Y[3] = q[3];
+                    } else {
+                        at4(q[0].x, q[1].x, q[2].x, q[3].x, q[4].x, q[5].x, Y[0].x, Y[1].x, Y[2].x, Y[3].x);
+                        at4(q[0].y, q[1].y, q[2].y, q[3].y, q[4].y, q[5].y, Y[0].y, Y[1].y, Y[2].y, Y[3].y);
+                        at4(q[0].z, q[1].z, q[2].z, q[3].z, q[4].z, q[5].z, Y[0].z, Y[1].z, Y[2].z, Y[3].z);
+                        at4(q[0].w, q[1].w, q[2].w, q[3].w, q[4].w, q[5].w, Y[0].w, Y[1].w, Y[2].w, Y[3].w);
+                    }
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
                         float4 v = Y[b];
@@ -550,7 +567,8 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                             v = f4_add(v, a_);
                         }
                         if (RL) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yrs, off[e][b], 0, 0);
+                        if (!(W4P_WHATIF & 4) || (e == 0 && b == 0))
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yrs, off[e][b], 0, 0);
                         if (ST) {
                             // out-of-image pixels and masked-out components count 0
                             const unsigned kin = ~(unsigned)(off[e][b] >> 31);
@@ -576,7 +594,9 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                     }
                 }
             };
-            if (relu) pixels(std::true_type{}); else pixels(std::false_type{});
+            if (!(W4P_WHATIF & 1)) {
+                if (relu) pixels(std::true_type{}); else pixels(std::false_type{});
+            }
             if (rnd == 3) {
                 // ... and its first B fragments (L2 hits: the last pair requested them once already)
 #pragma unroll

@@ -208,11 +208,21 @@ class AudioStager:
         else:
             import threading
             step = (nb + workers - 1) // workers
-            ths = [threading.Thread(target=fill, args=(lo, min(nb, lo + step))) for lo in range(0, nb, step)]
+            errors = []                           # an exception inside a worker (dtype / shape / copy error) must not die with
+                                                  # its thread: the H2D copy below would ship the PREVIOUS batch's audio
+
+            def guarded(lo, hi):
+                try:
+                    fill(lo, hi)
+                except BaseException as e:        # noqa: BLE001
+                    errors.append(e)
+            ths = [threading.Thread(target=guarded, args=(lo, min(nb, lo + step))) for lo in range(0, nb, step)]
             for t in ths:
                 t.start()
             for t in ths:
                 t.join()
+            if errors:
+                raise errors[0]
         with torch.cuda.stream(self.stream):
             if self.consumed[i] is not None:
                 self.stream.wait_event(self.consumed[i])              # dev[i] has been converted by the compute stream

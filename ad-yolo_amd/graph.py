@@ -15,8 +15,10 @@ varies from batch to batch) is padded to a fixed capacity with rows the assignme
 
 Results are bit-identical to the eager path (tests/test_gpu_graph.py compares losses and parameters with torch.equal).
 """
+import collections
 import contextlib
 import gc
+import os
 
 import torch
 
@@ -25,6 +27,20 @@ from . import ops
 from . import rng as _rng
 
 TARGET_QUANTUM = 4096          # AD-YOLO target rows are padded up to a multiple of this (bounds the number of graphs)
+MAX_GRAPHS = int(os.environ.get("ADYOLO_MAX_GRAPHS", "8"))     # recorded graphs kept per StepGraphs / ForwardGraphs (least recently
+#                                used one evicted): every graph owns a private memory pool with the activations of its shape, and a
+#                                data set with many distinct clip lengths / target capacities would otherwise grow without bound
+
+
+def _lru_insert(entries, key, ent, limit):
+    """entries: OrderedDict, most recently used last.  Evicts (outside any capture: the caller is not recording) until the new
+    entry fits; the evicted graphs and their pools are released by reference counting."""
+    evicted = 0
+    while len(entries) >= max(1, limit):
+        entries.popitem(last=False)
+        evicted += 1
+    entries[key] = ent
+    return evicted
 
 
 @contextlib.contextmanager
@@ -56,9 +72,10 @@ class StepGraphs:
     def __init__(self, trainer, warm_calls=1):
         self.trainer = trainer
         self.warm_calls = warm_calls
-        self.entries = {}
+        self.entries = collections.OrderedDict()      # most recently used last; at most MAX_GRAPHS
         self.seen = {}
         self.eager_only = set()        # input shapes whose step could not be recorded (host-computed values inside it)
+        self.evictions = 0
         self.streams = _rng.streams(trainer.model)
         self.captures = self.replays = self.eager_steps = 0
 
@@ -118,12 +135,22 @@ class StepGraphs:
                 loss = tr.step_eager(ent.audio, ent.target)
                 for s in self.streams:
                     ops.counter_add_(s.dev, s.offset - s.capture_base)
+        except BaseException:
+            # ``torch.cuda.graph.__exit__`` ends the capture also when its body raised; should the capture stream still be
+            # recording (its capture_end failed too), end it here -- the caller falls back to eager launches on this stream's
+            # device and a stream left capturing would refuse them
+            try:
+                if torch.cuda.is_current_stream_capturing():
+                    graph.capture_end()
+            except Exception:                                                    # noqa: BLE001
+                pass
+            raise
         finally:
             ent.deltas = [s.end_capture() for s in self.streams]
             tr.optimizer.step_count = step0
             tr.optimizer._dev_step_value = step0
         ent.graph, ent.loss = graph, loss
-        self.entries[key] = ent
+        self.evictions += _lru_insert(self.entries, key, ent, MAX_GRAPHS)
         self.captures += 1
         return ent
 
@@ -154,13 +181,16 @@ class StepGraphs:
                 return loss
             try:
                 ent = self._capture(key, audio, target)
-            except NotImplementedError as e:
-                # second line of defence (round 4, ADVICE: this used to raise out of the capture on every call)
-                self._mark_eager(key, str(e))
+            except Exception as e:                                               # noqa: BLE001
+                # second line of defence (round 4: NotImplementedError from a host draw inside the capture; round 5: ANY
+                # exception raised while recording, e.g. a RuntimeError from HIP): ``_capture`` has put the host-side state
+                # back, make sure the stream is not left capturing, remember the shape as eager-only and run the step eagerly
+                self._mark_eager(key, "%s: %s" % (type(e).__name__, e))
                 self.eager_steps += 1
                 return tr.step_eager(audio, target)
         else:
             self._load(ent, audio, target)
+            self.entries.move_to_end(key)
         tr.optimizer.sync_device_step()
         for s in self.streams:
             s.sync_device()
@@ -181,9 +211,9 @@ class ForwardGraphs:
     def __init__(self, model, features, postprocessor=None, warm_calls=1):
         self.model, self.features, self.post = model, features, postprocessor
         self.warm_calls = warm_calls
-        self.entries, self.seen = {}, {}
-        self.captures = self.replays = 0
-        self._tensors, self._calls = None, 0
+        self.entries, self.seen = collections.OrderedDict(), {}
+        self.captures = self.replays = self.evictions = 0
+        self._tensors, self._calls, self._tensors_epoch = None, 0, None
         self.epoch = self._stamp()
         self.primed = None
 
@@ -192,15 +222,18 @@ class ForwardGraphs:
         (``ops.PARAMS_EPOCH``), the version counters of every parameter and buffer (``p.copy_()``, a torch optimizer step or an
         EMA swap in evaluation mode bump these, not the epoch -- the eager caches honour them, a recorded graph would replay
         stale affines and packed filters; round 4, ADVICE) and the arithmetic switches read at pack time."""
-        # (the tensor list is cached: walking the module tree costs ~0.3 ms per call, a tenth of a one-clip forward; the identity of
-        #  the parameter / buffer objects only changes with .to() / load_state_dict(assign=True), which also bump the epoch or count)
+        # (the tensor list is cached: walking the module tree costs ~0.3 ms per call, a tenth of a one-clip forward.  It is rebuilt
+        #  whenever ops.PARAMS_EPOCH moved since it was made -- .to(), load_state_dict(assign=True) and every in-place kernel bump
+        #  the epoch, and after a replaced Parameter object later copy_() / optimizer writes land in the NEW objects, whose version
+        #  counters a stale list would never see (round 5, ADVICE) -- and every 256 calls regardless)
         ts = self._tensors
-        if ts is None or self._ntensors_check():
+        if ts is None or self._tensors_epoch != ops.PARAMS_EPOCH[0] or self._ntensors_check():
             ts = self._tensors = list(self.model.parameters()) + list(self.model.buffers())
+            self._tensors_epoch = ops.PARAMS_EPOCH[0]
         ver = 0
         for t in ts:
             ver += t._version
-        return (ops.PARAMS_EPOCH[0], ver, len(ts), ops.math_mode(), ops.conv_algo())
+        return (ops.PARAMS_EPOCH[0], ver, len(ts), ops.conv_algo())
 
     def _ntensors_check(self):
         """every 256 calls the cached tensor list is rebuilt (a module that replaced a parameter object without moving the model)"""
@@ -240,8 +273,10 @@ class ForwardGraphs:
                 with _quiet_collector(), torch.cuda.graph(graph):
                     outs = self._run(static)
                 ent = (graph, static, outs)
-                self.entries[key] = ent
+                self.evictions += _lru_insert(self.entries, key, ent, MAX_GRAPHS)
                 self.captures += 1
+            else:
+                self.entries.move_to_end(key)
             graph, static, outs = ent
             if audio.data_ptr() != static.data_ptr():
                 static.copy_(audio, non_blocking=True)

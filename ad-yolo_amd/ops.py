@@ -137,42 +137,44 @@ def conv_algo():
     return a
 
 
+# Dispatch thresholds of the F(4x4,3x3) kernel, read from the environment ONCE (at import, and again by ``reload_thresholds()``
+# -- tests and A/B tools that move them call it); ``conv3x3`` consults the cached values on every launch.
+W4_THRESHOLDS = {}
+
+
+def reload_thresholds():
+    """ADYOLO_W4_MIN_K (64): smallest contraction that gets the F(4x4) form packed; ADYOLO_W4_MIN_K_ADDEND (64; 128 until the
+    persistent kernel of round 5): the same for launches that add a tensor in their epilogue; ADYOLO_W4_MIN_WGS (200): below
+    that many 64-channel x patch work items a launch stays on the F(2x2) kernel (two workgroups per CU)."""
+    W4_THRESHOLDS.update(min_k=int(os.environ.get("ADYOLO_W4_MIN_K", "64")),
+                         min_k_addend=int(os.environ.get("ADYOLO_W4_MIN_K_ADDEND", "64")),
+                         min_wgs=int(os.environ.get("ADYOLO_W4_MIN_WGS", "200")))
+    return dict(W4_THRESHOLDS)
+
+
+reload_thresholds()
+
+# When set to a dict, ``conv3x3`` counts its launches in it: key = (kernel name, Cin, Cout, operand bits) -- the table bench.py prints as
+# ``dispatch`` and tests/test_gpu_parity_scale.py asserts at the bench shape.
+DISPATCH_LOG = None
+
+
 def _w4_eligible(k_gemm, n_gemm):
     """Does this GEMM direction (contraction over k_gemm channels, n_gemm output channels) get the F(4x4,3x3) form
-    (csrc/wino4.hip) packed beside the F(2x2) one?  The kernel needs 64 output channels per workgroup and 16-channel pairs of
-    the contraction.  One workgroup per CU: its prologue / epilogue is not overlapped, so it wins by more the longer the
-    contraction -- per launch at the bench shapes 1.26-1.46 x at 256 channels, 1.11-1.28 x at 128, 1.08-1.15 x at 64 except
-    with an addend in the epilogue (0.94-0.97 x: ``DualPack.pick`` keeps the F(2x2) kernel there); DESIGN.md, "F(4x4,3x3),
-    round 4".  ADYOLO_W4_MIN_K moves the threshold."""
-    return n_gemm % 64 == 0 and k_gemm % 32 == 0 and int(os.environ.get("ADYOLO_W4_MIN_K", "64")) <= k_gemm <= 512
+    (csrc/wino4.hip, wino4p.hpp) packed beside the F(2x2) one?  The kernel needs 64 output channels per workgroup and 16-channel
+    pairs of the contraction.  One workgroup per CU: it wins by more the longer the contraction -- per launch at the bench
+    shapes (round 5, persistent form) 1.4-1.6 x the F(2x2) kernel at 256 channels, 1.3-1.4 x at 128, 1.2-1.4 x at 64; DESIGN.md,
+    "F(4x4,3x3), round 5".  ADYOLO_W4_MIN_K moves the threshold (``reload_thresholds``)."""
+    return n_gemm % 64 == 0 and k_gemm % 32 == 0 and W4_THRESHOLDS["min_k"] <= k_gemm <= 512
 
 
-def math_mode():
-    """'f32' (default: every matrix product on the exact-fp32 MFMA) or 'bf16x3' (OPT-IN, ADYOLO_MATH=bf16x3): the Winograd
-    forward / data-gradient GEMMs with more than one 32-channel chunk run on the bf16 MFMA with every fp32 operand split
-    exactly into three bf16 terms and six products per multiply (csrc/wino_b3.hip; fp32 accumulation, error of the order
-    of the fp32 MFMA's own rounding).  Read per call of ``pack_w3x3`` / ``WinoPackSet.refresh``."""
-    m = os.environ.get("ADYOLO_MATH", "f32").lower()
-    if m not in ("f32", "bf16x3"):
-        raise _lib.AdyoloHipError("ADYOLO_MATH must be 'f32' or 'bf16x3' (got %r)" % m)
-    return m
-
-
-def _b3_eligible(k_gemm, math):
-    """the bf16x3 kernel takes the multi-chunk contractions; one-chunk (32-channel) ones stay on the fp32 kernel, whose
-    single-buffer form keeps three workgroups per CU (ADYOLO_B3_MIN_K=32 sends them over as well: 3-40 % faster launch by
-    launch in isolation, but the whole step goes 143.3 -> 145.9 ms; DESIGN "bf16x3, round 3")"""
-    return math == "bf16x3" and k_gemm >= int(os.environ.get("ADYOLO_B3_MIN_K", "64"))
-
-
-def pack_w3x3(w, cin_pad, want_dgrad=True, algo=None, math=None):
+def pack_w3x3(w, cin_pad, want_dgrad=True, algo=None):
     """w [Cout][Cin][3][3] -> (fwd pack, dgrad pack or None).
 
     direct:   wpk_fwd [Cout][9][cin_pad], wpk_dgrad [cin_pad][9][Cout]
     winograd: u_fwd [16][Cout/32][cin_pad/8][256], u_dgrad [16][cin_pad/32][Cout/8][256]  (needs both channel
               counts to be multiples of 32; the 8-channel stem stays direct).  ``conv3x3`` tells them apart by rank.
-    winograd, math 'bf16x3': a direction whose contraction has more than 32 channels is packed pre-split,
-              [16][Cout/32][cin_pad/16][768] (resp. [16][cin_pad/32][Cout/16][768]); ``conv3x3`` tells by the last axis."""
+    winograd4: per direction the F(4x4,3x3) form [36][N/32][K/8][256] where ``_w4_eligible`` says so, else the F(2x2) form."""
     _chk(w)
     cout, cin = w.shape[0], w.shape[1]
     algo = algo or conv_algo()
@@ -188,16 +190,9 @@ def pack_w3x3(w, cin_pad, want_dgrad=True, algo=None, math=None):
                cin_pad, _stream())
         return uf, ud
     if algo == "winograd" and cin_pad % 32 == 0 and cout % 32 == 0:
-        math = math or math_mode()
-        fb, db = _b3_eligible(cin_pad, math), _b3_eligible(cout, math) and want_dgrad
-        uf = _new(w, 16, cout // 32, cin_pad // 16, 768) if fb else _new(w, 16, cout // 32, cin_pad // 8, 256)
-        ud = None
-        if want_dgrad:
-            ud = _new(w, 16, cin_pad // 32, cout // 16, 768) if db else _new(w, 16, cin_pad // 32, cout // 8, 256)
-        if fb or db:
-            _c("adyolo_wino_pack_w_b3", _p(w), _p(uf if fb else None), _p(ud if db else None), cout, cin, cin_pad, _stream())
-        if not fb or (want_dgrad and not db):
-            _c("adyolo_wino_pack_w", _p(w), _p(None if fb else uf), _p(None if db else ud), cout, cin, cin_pad, _stream())
+        uf = _new(w, 16, cout // 32, cin_pad // 8, 256)
+        ud = _new(w, 16, cin_pad // 32, cout // 8, 256) if want_dgrad else None
+        _c("adyolo_wino_pack_w", _p(w), _p(uf), _p(ud), cout, cin, cin_pad, _stream())
         return uf, ud
     wf = _new(w, cout, 9, cin_pad)
     wd = _new(w, cin_pad, 9, cout) if want_dgrad else None
@@ -215,12 +210,12 @@ class DualPack:
         self.f4, self.f2 = f4, f2
 
     def pick(self, n, h, w, cout, addend=False):
-        """addend: the launch adds a tensor in its epilogue (the data-gradient of a block's first convolution) -- with a
-        contraction of fewer than 128 channels the F(2x2) kernel is the faster one then (ADYOLO_W4_MIN_K_ADDEND)"""
+        """addend: the launch adds a tensor in its epilogue (the data-gradient of a block's first convolution); until round 5 the
+        F(2x2) kernel was the faster one there below 128 channels (ADYOLO_W4_MIN_K_ADDEND, now 64)"""
         wgs = _lib.load().adyolo_wino4_tiles(n, h, w) * (cout // 64)
-        if wgs < int(os.environ.get("ADYOLO_W4_MIN_WGS", "200")):
+        if wgs < W4_THRESHOLDS["min_wgs"]:
             return self.f2
-        if addend and self.f4.shape[2] * 8 < int(os.environ.get("ADYOLO_W4_MIN_K_ADDEND", "128")):
+        if addend and self.f4.shape[2] * 8 < W4_THRESHOLDS["min_k_addend"]:
             return self.f2
         return self.f4
 
@@ -237,9 +232,8 @@ class WinoPackSet:
     def refresh(self, weights, frozen=False):
         """frozen (evaluation mode): skip the launch when nothing was written to the filters since the last one
         (``PARAMS_EPOCH`` for in-place kernels, the tensors' version counters for ``copy_`` / ``load_state_dict``)."""
-        math = math_mode()
         w4 = conv_algo() == "winograd4"
-        key = (math, w4, os.environ.get("ADYOLO_W4_MIN_K")) + tuple(w.data_ptr() for w in weights)
+        key = (w4, W4_THRESHOLDS["min_k"]) + tuple(w.data_ptr() for w in weights)
         stamp = (PARAMS_EPOCH[0],) + tuple(w._version for w in weights)
         if frozen and key == self.key and stamp == self.stamp:
             return self
@@ -252,13 +246,12 @@ class WinoPackSet:
                 cout, cin = w.shape[0], w.shape[1]
                 if cout % 32 or cin % 32:
                     raise _lib.AdyoloHipError("WinoPackSet: channel counts must be multiples of 32")
-                # per direction: the F(2x2) form (fp32 or bf16x3) always, the F(4x4) form [36][N/32][K/8][256] beside it where
-                # it applies (winograd4): ``conv3x3`` picks by the size of the launch (``DualPack``)
+                # per direction: the F(2x2) form always, the F(4x4) form [36][N/32][K/8][256] beside it where it applies
+                # (winograd4): ``conv3x3`` picks by the size of the launch (``DualPack``)
                 f4, d4 = w4 and _w4_eligible(cin, cout), w4 and _w4_eligible(cout, cin)
-                fb, db = _b3_eligible(cin, math), _b3_eligible(cout, math)
-                uf = _new(w, 16, cout // 32, cin // 16, 768) if fb else _new(w, 16, cout // 32, cin // 8, 256)
-                ud = _new(w, 16, cin // 32, cout // 16, 768) if db else _new(w, 16, cin // 32, cout // 8, 256)
-                rows.append([w.data_ptr(), uf.data_ptr(), ud.data_ptr(), cout, cin, cin, int(fb), int(db)])
+                uf = _new(w, 16, cout // 32, cin // 8, 256)
+                ud = _new(w, 16, cin // 32, cout // 8, 256)
+                rows.append([w.data_ptr(), uf.data_ptr(), ud.data_ptr(), cout, cin, cin, 0, 0])
                 if f4 or d4:
                     uf4 = _new(w, 36, cout // 32, cin // 8, 256) if f4 else None
                     ud4 = _new(w, 36, cin // 32, cout // 8, 256) if d4 else None
@@ -314,11 +307,31 @@ def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, 
     if wino4:
         fn = "adyolo_wino4_fwd"
     else:
-        fn = ("adyolo_wino_fwd_b3" if wpk.shape[-1] == 768 else "adyolo_wino_fwd") if wino else "adyolo_conv3x3_fwd"
+        fn = "adyolo_wino_fwd" if wino else "adyolo_conv3x3_fwd"
     _c(fn, _p(x), _p(wpk), _p(bias), _p(addend), _p(addend_mask),
        _p(sc), _p(sh), _p(y), _p(stats), _p(sa), _p(sm), _p(si), _p(stat_mask), n, h, w, cin, cout, int(relu), mbits,
        _stream())
+    if DISPATCH_LOG is not None:
+        if wino4:
+            name = "wino4p_fwd_kernel" if _lib.load().adyolo_wino4_last_form() == 2 else "wino4_fwd_kernel"
+        else:
+            name = "wino_fwd_kernel" if wino else "conv3x3_fwd_kernel"
+        # operand combination, as the persistent kernel's EPI bits: 1 statistics, 2 addend, 4 addend mask, 8 stat_bn, 16 stat mask
+        epi = (1 if want_stats else 0) | (2 if addend is not None else 0) | (4 if addend_mask is not None else 0) | \
+              (8 if stat_bn is not None else 0) | (16 if stat_mask is not None else 0)
+        k = (name, cin, cout, epi)
+        DISPATCH_LOG[k] = DISPATCH_LOG.get(k, 0) + 1
     return (y, stats) if want_stats else y
+
+
+def wgrad_form(cin, cout, algo=None):
+    """-> (kernel name, matrix FLOPs issued / direct-convolution FLOPs) of the weight-gradient ``conv3x3_wgrad`` launches for these
+    channel counts: the Winograd F(2x2,3x3) form (16 multiplies per 36) when both are multiples of 32, else the direct implicit
+    GEMM.  The ONE place that decides it -- bench.py reports the share from here."""
+    algo = algo or os.environ.get("ADYOLO_WGRAD_ALGO") or conv_algo()
+    if algo in ("winograd", "winograd4") and cin % 32 == 0 and cout % 32 == 0:      # (the weight gradient has the F(2x2) form only)
+        return "wino_wgrad_kernel", 16.0 / 36.0
+    return "conv3x3_wgrad_kernel", 1.0
 
 
 def conv3x3_wgrad(x, dy, cin_real, in_affine=None, algo=None, out=None):
@@ -330,8 +343,7 @@ def conv3x3_wgrad(x, dy, cin_real, in_affine=None, algo=None, out=None):
     cout = dy.shape[3]
     sc, sh = in_affine if in_affine is not None else (None, None)
     dw = out if out is not None else _new(x, cout, cin_real, 3, 3)      # out: e.g. the parameter's slice of the flat gradient buffer
-    algo = algo or os.environ.get("ADYOLO_WGRAD_ALGO") or conv_algo()
-    if algo in ("winograd", "winograd4") and cin % 32 == 0 and cout % 32 == 0:      # (the weight gradient has the F(2x2) form only)
+    if wgrad_form(cin, cout, algo)[0] == "wino_wgrad_kernel":
         nslab = _lib.load().adyolo_wino_wgrad_slabs(n, h, w, cin, cout)
         if nslab <= 0:
             raise _lib.AdyoloHipError("wino_wgrad_slabs rejected the shape")

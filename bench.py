@@ -132,7 +132,8 @@ class KernelTimer:
         return sorted({r[2][2] for r in self.records.get(family, []) if len(r[2]) > 2})
 
 
-_KERNEL_OF = {36: "wino4_fwd_kernel (Winograd F(4x4,3x3))", 16: "wino_fwd_kernel (Winograd F(2x2,3x3))"}
+_KERNEL_OF = {36: "wino4_fwd_kernel", 16: "wino_fwd_kernel"}       # (F(4x4,3x3) one-patch form / F(2x2,3x3)); the persistent
+#                                                                       F(4x4) form, wino4p_fwd_kernel, is recognised after the launch
 
 
 def _issued_share(wpk):
@@ -143,9 +144,9 @@ def _issued_share(wpk):
     return 9.0 / 36.0 if wpk.shape[0] == 36 else 16.0 / 36.0
 
 
-def _picked(ops_mod, x, wpk, cout):
+def _picked(ops_mod, x, wpk, cout, addend=False):
     """the packed form ``ops.conv3x3`` will launch with (``ops.DualPack``: F(4x4) or F(2x2) by the size of the launch)"""
-    return wpk.pick(x.shape[0], x.shape[1], x.shape[2], cout) if isinstance(wpk, ops_mod.DualPack) else wpk
+    return wpk.pick(x.shape[0], x.shape[1], x.shape[2], cout, addend) if isinstance(wpk, ops_mod.DualPack) else wpk
 
 
 def load_traffic(algo):
@@ -153,7 +154,7 @@ def load_traffic(algo):
     --pmc FETCH_SIZE and --pmc WRITE_SIZE over this same command, corrected as MI355X_MICROARCH.md prescribes).  Counters
     cannot be collected inside the timed run: the figure is READ from the committed file, whose name is returned beside it
     (``roofline.traffic_source``); (None, None) when no PMC summary matches the algorithm."""
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)
@@ -267,10 +268,6 @@ EXTRA_CONFIGS = {
                                            "reference (parity unpinned)"),
     "conformer_bs32x20s": dict(kind="train", encoder="resnet-conformer", batch=32, seconds=20, steps=4,
                                ref="BASELINE.json configs[3]: resnet-conformer + adyolo, bs = 32 x 20 s"),
-    "headline_b64x60s_math_bf16x3": dict(kind="train", encoder="se-resnet34", batch=64, seconds=60, steps=4, math="bf16x3",
-                                         ref="the headline workload with the OPT-IN math mode ADYOLO_MATH=bf16x3: multi-chunk Winograd "
-                                             "forward / data-gradient GEMMs on the bf16 MFMA with fp32 operands split exactly into three "
-                                             "bf16 terms (six products, fp32 accumulation; csrc/wino_b3.hip); NOT the headline's arithmetic"),
 }
 
 
@@ -288,20 +285,7 @@ def _small_shape_kernel_ms(name):
 
 
 def run_extra_config(name, torch, modes="both"):
-    cfg = EXTRA_CONFIGS[name]
-    if cfg.get("math"):                     # opt-in math mode for this configuration only
-        prev = os.environ.get("ADYOLO_MATH")
-        os.environ["ADYOLO_MATH"] = cfg["math"]
-        try:
-            ent = _run_extra_config(name, cfg, torch, modes)
-        finally:
-            if prev is None:
-                os.environ.pop("ADYOLO_MATH", None)
-            else:
-                os.environ["ADYOLO_MATH"] = prev
-        ent["math"] = cfg["math"]
-        return ent
-    return _run_extra_config(name, cfg, torch, modes)
+    return _run_extra_config(name, EXTRA_CONFIGS[name], torch, modes)
 
 
 def _run_extra_config(name, cfg, torch, modes):
@@ -378,7 +362,7 @@ def _run_extra_config(name, cfg, torch, modes):
             kt.wrap(_ops, "attn_bwd", "attention backward (7 products)",
                     lambda q, *a, **kw: fl(14.0 * q.shape[0] * q.shape[1] ** 2 * q.shape[2]))
             kt.wrap(_ops, "conv3x3", "Winograd 3x3 forward / dgrad [issued FLOPs]",
-                    lambda x, wpk, cout, **kw: fl(2.0 * x.shape[0] * x.shape[1] * x.shape[2] * cout * 9 * x.shape[3] * (_issued_share(_picked(_ops, x, wpk, cout)))))
+                    lambda x, wpk, cout, **kw: fl(2.0 * x.shape[0] * x.shape[1] * x.shape[2] * cout * 9 * x.shape[3] * (_issued_share(_picked(_ops, x, wpk, cout, kw.get("addend") is not None)))))
             kt.wrap(_ops, "conv3x3_wgrad", "Winograd 3x3 weight-gradient [issued FLOPs]",
                     lambda x, dy, cin_real, **kw: fl(2.0 * x.shape[0] * x.shape[1] * x.shape[2] * dy.shape[3] * 9 * x.shape[3] * 16.0 / 36.0))
             torch.manual_seed(100)
@@ -505,15 +489,15 @@ def main():
     conv_algo = ops.conv_algo()
     wino = conv_algo in ("winograd", "winograd4")
 
-    # parity gate at the benchmark's clip shape on a SLICE of the batch (8 clips: the smallest launch at which every layer still
-    # takes the kernel the full batch takes -- ops.DualPack picks by launch size; round 3 ran it on all 64 clips, 40 GB of
-    # allocator churn before the timed region): the first forward loss with the benchmarked (Winograd) convolutions must equal
+    # parity gate at the benchmark's clip shape on a SLICE of the batch (12 clips: every layer still takes the kernel the full
+    # batch takes -- ops.DualPack picks by launch size, the 128 -> 64 data-gradient needs 11 clips; round 3 ran it on all 64
+    # clips, 40 GB of allocator churn before the timed region): the first forward loss with the benchmarked (Winograd) convolutions must equal
     # the direct implicit-GEMM path within 1e-3 (both are checked against torch / the oracle in tests/)
     parity = None
     if args.encoder == "se-resnet34" and wino and world == 1 and not args.no_parity:      # (N > 1: a rank-0-only assert would strand the other ranks)
         model.train()
         vals, outs = {}, {}
-        nb = min(B, 8)
+        nb = min(B, 12)
         tgt_slice = synthetic_targets(nb, T // 4, 12, seed=1234 + rank).to(device)
         with torch.no_grad():
             feat = fx(audio[:nb], channels_last8=True)
@@ -539,14 +523,20 @@ def main():
     timer = KernelTimer(torch)
     # work = (algorithmic FLOPs of the 3x3 convolution, matrix FLOPs actually issued: 16/36 of that in Winograd form)
 
+    from adyolo_amd import _lib as _alib
+
     def conv_work(x, wpk, cout, **kw):
+        # (called right after the launch: which F(4x4) form it took is asked from the library)
         alg = 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * cout * 9 * x.shape[3]
-        pk = _picked(ops, x, wpk, cout)
-        return alg, alg * _issued_share(pk), _KERNEL_OF.get(pk.shape[0] if hasattr(pk, "dim") and pk.dim() == 4 else 0, "conv3x3_fwd_kernel (direct)")
+        pk = wpk.pick(x.shape[0], x.shape[1], x.shape[2], cout, kw.get("addend") is not None) if isinstance(wpk, ops.DualPack) else wpk
+        tag = _KERNEL_OF.get(pk.shape[0] if hasattr(pk, "dim") and pk.dim() == 4 else 0, "conv3x3_fwd_kernel")
+        if tag == "wino4_fwd_kernel" and _alib.load().adyolo_wino4_last_form() == 2:
+            tag = "wino4p_fwd_kernel"
+        return alg, alg * _issued_share(pk), tag
 
     def wgrad_work(x, dy, cin_real, **kw):
         alg = 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * dy.shape[3] * 9 * x.shape[3]
-        return alg, alg * (16.0 / 36.0 if (wino and x.shape[3] % 32 == 0 and dy.shape[3] % 32 == 0) else 1.0)
+        return alg, alg * ops.wgrad_form(x.shape[3], dy.shape[3], kw.get("algo"))[1]
     timer.wrap(ops, "conv3x3", "conv3x3_fwd_dgrad", conv_work)
     timer.wrap(ops, "conv3x3_wgrad", "conv3x3_wgrad", wgrad_work)
     feat_call = trainer.features.__call__
@@ -635,10 +625,7 @@ def main():
         ones = torch.ones(1, device=device)
         dist.all_reduce(ones)
         hooks_n, finish_n = red.fired_from_hooks - fired0[0], red.fired_from_finish - fired0[1]
-        red.active = False
-        off_ms = timed_steps(lambda i: trainer.step(audio, target), args.steps, 1)
-        red.active = True
-        trainer.flat.broadcast(0)                   # the ranks drifted apart while nothing was averaged
+        off_ms = None                               # (measured at the very end: see "reducer off" below)
         try:
             lib_ver = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:                                                              # noqa: BLE001
@@ -648,7 +635,7 @@ def main():
                 "buckets": len(red.buckets), "bucket_MB": [round((e_ - s_) * 4 / 1e6, 2) for s_, e_, _ in red.buckets],
                 "buckets_fired_from_hooks_per_step": round(hooks_n / args.steps, 2),
                 "buckets_fired_from_finish_per_step": round(finish_n / args.steps, 2),
-                "ms_per_step_reducer_off": round(off_ms, 3), "exposed_allreduce_ms": round(step_ms - off_ms, 3)}
+                "ms_per_step_reducer_off": None, "exposed_allreduce_ms": None}
 
     # ---- the same step fed the way a data loader feeds it (second weak-scaling mode): int16 clips in host memory ->
     # AudioStager's page-locked buffer (a worker thread, as DataLoader workers would) -> PCIe copy on a side stream, overlapped
@@ -687,8 +674,67 @@ def main():
         pool.shutdown()
         del stager, host
 
+    # ---- which kernel every 3x3 convolution of one step launches: counted in one extra step
+    # (every rank runs these extra steps -- with N > 1 the reducer's all-reduces need all of them; rank 0 keeps the books)
+    dispatch = None
+    if not args.graph:
+        ops.DISPATCH_LOG = {}
+        trainer.step(audio, target)
+        torch.cuda.synchronize()
+        log, ops.DISPATCH_LOG = ops.DISPATCH_LOG, None
+        by_name = {}
+        for (name, cin, cout, epi), cnt in sorted(log.items()):
+            by_name.setdefault(name, {"launches_per_step": 0, "by_shape": {}})
+            by_name[name]["launches_per_step"] += cnt
+            key = "%d->%d ops%d" % (cin, cout, epi)
+            by_name[name]["by_shape"][key] = by_name[name]["by_shape"].get(key, 0) + cnt
+        dispatch = {"fwd_dgrad": by_name, "thresholds": dict(ops.W4_THRESHOLDS),
+                    "env": {k: os.environ.get(k) for k in ("ADYOLO_LIB", "ADYOLO_CONV_ALGO", "ADYOLO_W4_PERSIST", "ADYOLO_W4_MIN_K",
+                                                           "ADYOLO_W4_MIN_K_ADDEND", "ADYOLO_W4_MIN_WGS",
+                                                           "ADYOLO_WGRAD_ALGO", "ADYOLO_GEMM_TILE")},
+                    "library": os.path.relpath(_alib.LIB_PATH, ROOT)}
+
+    # ---- the encoder + head FORWARD alone, training mode (north_star: ">= 40 % MFMA utilisation on the SE-ResNet forward";
+    # 2.269 GFLOP per audio-second algorithmic): HIP events around model(feat) on precomputed features
+    encoder_fwd = None
+    if not args.graph and args.encoder == "se-resnet34":
+        model.train()
+        feat = fx(audio, channels_last8=True)
+        n_f0 = len(timer.records.get("conv3x3_fwd_dgrad", []))
+        fwd_ms = []
+        for i in range(5):
+            timer.active = i >= 2
+            s_e, e_e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_e.record()
+            out = model(feat, channels_last8=True)
+            e_e.record()
+            torch.cuda.synchronize()
+            if i >= 2:
+                fwd_ms.append(s_e.elapsed_time(e_e))
+            del out
+        timer.active = False
+        recs = timer.records.get("conv3x3_fwd_dgrad", [])[n_f0:]
+        del timer.records["conv3x3_fwd_dgrad"][n_f0:]                 # (they must not enter the step's roofline below)
+        conv_alg = sum(w[0] for _, _, w in recs) / 3.0
+        conv_issued = sum(w[1] for _, _, w in recs) / 3.0
+        conv_ms = sum(a_.elapsed_time(b_) for a_, b_, _ in recs) / 3.0
+        alg = 2.269e9 * B * args.seconds
+        ms = sorted(fwd_ms)[1]
+        issued_f = conv_issued + max(0.0, alg - conv_alg)             # GEMMs / GRU / stem issue what they compute
+        encoder_fwd = {"ms": round(ms, 3), "algorithmic_TFLOP": round(alg / 1e12, 3),
+                       "algorithmic_tflops": round(alg / (ms * 1e-3) / 1e12, 2),
+                       "issued_tflops": round(issued_f / (ms * 1e-3) / 1e12, 2),
+                       "frac_of_mfma_peak_issued": round(issued_f / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                       "frac_of_mfma_peak_algorithmic": round(alg / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                       "conv3x3_ms": round(conv_ms, 3), "conv3x3_issued_frac": round(conv_issued / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+                       if conv_ms > 0 else 0.0,
+                       "note": "median of 3 training-mode forward passes (encoder + head, batch statistics, activations kept for "
+                               "backward) on precomputed features; issued = Winograd-reduced matrix FLOPs actually executed"}
+        del feat
+        torch.cuda.empty_cache()
+
     stages = {}
-    if rank == 0 and not args.no_stages and not args.graph:
+    if not args.no_stages and not args.graph:
         n_inst = 2
         stage["on"] = True
         t1 = time.perf_counter()
@@ -718,6 +764,16 @@ def main():
         stages["_elementwise_total"] = {"ms_per_step": round(ew_ms, 3), "share_of_step": round(ew_ms / step_ms, 4),
                                         "instrumented_step_ms": round(inst_ms, 3)}
 
+    if world > 1:
+        # "reducer off": the same step without the gradient all-reduce (its difference to ms_per_step = exposed all-reduce).  LAST
+        # measurement of the run: the replicas (parameters AND Adam moments) drift apart while nothing is averaged, and nothing
+        # that assumes identical replicas follows (round 4 ran it before the pipeline / stage passes; ADVICE)
+        trainer.reducer.active = False
+        off_ms = timed_steps(lambda i: trainer.step(audio, target), args.steps, 1)
+        trainer.reducer.active = True
+        rccl["ms_per_step_reducer_off"] = round(off_ms, 3)
+        rccl["exposed_allreduce_ms"] = round(step_ms - off_ms, 3)
+
     if rank == 0:
         n_f, ms_f, fl_f, ex_f = timer.summary("conv3x3_fwd_dgrad")
         n_w, ms_w, fl_w, ex_w = timer.summary("conv3x3_wgrad")
@@ -733,6 +789,7 @@ def main():
             by_kernel[tag] = {"launches": n_t, "avg_launch_ms": round(ms_t / max(1, n_t), 4), "share_of_step": round(ms_t / (dt * 1e3), 4),
                               "issued_tflops": round(ex_t / (ms_t * 1e-3) / 1e12, 2), "frac": round(ex_t / (ms_t * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                               "algorithmic_tflops": round(fl_t / (ms_t * 1e-3) / 1e12, 2)}
+        dom = max(by_kernel, key=lambda k_: by_kernel[k_]["share_of_step"]) if by_kernel else None
         line = {
             "metric": "train-step audio-sec/s (4ch, %s+adyolo)" % args.encoder,
             "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -742,18 +799,20 @@ def main():
                                    "12 classes, features+fwd+loss+bwd+allreduce+Adam" % (args.seconds, B),
                        "global_batch": world * B, "clip_seconds": args.seconds,
                        "parallelism": "dp%d" % world + (" (functional run: all ranks on one device over gloo)" if one_device else "")},
-            # achieved = matrix FLOPs ISSUED per second by the dominant kernel family (what the MFMA pipe executes);
-            # algorithmic_tflops = the direct-convolution FLOPs the same launches stand for, 36/16 of it in
-            # Winograd form
-            "roofline": {"bound": "mfma",
-                         "kernel": "3x3 convolution forward + data-gradient launches: " + " + ".join(timer.tags("conv3x3_fwd_dgrad")),
-                         "achieved": round(issued, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(issued / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "by_kernel": by_kernel,
-                         "algorithmic_tflops": round(algorithmic, 2),
-                         "launches": n_f, "avg_launch_ms": round(ms_f / max(1, n_f), 4),
-                         "share_of_step": round(ms_f / (dt * 1e3), 4)},
+            # the ONE dominant kernel of the step (largest share of step among the 3x3 forward / data-gradient kernels):
+            # achieved = matrix FLOPs it ISSUES per second (what the MFMA pipe executes: Winograd F(4x4) issues 9/36 of the
+            # direct-convolution FLOPs its launches stand for, algorithmic_tflops); the whole family is stages.conv3x3_fwd_dgrad
+            "roofline": {"bound": "mfma", "kernel": dom,
+                         "achieved": by_kernel[dom]["issued_tflops"] if dom else 0.0, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": by_kernel[dom]["frac"] if dom else 0.0, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_tflops": by_kernel[dom]["algorithmic_tflops"] if dom else 0.0,
+                         "launches": by_kernel[dom]["launches"] if dom else 0,
+                         "avg_launch_ms": by_kernel[dom]["avg_launch_ms"] if dom else 0.0,
+                         "share_of_step": by_kernel[dom]["share_of_step"] if dom else 0.0},
             "stages": {
+                "conv3x3_fwd_dgrad": {"kernels": by_kernel, "launches": n_f, "avg_launch_ms": round(ms_f / max(1, n_f), 4),
+                                      "mfma_issued_tflops": round(issued, 2), "frac_of_mfma_peak": round(issued / PEAK_FP32_MFMA_TFLOPS, 4),
+                                      "algorithmic_tflops": round(algorithmic, 2), "share_of_step": round(ms_f / (dt * 1e3), 4)},
                 "conv3x3_wgrad": {"launches": n_w, "avg_launch_ms": round(ms_w / max(1, n_w), 4),
                                   "mfma_issued_tflops": round(ex_w / (ms_w * 1e-3) / 1e12, 2) if ms_w > 0 else 0.0,
                                   "frac_of_mfma_peak": round(ex_w / (ms_w * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if ms_w > 0 else 0.0,
@@ -767,6 +826,10 @@ def main():
             "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
         }
         line["stages"].update(stages)
+        if encoder_fwd is not None:
+            line["stages"]["encoder_fwd"] = encoder_fwd
+        if dispatch is not None:
+            line["dispatch"] = dispatch
         if parity is not None:
             line["parity_check"] = parity
         if rccl is not None:

@@ -115,8 +115,7 @@ int adyolo_wino_pack_w(const float *w /*[Cout][Cin_real][3][3]*/, float *u_fwd /
                        int Cout, int Cin_real, int Cin, void *stream);
 /* the same for EVERY 3x3 filter of a model in one launch (the packed filters change once per optimizer step, not per layer
  * call: 64 pack launches per SE-ResNet34 train step become one).  table (device) = n rows of 8 int64:
- * {w, u_fwd, u_dgrad or 0, Cout, Cin_real, Cin, fwd_b3, dgrad_b3}; a non-zero *_b3 flag packs that direction in the pre-split
- * form of adyolo_wino_pack_w_b3 (K2w-b3 below); max_cout / max_cin = the largest channel counts in the table. */
+ * {w, u_fwd, u_dgrad or 0, Cout, Cin_real, Cin, unused, unused}; max_cout / max_cin = the largest channel counts in the table. */
 int adyolo_wino_pack_many(const int64_t *table, int n, int max_cout, int max_cin, void *stream);
 int adyolo_wino_tiles(int N, int H, int W);
 int adyolo_wino_fwd(const float *x, const float *u, const float *bias, const float *addend,
@@ -140,17 +139,12 @@ int adyolo_wino4_fwd(const float *x, const float *u, const float *bias, const fl
                      const float *in_scale, const float *in_shift, float *y, float *stats, const float *stat_aux,
                      const float *stat_mean, const float *stat_invstd, const float *stat_mask, int N, int H, int W, int Cin,
                      int Cout, int relu, int mask_bits, void *stream);
-/* K2w-b3 (OPT-IN, ADYOLO_MATH=bf16x3; csrc/wino_b3.hip): adyolo_wino_fwd with its GEMMs on the bf16 MFMA and every fp32 operand
- *      split exactly into three bf16 terms (six products per multiply, fp32 accumulation; error of the order of the fp32
- *      MFMA's own rounding).  Same operator, arguments and statistics rows as adyolo_wino_fwd; `u` comes from
- *      adyolo_wino_pack_w_b3: [16][Cout/32][Cin/16][3 terms][64 lanes][8 bf16] = 16 * (Cout/32) * (Cin/16) * 768 floats of
- *      storage per direction (1.5 x the fp32 pack). */
-int adyolo_wino_pack_w_b3(const float *w /*[Cout][Cin_real][3][3]*/, float *u_fwd /*or NULL*/, float *u_dgrad /*or NULL*/,
-                          int Cout, int Cin_real, int Cin, void *stream);
-int adyolo_wino_fwd_b3(const float *x, const float *u, const float *bias, const float *addend, const float *addend_mask,
-                       const float *in_scale, const float *in_shift, float *y, float *stats, const float *stat_aux,
-                       const float *stat_mean, const float *stat_invstd, const float *stat_mask, int N, int H, int W,
-                       int Cin, int Cout, int relu, int mask_bits, void *stream);
+/*      Round 5: adyolo_wino4_fwd launches the PERSISTENT form of the kernel (csrc/wino4p.hpp: one workgroup per CU walks the patches,
+ *      the staging pipeline runs across patch boundaries, raw accumulators are exchanged and transformed on the reader side) for
+ *      the operand combinations of the SE-ResNet block (no bias, masks as bits, Cout / 64 in {1, 2, 4, 8}) and the
+ *      one-patch-per-workgroup kernel otherwise or with ADYOLO_W4_PERSIST=0; same results within fp32 rounding.
+ *      adyolo_wino4_last_form(): which one the last call launched (1 one-patch, 2 persistent, 0 none yet) -- for reporting. */
+int adyolo_wino4_last_form(void);
 /* Winograd weight-gradient: dw = G^T [ sum_tiles (B^T d B)(.)(A e A^T) ] G.  slabs: [n_slabs][16][Cin][Cout] float32 with
  * n_slabs = adyolo_wino_wgrad_slabs(...); du: [16][Cin][Cout] scratch; dw: reference layout [Cout][Cin_real][3][3]. */
 int adyolo_wino_wgrad_slabs(int N, int H, int W, int Cin, int Cout);

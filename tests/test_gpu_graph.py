@@ -303,6 +303,71 @@ def test_uncapturable_step_falls_back_to_eager(ops, monkeypatch):
     assert losses[True] == losses[False], losses
 
 
+def test_runtime_error_inside_a_capture_falls_back_to_eager(ops, monkeypatch):
+    """A RuntimeError raised WHILE the step is being recorded (a HIP error, an op that refuses capture, ...) must not leave the
+    stream capturing or the trainer unusable: the capture is ended, the shape is remembered as eager-only with one warning, the
+    step runs eagerly and the losses equal those of a trainer that never records."""
+    import warnings
+    from adyolo_amd import ops as _ops
+    from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
+    from adyolo_amd.features import FeatureExtractor
+    from adyolo_amd.datasets import synthetic_audio, synthetic_targets
+    from adyolo_amd.train import TrainStep
+    n = 24000 * 2
+    audio = synthetic_audio(2, n, seed=11).to("cuda:0")
+    target = synthetic_targets(2, n // 2400, 12, seed=11).to("cuda:0")
+    real_loss = _ops.adyolo_loss
+
+    def loss_that_refuses_capture(*a, **kw):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("injected failure inside the capture")
+        return real_loss(*a, **kw)
+    losses = {}
+    for graph in (False, True):
+        torch.manual_seed(100)
+        prm = _params()
+        model = WrapperModel((1, 7, n // 600, 64), (), prm).to("cuda:0")
+        tr = TrainStep(model, WrapperCriterion(prm), FeatureExtractor(None, "cuda:0"), prm, graph=graph)
+        if graph:
+            monkeypatch.setattr(_ops, "adyolo_loss", loss_that_refuses_capture)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            losses[graph] = [float(tr.step(audio, target)) for _ in range(4)]
+        if graph:
+            assert not torch.cuda.is_current_stream_capturing()
+            assert tr.graphs.captures == 0 and len(tr.graphs.eager_only) == 1 and tr.graphs.eager_steps == 4
+            assert sum("not hipGraph-capturable" in str(w.message) and "injected failure" in str(w.message) for w in caught) == 1
+    assert losses[True] == losses[False], losses
+
+
+def test_recorded_graphs_are_bounded_lru(ops, monkeypatch):
+    """``StepGraphs`` / ``ForwardGraphs`` keep at most ``graph.MAX_GRAPHS`` recorded graphs (each owns a private pool with its
+    shape's activations): the least recently used one is evicted, an evicted shape is simply recorded again, and the outputs
+    stay those of the eager path."""
+    from adyolo_amd import graph as G
+    from adyolo_amd.wrapper import WrapperModel
+    from adyolo_amd.features import FeatureExtractor
+    from adyolo_amd.datasets import synthetic_audio
+    monkeypatch.setattr(G, "MAX_GRAPHS", 2)
+    torch.manual_seed(100)
+    prm = _params()
+    model = WrapperModel((1, 7, 80, 64), (), prm).to("cuda:0")
+    model.eval()
+    fx = FeatureExtractor(None, "cuda:0")
+    fg = G.ForwardGraphs(model, fx)
+    clips = {sec: synthetic_audio(1, 24000 * sec, seed=sec).to("cuda:0") for sec in (1, 2, 3)}
+    ref = {}
+    with torch.no_grad():
+        for sec, a in clips.items():
+            ref[sec] = model(fx(a, channels_last8=True), channels_last8=True).clone()
+    for sec in (1, 2, 3, 1, 1, 2, 3, 3, 1):                    # warm call + capture per shape, with evictions in between
+        for _ in range(2):
+            out, _dec = fg(clips[sec])
+            assert torch.equal(out, ref[sec]), sec
+        assert len(fg.entries) <= 2
+    assert fg.evictions >= 2 and fg.captures >= 5 and list(fg.entries)[-1] == tuple(clips[1].shape)
+
+
 def test_conformer_step_replays_from_a_graph(ops):
     """The ResNet-Conformer train step (config 4) recorded once and replayed: the attention-dropout seed, the only host-computed
     value of its step, is derived on the device from the stream's counter (``ops.seed32_dev``), and the max-pool backward is

@@ -87,6 +87,27 @@ def test_conv3x3_forward(ops, monkeypatch, n, h, w, cin, cout, relu, bias, adden
     assert_close(nchw(y), ref, 2e-5, "conv3x3 fwd (%s)" % algo)
 
 
+@pytest.mark.parametrize("persist", ["1", "0"])
+@pytest.mark.parametrize("algo", ["direct", "winograd", "winograd4"])
+def test_conv3x3_without_relu_propagates_nan(ops, monkeypatch, algo, persist):
+    """A NaN in the input must come out as NaN, not as -inf: round 4's branch-free ReLU (a maximum against a -inf floor for launches
+    without ReLU) turned NaN results into -inf in the two Winograd epilogues; now a maximum + wave-uniform select
+    (one-patch kernels) / a per-round wave-uniform branch (persistent F(4x4) kernel).  The other sample stays finite."""
+    monkeypatch.setenv("ADYOLO_W4_MIN_K", "32")
+    monkeypatch.setenv("ADYOLO_W4_PERSIST", persist)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 16, 16, 64, generator=g)
+    x[1, 5, 7, 3] = float("nan")
+    wt = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    wpk, _ = ops.pack_w3x3(dev(wt), 64, want_dgrad=False, algo=algo)
+    for relu in (False, True):
+        y = ops.conv3x3(dev(x), wpk, 64, relu=relu).cpu()
+        assert torch.isfinite(y[0]).all()
+        assert not torch.isinf(y).any(), "NaN became an infinity (relu=%s)" % relu
+        if not relu:
+            assert torch.isnan(y[1, 4:7, 6:9]).all()         # the 3 x 3 neighbourhood every filter tap reaches
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout", [
     (2, 16, 64, 32, 32), (2, 13, 32, 32, 64), (1, 18, 16, 64, 128), (1, 9, 16, 256, 256), (2, 20, 64, 7, 32),
     (3, 40, 64, 32, 32), (2, 150, 24, 32, 64), (1, 67, 37, 64, 32),
@@ -921,6 +942,25 @@ def test_audio_stager_double_buffers(ops):
         torch.cuda.synchronize()
         assert a.shape == (3, 2400, 4) and a.dtype == torch.float32
         assert np.array_equal(a.cpu().numpy(), (pcm.astype(np.float64) / 32768.0 + 1e-8).astype(np.float32))
+
+
+def test_audio_stager_reraises_worker_exceptions(ops):
+    """An exception inside a staging worker thread (here: a clip that cannot be converted to int16 samples) must surface in
+    ``stage()`` -- it used to die with the thread and the previous batch's audio was shipped again (round 4, ADVICE)."""
+    from adyolo_amd.datasets import AudioStager
+    st = AudioStager(4, 240, "cuda:0")
+    good = [np.zeros((240, 4), dtype=np.int16) for _ in range(4)]
+    st.stage(good, workers=2)
+
+    class Broken:
+        shape = (240, 4)
+
+        def __array__(self, *a, **kw):
+            raise TypeError("clip cannot be read")
+    bad = list(good)
+    bad[3] = Broken()
+    with pytest.raises(TypeError, match="clip cannot be read"):
+        st.stage(bad, workers=2)
 
 
 def test_specaug_masking_matches_numpy(ops):

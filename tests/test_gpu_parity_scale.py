@@ -473,6 +473,49 @@ def test_bench_shape_step_loss_direct_vs_winograd(ops, monkeypatch):
         assert np.isfinite(vals[algo]) and abs(vals[algo] - vals["direct"]) <= 1e-3 * abs(vals["direct"]), (algo, vals)
 
 
+def test_dispatch_table_at_the_bench_shape(ops):
+    """Which kernel every 3x3 convolution of one training step launches at the benchmark's clip shape with the DEFAULT thresholds
+    (12 clips x 60 s: every layer takes the kernel the 64-clip batch takes -- ``ops.DualPack`` picks by launch size, and the
+    smallest F(4x4) launch of the step, the 128 -> 64 data-gradient at 600 x 16 pixels, needs 11 clips for its 200 work items).  A threshold or dispatch regression cannot hide behind green parity tests: the parity tests force
+    ADYOLO_W4_MIN_K=32, this one asserts the table bench.py reports as ``dispatch``.
+    SE-ResNet34 (reference resnet.py:126-199): 16 blocks x 2 convolutions, forward + data-gradient = 64 launches + the 7 -> 32 stem.
+    F(4x4,3x3) takes a direction with >= 64 contraction channels and a multiple of 64 output channels: 25 forward + 25
+    data-gradient launches, all but one in the persistent form (the data-gradient of stage 3's first block adds the projection
+    shortcut's gradient without statistics -- an operand combination only the one-patch kernel is built for); F(2x2) keeps
+    stage 1 and the 32-channel sides of the 32 <-> 64 transition: 14; the stem is the direct kernel."""
+    import bench
+    from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
+    from adyolo_amd.features import FeatureExtractor
+    from adyolo_amd.datasets import synthetic_audio, synthetic_targets
+    from adyolo_amd.train import TrainStep
+    assert ops.reload_thresholds() == {"min_k": 64, "min_k_addend": 64, "min_wgs": 200}
+    assert ops.conv_algo() == "winograd4" and os.environ.get("ADYOLO_W4_PERSIST", "1") != "0"
+    b, n = 12, 24000 * 60
+    torch.manual_seed(100)
+    prm = bench.params("cuda:0")
+    model = WrapperModel((1, 7, n // 600, 64), (), prm).to("cuda:0")
+    tr = TrainStep(model, WrapperCriterion(prm), FeatureExtractor(None, "cuda:0"), prm)
+    audio = synthetic_audio(b, n, seed=1234).to("cuda:0")
+    target = synthetic_targets(b, n // 2400, 12, seed=1234).to("cuda:0")
+    tr.step(audio, target)
+    ops.DISPATCH_LOG = {}
+    try:
+        loss = float(tr.step(audio, target))
+        torch.cuda.synchronize()
+    finally:
+        log, ops.DISPATCH_LOG = ops.DISPATCH_LOG, None
+    assert np.isfinite(loss)
+    per_kernel = {}
+    for (name, cin, cout, epi), cnt in log.items():
+        per_kernel[name] = per_kernel.get(name, 0) + cnt
+    print(sorted(log.items()))
+    assert per_kernel == {"wino4p_fwd_kernel": 49, "wino4_fwd_kernel": 1, "wino_fwd_kernel": 14, "conv3x3_fwd_kernel": 1}, per_kernel
+    # the F(2x2) launches are exactly the ones with a 32-channel side, the direct one is the stem
+    assert all(min(cin, cout) == 32 for (name, cin, cout, _), _ in log.items() if name == "wino_fwd_kernel")
+    assert [(cin, cout) for (name, cin, cout, _), _ in log.items() if name == "conv3x3_fwd_kernel"] == [(8, 32)]
+    assert [(cin, cout, epi) for (name, cin, cout, epi), _ in log.items() if name == "wino4_fwd_kernel"] == [(128, 64, 2)]
+
+
 # ------------------------------------------------------------------------------ data-parallel path on one GPU (RCCL, 1 rank)
 _DP_CHILD = r"""
 import hashlib, json, os, sys

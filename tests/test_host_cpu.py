@@ -387,23 +387,26 @@ def test_raw_audio_dataset_shards_by_rank(tmp_path):
     assert te == [["t0", "t2"], ["t1"]]
 
 
-def test_math_mode_switch_and_parameter_epoch(monkeypatch):
-    """Host logic of round 3 that needs no GPU: the opt-in math mode is validated and only takes multi-chunk contractions by
-    default; the parameter epoch that evaluation-mode caches are keyed on moves when asked to; a state load on the wrapper
-    moves it too (the hook ``WrapperModel`` registers)."""
+def test_dispatch_thresholds_and_parameter_epoch(monkeypatch):
+    """Host logic that needs no GPU: the F(4x4) dispatch thresholds are read once and follow ``reload_thresholds()`` (the
+    conftest fixture calls it when a test moves an ADYOLO_W4_* variable); the weight-gradient form is decided in one place;
+    the parameter epoch that evaluation-mode caches are keyed on moves when asked to; a state load on the wrapper moves it too
+    (the hook ``WrapperModel`` registers).  (The bf16x3 math mode this test used to cover left the product in round 5.)"""
     import adyolo_amd  # noqa: F401
-    from adyolo_amd import ops, _lib
-    monkeypatch.delenv("ADYOLO_MATH", raising=False)
-    monkeypatch.delenv("ADYOLO_B3_MIN_K", raising=False)
-    assert ops.math_mode() == "f32" and not ops._b3_eligible(256, ops.math_mode())
-    monkeypatch.setenv("ADYOLO_MATH", "bf16x3")
-    assert ops.math_mode() == "bf16x3"
-    assert ops._b3_eligible(64, "bf16x3") and not ops._b3_eligible(32, "bf16x3")     # one-chunk contractions stay fp32
-    monkeypatch.setenv("ADYOLO_B3_MIN_K", "32")
-    assert ops._b3_eligible(32, "bf16x3")
-    monkeypatch.setenv("ADYOLO_MATH", "tf32")
-    with pytest.raises(_lib.AdyoloHipError):
-        ops.math_mode()
+    from adyolo_amd import ops
+    for k in ("ADYOLO_W4_MIN_K", "ADYOLO_W4_MIN_K_ADDEND", "ADYOLO_W4_MIN_WGS"):
+        monkeypatch.delenv(k, raising=False)
+    assert ops.reload_thresholds() == {"min_k": 64, "min_k_addend": 64, "min_wgs": 200}
+    assert ops._w4_eligible(64, 64) and not ops._w4_eligible(32, 64) and not ops._w4_eligible(64, 32) and not ops._w4_eligible(1024, 64)
+    monkeypatch.setenv("ADYOLO_W4_MIN_K", "32")                     # (the fixture reloads)
+    assert ops.W4_THRESHOLDS["min_k"] == 32 and ops._w4_eligible(32, 64)
+    monkeypatch.delenv("ADYOLO_W4_MIN_K")
+    assert ops.reload_thresholds()["min_k"] == 64
+    assert not hasattr(ops, "math_mode")
+    monkeypatch.delenv("ADYOLO_WGRAD_ALGO", raising=False)
+    monkeypatch.delenv("ADYOLO_CONV_ALGO", raising=False)
+    assert ops.wgrad_form(64, 128) == ("wino_wgrad_kernel", 16.0 / 36.0) and ops.wgrad_form(8, 32) == ("conv3x3_wgrad_kernel", 1.0)
+    assert ops.wgrad_form(64, 128, "direct")[1] == 1.0
     e0 = ops.PARAMS_EPOCH[0]
     ops.params_changed()
     assert ops.PARAMS_EPOCH[0] == e0 + 1

@@ -79,7 +79,7 @@ SHAPES = {1: (2400, 64, 32, 32), 2: (1200, 32, 64, 64), 3: (600, 16, 128, 128), 
           12: (1200, 32, 32, 64), 23: (600, 16, 64, 128), 34: (600, 16, 128, 256)}
 
 
-def bench(batch, iters, stages):
+def bench(batch, iters, stages, only=None):
     for st in stages:
         h, w, cin, cout = SHAPES[st]
         x = torch.randn(batch, h, w, cin, device=DEV)
@@ -89,6 +89,8 @@ def bench(batch, iters, stages):
         if wpk.shape[0] != 36:
             continue
         for name, kw in combos(batch, h, w, cin, cout).items():
+            if only and only not in name:
+                continue
             times = {}
             for rep in range(2):
                 for persist in (False, True):
@@ -116,6 +118,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--stages", default="2,3,4,23,34")
+    ap.add_argument("--only", default=None, help="time only the operand combinations whose name contains this string")
     a = ap.parse_args()
     if not a.skip_check:
         worst = 0.0
@@ -128,7 +131,7 @@ def main():
             worst = max(worst, check(*shp))
         print("WORST relative error %.3e %s" % (worst, "OK" if worst < 2e-5 else "FAIL"), flush=True)
     if not a.skip_bench:
-        bench(a.batch, a.iters, [int(s) for s in a.stages.split(",")])
+        bench(a.batch, a.iters, [int(s) for s in a.stages.split(",")], a.only)
 
 
 if __name__ == "__main__":
