@@ -722,7 +722,7 @@ extern "C" int adyolo_wino4_fwd(const float *x, const float *u, const float *bia
     const char *pe = getenv("ADYOLO_W4_PERSIST");
     const int epi = (stats ? 1 : 0) | (addend ? 2 : 0) | (addend_mask ? 4 : 0) | (stat_aux ? 8 : 0) | (stat_mask ? 16 : 0);
     const bool bits_ok = (!addend_mask || (mask_bits & 1)) && (!stat_mask || (mask_bits & 2));
-    if (xcd_div > 0 && bits_ok && !bias && !(pe && pe[0] == '0') && (epi == 0 || epi == 1 || epi == 9 || epi == 27 || epi == 31)) {
+    if (xcd_div > 0 && bits_ok && !bias && !(pe && pe[0] == '0') && (epi == 0 || epi == 1 || epi == 2 || epi == 9 || epi == 27 || epi == 31)) {
         static int ncus = 0;
         if (ncus == 0) {
             int dev = 0, v = 0;
@@ -739,6 +739,7 @@ extern "C" int adyolo_wino4_fwd(const float *x, const float *u, const float *bia
         switch (epi) {
             case 0: w4::launch_wino4p<0>(a); break;
             case 1: w4::launch_wino4p<1>(a); break;
+            case 2: w4::launch_wino4p<2>(a); break;
             case 9: w4::launch_wino4p<9>(a); break;
             case 27: w4::launch_wino4p<27>(a); break;
             default: w4::launch_wino4p<31>(a); break;

@@ -47,12 +47,30 @@ struct Cfg {
 __device__ __forceinline__ void bt6(const float4 (&c)[6], float4 (&t)[6]) {
     ADYOLO_W4_BT(x) ADYOLO_W4_BT(y) ADYOLO_W4_BT(z) ADYOLO_W4_BT(w)
 }
+// Packed fp32 fma d = k * a + c on <4 x float> (two v_pk_fma_f32), k wave-uniform.  INLINE ASSEMBLY on purpose: this LLVM unpacks
+// packed fp32 instructions that sit in the shadow of an MFMA into two scalar ones (it assumes they co-issue with the matrix
+// pipe); next to the fp32 MFMA nothing co-issues (tools/micro/mfma32_coissue.hip) and with one wave per SIMD a packed
+// instruction issues in the time of a scalar one (profiles/r03_valu_rate.txt: 6.0 vs 6.1 cycles), so the unpacking doubled the
+// transform cost of the pair loop.  (a - b: there is no
+// v_pk_sub_f32 and the backend scalarises a packed subtraction -- pkfma4(-1, b, a).)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 pkfma4(float k, f32x4 a, f32x4 c) {
+    const f32x2 kk = {k, k};                      // (an aligned SGPR pair: a lone 32-bit SGPR may be odd-numbered, which the packed
+    f32x2 lo, hi;                                 //  encoding rejects)
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(a.lo), "s"(kk), "v"(c.lo));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(a.hi), "s"(kk), "v"(c.hi));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+// d = a * b + c, all per-lane
+__device__ __forceinline__ f32x4 pkfma4v(f32x4 a, f32x4 b, f32x4 c) {
+    f32x2 lo, hi;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(a.lo), "v"(b.lo), "v"(c.lo));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(a.hi), "v"(b.hi), "v"(c.hi));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
 // the same, in place, on ext-vector pixels (wino4p.hpp)
 __device__ __forceinline__ void bt6v(f32x4 (&c)[6]) {
-    auto fm = [](float k, f32x4 a, f32x4 b) {
-        const f32x4 kk = {k, k, k, k};
-        return __builtin_elementwise_fma(kk, a, b);
-    };
+    auto fm = [](float k, f32x4 a, f32x4 b) { return pkfma4(k, a, b); };
     const f32x4 e12 = fm(-B2, c[2], c[4]), o12 = fm(-B2, c[1], c[3]);
     const f32x4 e34 = fm(-A2, c[2], c[4]), o34 = fm(-A2, c[1], c[3]);
     const f32x4 t0 = fm(P2, c[0], fm(-S2, c[2], c[4]));
@@ -63,6 +81,26 @@ __device__ __forceinline__ void bt6v(f32x4 (&c)[6]) {
     c[3] = fm(PB, o34, e34);
     c[4] = fm(-PB, o34, e34);
     c[5] = t5;
+}
+// out of place
+__device__ __forceinline__ void bt6v2(const f32x4 (&c)[6], f32x4 &t0, f32x4 &t1, f32x4 &t2, f32x4 &t3, f32x4 &t4, f32x4 &t5) {
+    auto fm = [](float k, f32x4 a, f32x4 b) { return pkfma4(k, a, b); };
+    const f32x4 e12 = fm(-B2, c[2], c[4]), o12 = fm(-B2, c[1], c[3]);
+    const f32x4 e34 = fm(-A2, c[2], c[4]), o34 = fm(-A2, c[1], c[3]);
+    t0 = fm(P2, c[0], fm(-S2, c[2], c[4]));
+    t5 = fm(P2, c[1], fm(-S2, c[3], c[5]));
+    t1 = fm(PA, o12, e12);
+    t2 = fm(-PA, o12, e12);
+    t3 = fm(PB, o34, e34);
+    t4 = fm(-PB, o34, e34);
+}
+// ... and the half column (see bt3 below) on ext vectors
+__device__ __forceinline__ void bt3v(const f32x4 (&c)[4], const f32x4 (&z)[3], f32x4 &t0, f32x4 &t1, f32x4 &t2, float K2, float KP) {
+    auto fm = [](float k, f32x4 a, f32x4 b) { return pkfma4(k, a, b); };
+    const f32x4 e = fm(-K2, c[1], c[3]), o = fm(-K2, c[0], c[2]);
+    t0 = fm(P2, z[0], fm(-S2, z[1], z[2]));
+    t1 = fm(KP, o, e);
+    t2 = fm(-KP, o, e);
 }
 __device__ __forceinline__ void bt6s(const float (&c)[6], float (&t)[6]) {      // the same on scalars
     const float e12 = fmaf(-B2, c[2], c[4]), o12 = fmaf(-B2, c[1], c[3]);

@@ -21,6 +21,10 @@
 #include "wino4_common.hpp"
 #include "wino4p_launch.hpp"
 
+#ifndef W4P_TIMING
+#define W4P_TIMING 0      // 1: one workgroup writes s_memtime stamps of its first patches to the stat_mean pointer (results stay valid
+                          // for plain launches; tools/wino4/persist_timing.py)
+#endif
 #ifndef W4P_WHATIF
 #define W4P_WHATIF 0      // timing-only builds (results invalid): bit 0 no reader half of the epilogue rounds, 1 no writer half, 2 no
                           // output stores, 3 no xi pass (LDS reads), 4 no MFMAs, 5 no nu pass
@@ -81,6 +85,13 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
         int z;
         asm volatile("v_mov_b32 %0, 0" : "=v"(z));
         return z;
+    };
+    int tpatch = 0;
+    auto tstamp = [&](int k) {
+        if (W4P_TIMING) {
+            if (blockIdx.x == 8 && tid == 0 && tpatch < 6)
+                reinterpret_cast<unsigned long long *>(const_cast<float *>(stat_mean))[tpatch * 16 + k] = __builtin_amdgcn_s_memtime();
+        }
     };
     // ---- GEMM-side constants (as in wino4_fwd_kernel)
     const int nuF = wave == 0 ? 0 : wave == 1 ? 2 : wave == 2 ? 3 : 5;
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
             for (int j = 0; j < 6; ++j) {
                 const int vo = round == 0 ? offF[j] : round == 1 ? offF[j] + RS * rowb : offL[j];
                 const bool ok = (unsigned)vo < nrec;
-                p[j] = __builtin_elementwise_fma(p[j], isc, ok ? ish : zero);
+                p[j] = pkfma4v(p[j], isc, ok ? ish : zero);
             }
         }
         bt6v(p);
@@ -224,38 +235,35 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
     st_load(pvB, 1, 1, true);
     __syncthreads();
 
-    float4 cF[6], cP[4], cZ[3];
-    float4 a[9];
+    // (ext-vector values throughout: with one wave per SIMD a v_pk_fma_f32 issues in the time of a v_fma_f32 --
+    //  profiles/r03_valu_rate.txt: 6.0 vs 6.1 cycles -- so every transform is written on <4 x float>, which the backend
+    //  splits into two packed instructions; the float4-struct form compiled to scalar fmas)
+    f32x4 cF[6], cP[4], cZ[3];
+    f32x4 a[9];
     int bF[4], bH[3], bZ[3];
     const char *ldsb = reinterpret_cast<const char *>(lds);
     auto a_reads_full = [&](int g) {
-        cF[0] = *reinterpret_cast<const float4 *>(ldsb + bF[0] + g * (CBUF * 4));
-        cF[1] = *reinterpret_cast<const float4 *>(ldsb + bF[1] + g * (CBUF * 4));
-        cF[2] = *reinterpret_cast<const float4 *>(ldsb + bF[2] + g * (CBUF * 4));
-        cF[3] = *reinterpret_cast<const float4 *>(ldsb + bF[3] + g * (CBUF * 4));
-        cF[4] = *reinterpret_cast<const float4 *>(ldsb + bF[1] + g * (CBUF * 4) + ROW4);
-        cF[5] = *reinterpret_cast<const float4 *>(ldsb + bF[2] + g * (CBUF * 4) + ROW4);
+        cF[0] = *reinterpret_cast<const f32x4 *>(ldsb + bF[0] + g * (CBUF * 4));
+        cF[1] = *reinterpret_cast<const f32x4 *>(ldsb + bF[1] + g * (CBUF * 4));
+        cF[2] = *reinterpret_cast<const f32x4 *>(ldsb + bF[2] + g * (CBUF * 4));
+        cF[3] = *reinterpret_cast<const f32x4 *>(ldsb + bF[3] + g * (CBUF * 4));
+        cF[4] = *reinterpret_cast<const f32x4 *>(ldsb + bF[1] + g * (CBUF * 4) + ROW4);
+        cF[5] = *reinterpret_cast<const f32x4 *>(ldsb + bF[2] + g * (CBUF * 4) + ROW4);
     };
     auto a_reads_half = [&](int g) {
-        cP[0] = *reinterpret_cast<const float4 *>(ldsb + bH[0] + g * (CBUF * 4));
-        cP[1] = *reinterpret_cast<const float4 *>(ldsb + bH[1] + g * (CBUF * 4));
-        cP[2] = *reinterpret_cast<const float4 *>(ldsb + bH[2] + g * (CBUF * 4));
-        cP[3] = *reinterpret_cast<const float4 *>(ldsb + bH[0] + g * (CBUF * 4) + ROW4);
-        cZ[0] = *reinterpret_cast<const float4 *>(ldsb + bZ[0] + g * (CBUF * 4));
-        cZ[1] = *reinterpret_cast<const float4 *>(ldsb + bZ[1] + g * (CBUF * 4));
-        cZ[2] = *reinterpret_cast<const float4 *>(ldsb + bZ[2] + g * (CBUF * 4));
+        cP[0] = *reinterpret_cast<const f32x4 *>(ldsb + bH[0] + g * (CBUF * 4));
+        cP[1] = *reinterpret_cast<const f32x4 *>(ldsb + bH[1] + g * (CBUF * 4));
+        cP[2] = *reinterpret_cast<const f32x4 *>(ldsb + bH[2] + g * (CBUF * 4));
+        cP[3] = *reinterpret_cast<const f32x4 *>(ldsb + bH[0] + g * (CBUF * 4) + ROW4);
+        cZ[0] = *reinterpret_cast<const f32x4 *>(ldsb + bZ[0] + g * (CBUF * 4));
+        cZ[1] = *reinterpret_cast<const f32x4 *>(ldsb + bZ[1] + g * (CBUF * 4));
+        cZ[2] = *reinterpret_cast<const f32x4 *>(ldsb + bZ[2] + g * (CBUF * 4));
     };
     auto a_xform_full = [&]() {
-        float4 tF[6];
-        bt6(cF, tF);
-#pragma unroll
-        for (int s = 0; s < 6; ++s) a[s] = tF[s];
+        bt6v2(cF, a[0], a[1], a[2], a[3], a[4], a[5]);    // the six xi of the full column
     };
     auto a_xform_half = [&]() {
-        float4 tH[3];
-        bt3(cP, cZ, tH, K2, KP);
-#pragma unroll
-        for (int s = 0; s < 3; ++s) a[6 + s] = tH[s];
+        bt3v(cP, cZ, a[6], a[7], a[8], K2, KP);
     };
     auto pair_bases = [&](int pr) {
         const int pboff = (pr & 1) * (2 * CBUF * 4);
@@ -312,17 +320,17 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                         xbL = x + (size_t)nn * xsample;
                     }
                     if (W4P_WHATIF & 16) {
-                        asm volatile("" : "+v"(a[s].x), "+v"(a[s].y), "+v"(a[s].z), "+v"(a[s].w));
+                        asm volatile("" : "+v"(a[s]));
                         asm volatile("" : "+v"(bq[slot_].x), "+v"(bq[slot_].y), "+v"(bq[slot_].z), "+v"(bq[slot_].w));
                     } else if (s < 8) {
-                        asm volatile("" : "+v"(a[s].x));
-                        acc[s][nt] = mfma32(a[s].x, bq[slot_].x, acc[s][nt]);
-                        acc[s][nt] = mfma32(a[s].y, bq[slot_].y, acc[s][nt]);
-                        acc[s][nt] = mfma32(a[s].z, bq[slot_].z, acc[s][nt]);
-                        acc[s][nt] = mfma32(a[s].w, bq[slot_].w, acc[s][nt]);
+                        asm volatile("" : "+v"(a[s]));
+                        acc[s][nt] = mfma32(a[s][0], bq[slot_].x, acc[s][nt]);
+                        acc[s][nt] = mfma32(a[s][1], bq[slot_].y, acc[s][nt]);
+                        acc[s][nt] = mfma32(a[s][2], bq[slot_].z, acc[s][nt]);
+                        acc[s][nt] = mfma32(a[s][3], bq[slot_].w, acc[s][nt]);
                         asm volatile("" : "+a"(acc[s][nt]));
                     } else {
-                        mfma32x4_vgpr(acc[s][nt], a[s], bq[slot_]);
+                        mfma32x4_vgpr(acc[s][nt], make_float4(a[s][0], a[s][1], a[s][2], a[s][3]), bq[slot_]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     // ---- loads of the step
@@ -357,8 +365,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ptr), 0, bytes, 0x00020000);
     };
     auto load4 = [&](const __amdgpu_buffer_rsrc_t &rs, int o_) {
-        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o_, 0, 0));
-        return make_float4(t.x, t.y, t.z, t.w);
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o_, 0, 0));
     };
 
     make_o(tid + opaque0());
@@ -374,7 +381,9 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
             decode(spn, nn, nty, ntx);
             Wn = W;
         }
+        tstamp(0);
         for (int pr = 0; pr < npairs; ++pr) pair_body(pr);
+        tstamp(1);
         __syncthreads();                                  // every wave is done with image buffers 2, 3
 
         // ---- epilogue of patch sp (n, ty0, tx0).  Its per-lane constants are made here, from an opaque copy of tid, and its
@@ -392,8 +401,8 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
         const int rrd = ((te >> 4) & 3) + 4 * (wave & 1), idx = te & 15, lhr = idx >> 3, c4 = idx & 7;
         const char *xrd = ldsb + CP::XOFF * 4 + rrd * 256 + idx * 16;
         float *xwr = lds + CP::XOFF + (wave * 9 * 8) * 64 + (te & 63);
-        float4 ssum[2], ssq[2];
-        ssum[0] = ssum[1] = ssq[0] = ssq[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x4 ssum[2], ssq[2];
+        ssum[0] = ssum[1] = ssq[0] = ssq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
         const size_t sbase = (size_t)n * ysample;         // floats
         const __amdgpu_buffer_rsrc_t yrs = rsrc_of(karg(56) + sbase, sbytes);                    // y
 #pragma unroll
@@ -421,7 +430,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
             // per component holds the bit.  The 32 dwords of a mask are squeezed into ONE register (bit 4 pixel + component) right
             // after the barrier -- they are small and mostly L2 hits, the operand tensors are not -- and a v_bfe_i32 with constant
             // offsets turns a bit into an and-mask where it is applied.
-            float4 ad[2][4], ax[2][4];
+            f32x4 ad[2][4], ax[2][4];
             unsigned amk_raw[2][4][4], smk_raw[2][4][4], amk = 0, smk = 0;
             auto keep = [&](const float *mptr, unsigned (&mk)[2][4][4]) {
                 const __amdgpu_buffer_rsrc_t rs = rsrc_of(mptr + (sbase >> 8) * 8, sbytes >> 5);
@@ -475,31 +484,37 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                         acc[s][nt][rh * 8 + rr] = 0.f;
                     }
             }
+            tstamp(2 + rnd);
             __syncthreads();
             if (MK) amk = squeeze(amk_raw);
             if (SMK) smk = squeeze(smk_raw);
             // ---- reader, xi direction: Q[row][nu] for the thread's two rows (rows 0, 2 take the sums m1 + m2, m3 + m4, rows 1, 3
-            // the differences: a wave-uniform branch), two nu columns of reads in flight
-            float4 qa[6], qb[6];
+            // the differences: a wave-uniform branch), two nu columns of reads in flight.  All arithmetic on <4 x float> values:
+            // packed instructions (see the pair loop).
+            auto fm = [](float k, f32x4 a_, f32x4 b_) { return pkfma4(k, a_, b_); };
+            auto sc = [](float k, f32x4 a_) {
+                const f32x4 kk = {k, k, k, k};
+                return kk * a_;
+            };
+            f32x4 qa[6], qb[6];
             if (W4P_WHATIF & (1 | 8)) {
 #pragma unroll
-                for (int nu = 0; nu < 6; ++nu) qa[nu] = qb[nu] = make_float4(1.f + nu, 2.f, 3.f, 4.f);
+                for (int nu = 0; nu < 6; ++nu) qa[nu] = qb[nu] = f32x4{1.f + nu, 2.f, 3.f, 4.f};
             } else {
-                float4 mm[2][5];
-                auto rd5 = [&](float4 (&d)[5], int nu) {
+                f32x4 mm[2][5];
+                auto rd5 = [&](f32x4 (&d)[5], int nu) {
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) d[k] = *reinterpret_cast<const float4 *>(xrd + DPOS[nu][k + (par ? 1 : 0)] * 2048);
+                    for (int k = 0; k < 5; ++k) d[k] = *reinterpret_cast<const f32x4 *>(xrd + DPOS[nu][k + (par ? 1 : 0)] * 2048);
                 };
                 if (par == 0) {
                     rd5(mm[0], 0);
                     rd5(mm[1], 1);
 #pragma unroll
                     for (int nu = 0; nu < 6; ++nu) {
-                        const float4(&v)[5] = mm[nu & 1];                       // m0 .. m4
-                        const float4 s12 = f4_add(v[1], v[2]), s34 = f4_add(v[3], v[4]);
-                        qa[nu] = f4_add(f4_add(v[0], s12), s34);
-                        qb[nu] = make_float4(fmaf(A2, s12.x, B2 * s34.x), fmaf(A2, s12.y, B2 * s34.y), fmaf(A2, s12.z, B2 * s34.z),
-                                             fmaf(A2, s12.w, B2 * s34.w));
+                        const f32x4(&v)[5] = mm[nu & 1];                        // m0 .. m4
+                        const f32x4 s12 = v[1] + v[2], s34 = v[3] + v[4];
+                        qa[nu] = (v[0] + s12) + s34;
+                        qb[nu] = fm(A2, s12, sc(B2, s34));
                         __builtin_amdgcn_sched_barrier(0);
                         if (nu + 2 < 6) rd5(mm[nu & 1], nu + 2);
                         __builtin_amdgcn_sched_barrier(0);
@@ -509,12 +524,10 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                     rd5(mm[1], 1);
 #pragma unroll
                     for (int nu = 0; nu < 6; ++nu) {
-                        const float4(&v)[5] = mm[nu & 1];                       // m1 .. m5
-                        const float4 d12 = f4_sub(v[0], v[1]), d34 = f4_sub(v[2], v[3]);
-                        qa[nu] = make_float4(fmaf(PA, d12.x, PB * d34.x), fmaf(PA, d12.y, PB * d34.y), fmaf(PA, d12.z, PB * d34.z),
-                                             fmaf(PA, d12.w, PB * d34.w));
-                        qb[nu] = make_float4(fmaf(A3, d12.x, fmaf(B3, d34.x, v[4].x)), fmaf(A3, d12.y, fmaf(B3, d34.y, v[4].y)),
-                                             fmaf(A3, d12.z, fmaf(B3, d34.z, v[4].z)), fmaf(A3, d12.w, fmaf(B3, d34.w, v[4].w)));
+                        const f32x4(&v)[5] = mm[nu & 1];                        // m1 .. m5
+                        const f32x4 d12 = fm(-1.f, v[1], v[0]), d34 = fm(-1.f, v[3], v[2]);   // (no v_pk_sub_f32: a - b as a packed fma)
+                        qa[nu] = fm(PA, d12, sc(PB, d34));
+                        qb[nu] = fm(A3, d12, fm(B3, d34, v[4]));
                         __builtin_amdgcn_sched_barrier(0);
                         if (nu + 2 < 6) rd5(mm[nu & 1], nu + 2);
                         __builtin_amdgcn_sched_barrier(0);
@@ -533,63 +546,56 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
             // ---- nu direction and the pixels (ReLU: one wave-uniform branch per round around two copies of the loop)
-            float4 smean = make_float4(0.f, 0.f, 0.f, 0.f), sinv = smean;
+            f32x4 smean = {0.f, 0.f, 0.f, 0.f}, sinv = smean;
             if (AUX) {
-                smean = *reinterpret_cast<const float4 *>(karg(80) + co);                         // stat_mean, stat_invstd
-                sinv = *reinterpret_cast<const float4 *>(karg(88) + co);
+                smean = *reinterpret_cast<const f32x4 *>(karg(80) + co);                          // stat_mean, stat_invstd
+                sinv = *reinterpret_cast<const f32x4 *>(karg(88) + co);
             }
             auto andf = [](float v, unsigned k) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & k); };
             auto pixels = [&](auto RL_) {
                 constexpr bool RL = decltype(RL_)::value;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const float4(&q)[6] = e ? qb : qa;
-                    float4 Y[4];
+                    const f32x4(&q)[6] = e ? qb : qa;
+                    f32x4 Y[4];
                     if (W4P_WHATIF & 32) {
                         Y[0] = q[0]; Y[1] = q[1]; Y[2] = q[2]; Y[3] = q[3];
                     } else {
-                        at4(q[0].x, q[1].x, q[2].x, q[3].x, q[4].x, q[5].x, Y[0].x, Y[1].x, Y[2].x, Y[3].x);
-                        at4(q[0].y, q[1].y, q[2].y, q[3].y, q[4].y, q[5].y, Y[0].y, Y[1].y, Y[2].y, Y[3].y);
-                        at4(q[0].z, q[1].z, q[2].z, q[3].z, q[4].z, q[5].z, Y[0].z, Y[1].z, Y[2].z, Y[3].z);
-                        at4(q[0].w, q[1].w, q[2].w, q[3].w, q[4].w, q[5].w, Y[0].w, Y[1].w, Y[2].w, Y[3].w);
+                        // A^T along nu: y[b] = sum_nu AT[b][nu] q[nu]
+                        const f32x4 s12 = q[1] + q[2], d12 = fm(-1.f, q[2], q[1]), s34 = q[3] + q[4], d34 = fm(-1.f, q[4], q[3]);
+                        Y[0] = (q[0] + s12) + s34;
+                        Y[1] = fm(PA, d12, sc(PB, d34));
+                        Y[2] = fm(A2, s12, sc(B2, s34));
+                        Y[3] = fm(A3, d12, fm(B3, d34, q[5]));
                     }
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        float4 v = Y[b];
+                        f32x4 v = Y[b];
                         const unsigned bit0 = 16 * e + 4 * b;
                         if (AD) {
-                            float4 a_ = ad[e][b];
-                            if (MK)
-                                a_ = make_float4(andf(a_.x, (unsigned)__builtin_amdgcn_sbfe((int)amk, bit0, 1u)),
-                                                 andf(a_.y, (unsigned)__builtin_amdgcn_sbfe((int)amk, bit0 + 1, 1u)),
-                                                 andf(a_.z, (unsigned)__builtin_amdgcn_sbfe((int)amk, bit0 + 2, 1u)),
-                                                 andf(a_.w, (unsigned)__builtin_amdgcn_sbfe((int)amk, bit0 + 3, 1u)));
-                            v = f4_add(v, a_);
+                            f32x4 a_ = ad[e][b];
+                            if (MK) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) a_[k] = andf(a_[k], (unsigned)__builtin_amdgcn_sbfe((int)amk, bit0 + k, 1u));
+                            }
+                            v = v + a_;
                         }
-                        if (RL) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                        if (RL) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+                        }
                         if (!(W4P_WHATIF & 4) || (e == 0 && b == 0))
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yrs, off[e][b], 0, 0);
                         if (ST) {
                             // out-of-image pixels and masked-out components count 0
                             const unsigned kin = ~(unsigned)(off[e][b] >> 31);
-                            if (SMK)
-                                v = make_float4(andf(v.x, kin & (unsigned)__builtin_amdgcn_sbfe((int)smk, bit0, 1u)),
-                                                andf(v.y, kin & (unsigned)__builtin_amdgcn_sbfe((int)smk, bit0 + 1, 1u)),
-                                                andf(v.z, kin & (unsigned)__builtin_amdgcn_sbfe((int)smk, bit0 + 2, 1u)),
-                                                andf(v.w, kin & (unsigned)__builtin_amdgcn_sbfe((int)smk, bit0 + 3, 1u)));
-                            else
-                                v = make_float4(andf(v.x, kin), andf(v.y, kin), andf(v.z, kin), andf(v.w, kin));
-                            ssum[nt] = f4_add(ssum[nt], v);
-                            float4 w_ = v;
-                            if (AUX) {
-                                const float4 x_ = ax[e][b];
-                                w_ = make_float4((x_.x - smean.x) * sinv.x, (x_.y - smean.y) * sinv.y, (x_.z - smean.z) * sinv.z,
-                                                 (x_.w - smean.w) * sinv.w);
-                            }
-                            ssq[nt].x = fmaf(v.x, w_.x, ssq[nt].x);
-                            ssq[nt].y = fmaf(v.y, w_.y, ssq[nt].y);
-                            ssq[nt].z = fmaf(v.z, w_.z, ssq[nt].z);
-                            ssq[nt].w = fmaf(v.w, w_.w, ssq[nt].w);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                v[k] = andf(v[k], SMK ? (kin & (unsigned)__builtin_amdgcn_sbfe((int)smk, bit0 + k, 1u)) : kin);
+                            ssum[nt] = ssum[nt] + v;
+                            f32x4 w_ = v;
+                            if (AUX) w_ = fm(-1.f, smean, ax[e][b]) * sinv;
+                            ssq[nt] = __builtin_elementwise_fma(v, w_, ssq[nt]);
                         }
                     }
                 }
@@ -602,6 +608,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
 #pragma unroll
                 for (int uu = 0; uu < BR; ++uu) bq[uu] = bload(uu % 18, (uu / 18) % nkg);
             }
+            tstamp(6 + rnd);
             __syncthreads();                              // the exchange region is free again
         }
         if (ST) {
@@ -610,8 +617,8 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
             const int grp = (te >> 4) * 2 + lhr;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                *reinterpret_cast<float4 *>(&red[(0 * 32 + grp) * 64 + nt * 32 + c4 * 4]) = ssum[nt];
-                *reinterpret_cast<float4 *>(&red[(1 * 32 + grp) * 64 + nt * 32 + c4 * 4]) = ssq[nt];
+                *reinterpret_cast<f32x4 *>(&red[(0 * 32 + grp) * 64 + nt * 32 + c4 * 4]) = ssum[nt];
+                *reinterpret_cast<f32x4 *>(&red[(1 * 32 + grp) * 64 + nt * 32 + c4 * 4]) = ssq[nt];
             }
             __syncthreads();
             if (te < 128) {
@@ -628,6 +635,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
             }
             __syncthreads();
         }
+        tstamp(10);
         if (!more) break;
         sp = spn;
         n = nn;
@@ -642,6 +650,8 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
         a_reads_full(0);
         a_xform_full();
         a_reads_half(0);
+        tstamp(11);
+        ++tpatch;
     }
 }
 

@@ -16,7 +16,8 @@ struct W4Launch {                                         // everything adyolo_w
 // mask (bits).  Compile-time, one translation unit per value (wino4p_e<EPI>.hip): the register allocation of a 512-register
 // kernel does not survive run-time operand combinations (conditionally loaded operand arrays were merged through scratch
 // memory).  Instantiated: the combinations the SE-ResNet block launches (functional.py) -- 0 plain, 1 forward convolutions,
-// 9 data-gradient of conv2, 27 / 31 data-gradient of conv1 (projection / identity shortcut); every other combination, and
+// 9 data-gradient of conv2, 2 / 27 / 31 data-gradient of conv1 (projection shortcut after a pooled / un-pooled stage boundary,
+// identity shortcut); every other combination, and
 // masks given as float tensors, take the one-patch kernel (wino4.hip)
 template <int EPI>
 void launch_wino4p(const W4Launch &a);

@@ -9,7 +9,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc_write_$tag -o run
 cd $R
 python3 tools/make_traffic.py $(find gpurun_out/pmc_fetch_$tag -name "*counter_collection.csv" | head -1) $(find gpurun_out/pmc_write_$tag -name "*counter_collection.csv" | head -1) winograd wino_fwd_kernel gpurun_out/${tag}_traffic.json
 # round 4: the F(4x4,3x3) kernel of the default algorithm (bench.py looks its algorithm's key up: roofline.traffic)
-python3 tools/make_traffic.py $(find gpurun_out/pmc_fetch_$tag -name "*counter_collection.csv" | head -1) $(find gpurun_out/pmc_write_$tag -name "*counter_collection.csv" | head -1) winograd4 wino4_fwd_kernel gpurun_out/${tag}_traffic.json
+python3 tools/make_traffic.py $(find gpurun_out/pmc_fetch_$tag -name "*counter_collection.csv" | head -1) $(find gpurun_out/pmc_write_$tag -name "*counter_collection.csv" | head -1) winograd4 wino4p_fwd_kernel gpurun_out/${tag}_traffic.json
 python3 tools/pmc_summary.py $(find gpurun_out/pmc_fetch_$tag -name "*counter_collection.csv" | head -1) adyolo > gpurun_out/${tag}_pmc_fetch_summary.txt
 python3 tools/pmc_summary.py $(find gpurun_out/pmc_write_$tag -name "*counter_collection.csv" | head -1) adyolo > gpurun_out/${tag}_pmc_write_summary.txt
 # per (full template name, grid) HBM rooflines; durations from the kernel trace of the --stats pass (no counters running)
