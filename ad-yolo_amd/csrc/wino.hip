@@ -434,6 +434,10 @@ extern "C" int adyolo_wino_fwd(const float *x, const float *u, const float *bias
     return check_launch("wino_fwd");
 }
 
+#ifndef WGRAD_WHATIF
+#define WGRAD_WHATIF 0
+#endif
+
 namespace adyolo {
 
 // ================================================================================================
@@ -698,6 +702,17 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
                 s1[nt] = f4_fma(q1, sgd, p1);
             }
             __builtin_amdgcn_sched_barrier(0);
+#if WGRAD_WHATIF
+            // timing-only model of a F(4x4)-domain weight-gradient (results invalid): 9/16 of the MFMAs
+            // (18 of the 32 per tile row) and the extra transform instructions of 6 x 6 tiles as dependent-free dummy VALU
+            // (WGRAD_WHATIF = their number per tile row)
+            {
+                float dmy[4] = {r0.x, r1.y, r2.z, r3.w};
+#pragma unroll
+                for (int i = 0; i < WGRAD_WHATIF; ++i) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dmy[i & 3]));
+                r0.x = dmy[0]; r1.y = dmy[1]; r2.z = dmy[2]; r3.w = dmy[3];
+            }
+#endif
             __builtin_amdgcn_s_setprio(3);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
@@ -707,8 +722,12 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
                     const float4 b = v == 0 ? s0[nt] : (v == 1 ? f4_add(s0[nt], s1[nt]) : (v == 2 ? f4_sub(s0[nt], s1[nt]) : s1[nt]));
                     acc[v][nt] = mfma32(a.x, b.x, acc[v][nt]);
                     acc[v][nt] = mfma32(a.y, b.y, acc[v][nt]);
+#if WGRAD_WHATIF
+                    if (v == 0 || (v == 1 && nt == 0)) acc[v][nt] = mfma32(a.z, b.z, acc[v][nt]);      // 2 per (v, nt) + 2 more = 18 of 32
+#else
                     acc[v][nt] = mfma32(a.z, b.z, acc[v][nt]);
                     acc[v][nt] = mfma32(a.w, b.w, acc[v][nt]);
+#endif
                 }
             }
             __builtin_amdgcn_s_setprio(0);

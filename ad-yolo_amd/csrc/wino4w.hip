@@ -1,0 +1,410 @@
+// K2w4w: weight gradient of the 3x3 convolution (stride 1, pad 1, channels-last) in the Winograd F(4x4,3x3) domain on the exact-fp32
+// MFMA (round 5).  Replaces the backward-weights half of nn.Conv2d at /root/reference/src/models/backbones/resnet.py:16,18, like
+// wino.hip's wino_wgrad_kernel (F(2x2) domain: 16 multiplies per 2x2 tile and channel pair = 16/36 of the direct form's); here
+//     dw = G^T [ sum over 4x4 output tiles of (B^T d B) (.) (A e A^T) ] G      d: 6x6 input tile, e: 4x4 tile of dy, A = (A^T)^T
+// with the matrices of csrc/wino4.hip (interpolation points 0, +-3/4, +-3/2, infinity; every constant of B^T and A dyadic): 36
+// multiplies per 16 outputs = 9/36 of the direct form's matrix FLOPs, 1.78x fewer MFMAs than wino_wgrad_kernel.  Error against a
+// float64 weight gradient: 1.1-2.6e-6 of its absmax with fp32 accumulation in MFMA order (tools/wino4w/numerics.py; F(2x2): 0.7-2.0e-6).
+// The 36 positions (xi, nu) are 36 GEMMs  dU[pos][ci][co] = sum_tiles V[pos][tile][ci] E[pos][tile][co]  with the contraction over TILES.
+//
+// One workgroup (4 waves, one per SIMD, 256 AccVGPR + 256 VGPR each: the register budget of wino4_fwd_kernel) per CU owns a
+// (32 ci x 64 co) block of all 36 positions -- wave w one column nu of the 6 x 6 grid and half of another, as in wino4.hip --
+// and walks pairs of RUNS (a run = four tiles side by side = 16 output columns; with W = 16 the two runs of a pair come from two
+// samples, with W = 32 from one row) top to bottom, one tile row = 8 tiles = four MFMA k-steps per step (72 MFMAs per wave).
+// Both transforms are separable and split like the forward kernel's input transform:
+//   * W direction while staging: a thread fetches the 18 input pixels (dword loads, channel-contiguous: a lane = a channel) of one
+//     (new row, channel, run), applies the producer's BatchNorm affine, transforms the four tiles at once (<4 x float> = the four
+//     tiles: packed instructions) and writes six ds_write_b128 into C[nu][row slot][channel][8 tiles]; dy likewise (16 pixels ->
+//     D[nu][row][channel][8 tiles], 4 -> 6 points with A).  The tile index runs along a lane's registers, so a ds_read_b128
+//     yields the operand of four k-steps; the two tile quads of a channel are swapped when (channel >> 3) is odd, which keeps
+//     every 16-lane ds_read_b128 group conflict-free (wino.hip).
+//   * H direction in the GEMM waves: six (x) / four (dy) ds_read_b128 per column give the six A / B operand quads of the column.
+// x rows live in a six-slot ring (a step's window; the four rows a step retires are overwritten by the next step's new rows after
+// a barrier that follows the window's reads), dy rows in two buffers: 37 + 2 x 49 KB of LDS.  Slabs of dU (one per workgroup) are
+// summed in a fixed order and G^T . G applied by one small kernel (deterministic).
+#include "wino4_common.hpp"
+
+namespace adyolo {
+namespace w4 {
+
+#ifndef W4W_WHATIF
+#define W4W_WHATIF 0
+#endif
+
+// A (6 x 4) along one direction on the four tiles of a run: t = A v
+__device__ __forceinline__ void a6v(const f32x4 (&v)[4], f32x4 (&t)[6]) {
+    auto fm = [](float k, f32x4 a, f32x4 b) { return pkfma4(k, a, b); };
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 ea = fm(A2, v[2], v[0]), oa = fm(A3, v[3], fm(PA, v[1], z));
+    const f32x4 eb = fm(B2, v[2], v[0]), ob = fm(B3, v[3], fm(PB, v[1], z));
+    t[0] = v[0];
+    t[1] = ea + oa;
+    t[2] = fm(-1.f, oa, ea);
+    t[3] = eb + ob;
+    t[4] = fm(-1.f, ob, eb);
+    t[5] = v[3];
+}
+// half of it: rows xi = 0, 1, 2 (K = 3/4) or 5, 3, 4 (K = 3/2), in that order; z = v[0] or v[3] (read through a wave-uniform address)
+__device__ __forceinline__ void a3v(const f32x4 (&v)[4], const f32x4 &zrow, f32x4 &t0, f32x4 &t1, f32x4 &t2, float K1, float K2,
+                                    float K3) {
+    auto fm = [](float k, f32x4 a, f32x4 b) { return pkfma4(k, a, b); };
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 e = fm(K2, v[2], v[0]), o = fm(K3, v[3], fm(K1, v[1], z));
+    t0 = zrow;
+    t1 = e + o;
+    t2 = fm(-1.f, o, e);
+}
+
+constexpr int XROWB = 1024;                 // bytes of an x row slot: 32 channels x 8 tiles
+constexpr int XSLOTS = 6;
+constexpr int XNU = XSLOTS * XROWB;         // per nu plane
+constexpr int XBYTES = 6 * XNU;             // 36 864
+constexpr int DROWB = 2048;                 // 64 channels x 8 tiles
+constexpr int DNU = 4 * DROWB;
+constexpr int DBUF = 6 * DNU;               // 49 152
+
+template <bool AFF>
+__global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
+    const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ in_scale,
+    const float *__restrict__ in_shift, float *__restrict__ slabs, int N, int H, int W, int Cin, int Cout, int runsW, int npairs,
+    int nseg, int seg_steps, int nitems, int nsplit, int ciBlocks, int nblk) {
+    __shared__ __attribute__((aligned(16))) float lds[(XBYTES + 2 * DBUF) / 4];
+    char *ldsb = reinterpret_cast<char *>(lds);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    // workgroup -> (split, channel block): the 32 workgroups of an XCD are all channel blocks of 32 / nblk splits, so that one
+    // XCD's L2 sees the x / dy rows of its splits once for every channel block that needs them
+    int split, blk;
+    if (32 % nblk == 0 && (int)gridDim.x == 8 * 32) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        blk = j % nblk;
+        split = xcd * (32 / nblk) + j / nblk;
+    } else {
+        blk = blockIdx.x % nblk;
+        split = blockIdx.x / nblk;
+    }
+    if (split >= nsplit) return;
+    const int cbk = blk / ciBlocks, ibk = blk - cbk * ciBlocks;
+    const int co0 = cbk * 64, c0 = ibk * 32;
+
+    // ---- GEMM side: positions of the wave (wino4.hip): full column nuF (xi = 0..5 -> acc 0..5), half column nuH (acc 6..8 =
+    // xi 0, 1, 2 for hh = 0, xi 5, 3, 4 for hh = 1)
+    const int nuF = wave == 0 ? 0 : wave == 1 ? 2 : wave == 2 ? 3 : 5;
+    const int nuH = wave < 2 ? 1 : 4;
+    const int hh = wave & 1;
+    const float K2x = hh ? A2 : B2, KPx = hh ? PB : PA;                       // x half column (bt3v)
+    const float K1d = hh ? PB : PA, K2d = hh ? B2 : A2, K3d = hh ? B3 : A3;   // dy half column (a3v)
+    const int lsw = (lh ^ ((li >> 3) & 1)) << 4;                              // tile quad of the lane's half, swizzled
+    const int lx = li * 32 + lsw;                                             // lane part of an x read / a dy read inside a 32-channel block
+
+    f32x16 acc[9][2];
+#pragma unroll
+    for (int s = 0; s < 9; ++s)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][cb][r] = 0.f;
+
+    // ---- staging roles.  A wave stages ONE run (the two runs of a pair may belong to different samples).
+    // x: channel sxc, new row (wave >> 1) * 2 + lh of the step's four, run wave & 1.   dy: channel sdc (64), rows (wave >> 1) * 2 + {0, 1}
+    const int run = wave & 1;
+    const int sxc = li, sxr = (wave >> 1) * 2 + lh;
+    const int sdc = lane, sdr = (wave >> 1) * 2;
+    float xsc = 1.f, xsh = 0.f;
+    if (AFF) {
+        xsc = in_scale[c0 + sxc];
+        xsh = in_shift[c0 + sxc];
+    }
+    const int xrowb = W * Cin * 4, drowb = W * Cout * 4, xpixb = Cin * 4, dpixb = Cout * 4;
+    // whole-tensor buffer descriptors (the host checks that both tensors stay below 4 GiB); image-border pixels / rows are
+    // redirected out of range (0x80000000 exceeds num_records: the load returns 0)
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, (int)((size_t)N * H * W * Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dy), 0, (int)((size_t)N * H * W * Cout * 4), 0x00020000);
+    const int wxl = (sxc * 32 + ((run ^ ((sxc >> 3) & 1)) << 4));             // lane part of an x write
+    const int wdl = (sdc * 32 + ((run ^ ((sdc >> 3) & 1)) << 4));             // ... of a dy write (64 channels: two 32-channel blocks of 1 KB)
+
+    for (int item = split; item < nitems; item += nsplit) {
+        const int seg = item % nseg;
+        const int pair = item / nseg;
+        // the wave's run of the pair: run index q over (sample, 16-column run inside a row); an odd total leaves the last pair half empty
+        const int q = 2 * pair + run;
+        const bool qok = q < N * runsW;
+        const int n = qok ? q / runsW : 0, rw = qok ? q - (q / runsW) * runsW : 0;
+        const int t0 = seg * seg_steps;                                       // first tile row of the segment
+        const int nsteps = min(seg_steps, H / 4 - t0);
+        const unsigned xbase = (unsigned)(((size_t)n * H * W + (size_t)rw * 16) * Cin + c0) * 4u + (unsigned)sxc * 4u;
+        const unsigned dbase = (unsigned)(((size_t)n * H * W + (size_t)rw * 16) * Cout + co0) * 4u + (unsigned)sdc * 4u;
+        const bool edgeL = rw == 0, edgeR = rw == runsW - 1;
+
+        // x pixels of image row gy (any, also -1 / H), columns 16 rw - 1 .. 16 rw + 16, of the thread's channel; W-transformed
+        // -> six <4 tiles> values
+        float xpx[18];
+        auto x_load = [&](int gy) {
+            const bool rowok = qok && gy >= 0 && gy < H;
+            const int vrow = rowok ? (int)(xbase + (unsigned)gy * (unsigned)xrowb) : (int)0x80000000;
+            // columns 0 .. 15 of the run through the scalar offset; the two neighbours (column -1 / 16) have offsets of their own
+            const int vL = (rowok && !edgeL) ? vrow - xpixb : (int)0x80000000;
+            const int vR = (rowok && !edgeR) ? vrow + 16 * xpixb : (int)0x80000000;
+            xpx[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vL, 0, 0));
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                xpx[1 + k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vrow, k * xpixb, 0));
+            xpx[17] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vR, 0, 0));
+        };
+        auto x_store = [&](int gy, int slot) {
+            if (AFF) {
+                // x' = scale x + shift inside the image, 0 outside (the loads returned 0 there)
+                const bool rowok = qok && gy >= 0 && gy < H;
+                const float sh = rowok ? xsh : 0.f;
+                xpx[0] = fmaf(xpx[0], xsc, edgeL ? 0.f : sh);
+#pragma unroll
+                for (int k = 1; k < 17; ++k) xpx[k] = fmaf(xpx[k], xsc, sh);
+                xpx[17] = fmaf(xpx[17], xsc, edgeR ? 0.f : sh);
+            }
+            f32x4 c[6], t0_, t1_, t2_, t3_, t4_, t5_;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) c[i] = f32x4{xpx[i], xpx[4 + i], xpx[8 + i], xpx[12 + i]};
+            bt6v2(c, t0_, t1_, t2_, t3_, t4_, t5_);
+            char *dst = ldsb + slot * XROWB + wxl;
+            *reinterpret_cast<f32x4 *>(dst + 0 * XNU) = t0_;
+            *reinterpret_cast<f32x4 *>(dst + 1 * XNU) = t1_;
+            *reinterpret_cast<f32x4 *>(dst + 2 * XNU) = t2_;
+            *reinterpret_cast<f32x4 *>(dst + 3 * XNU) = t3_;
+            *reinterpret_cast<f32x4 *>(dst + 4 * XNU) = t4_;
+            *reinterpret_cast<f32x4 *>(dst + 5 * XNU) = t5_;
+        };
+        float dpx[2][16];
+        auto d_load = [&](int trow) {                                          // dy rows 4 trow + sdr, + 1 (always inside the image)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int vrow = qok ? (int)(dbase + (unsigned)(4 * trow + sdr + p) * (unsigned)drowb) : (int)0x80000000;
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    dpx[p][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, vrow, k * dpixb, 0));
+            }
+        };
+        auto d_store = [&](int buf) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                f32x4 v[4], t[6];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = f32x4{dpx[p][i], dpx[p][4 + i], dpx[p][8 + i], dpx[p][12 + i]};
+                a6v(v, t);
+                char *dst = ldsb + XBYTES + buf * DBUF + (sdr + p) * DROWB + wdl;
+#pragma unroll
+                for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<f32x4 *>(dst + nu * DNU) = t[nu];
+            }
+        };
+
+        // ---- prologue: the whole window of the first step (rows 4 t0 - 1 .. 4 t0 + 4 -> slots 0 .. 5) and its dy rows
+        __syncthreads();                                                       // (the previous item's readers are done)
+        x_load(4 * t0 - 1 + sxr);
+        d_load(t0);
+        x_store(4 * t0 - 1 + sxr, sxr);
+        if (sxr < 2) {
+            x_load(4 * t0 + 3 + sxr);
+            x_store(4 * t0 + 3 + sxr, 4 + sxr);
+        }
+        d_store(0);
+        // requests of step 1 (its four new x rows: window rows 2 .. 5; its dy rows)
+        x_load(4 * (t0 + 1) + 1 + sxr);
+        d_load(t0 + 1);
+        __syncthreads();
+
+        int rot = 0;                                                           // slot of window row 0 of the current step
+        for (int k = 0; k < nsteps; ++k) {
+            const int buf = k & 1;
+            // ---- the wave's operands of the step.  x: rows of the window for its two columns
+            f32x4 a[9];
+            {
+                int so[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    int sl = rot + i;
+                    sl = sl >= 6 ? sl - 6 : sl;
+                    so[i] = sl * XROWB;                                        // (uniform)
+                }
+                const char *xp = ldsb + lx;
+                f32x4 cF[6], cP[4], cZ[3];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) cF[i] = *reinterpret_cast<const f32x4 *>(xp + nuF * XNU + so[i]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cP[i] = *reinterpret_cast<const f32x4 *>(xp + nuH * XNU + so[1 + i]);
+                // rows hh, hh + 2, hh + 4 of the half column (the single term's operands)
+                cZ[0] = *reinterpret_cast<const f32x4 *>(xp + nuH * XNU + (hh ? so[1] : so[0]));
+                cZ[1] = *reinterpret_cast<const f32x4 *>(xp + nuH * XNU + (hh ? so[3] : so[2]));
+                cZ[2] = *reinterpret_cast<const f32x4 *>(xp + nuH * XNU + (hh ? so[5] : so[4]));
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();                                               // every wave has read the window: its four oldest rows are free
+                // ---- staging of step k + 1 (loads requested one step ago): x rows -> the slots the window just retired
+                {
+                    int sl = rot + sxr;                                        // window row sxr of step k = slot of new row 2 + sxr of step k + 1
+                    sl = sl >= 6 ? sl - 6 : sl;
+                    x_store(4 * (t0 + k + 1) + 1 + sxr, sl);
+                }
+                d_store(buf ^ 1);
+                // requests of step k + 2 (clamped to the image: unused past the end)
+                x_load(4 * (t0 + k + 2) + 1 + sxr);
+                d_load(min(t0 + k + 2, H / 4 - 1));
+                __builtin_amdgcn_sched_barrier(0);
+                bt6v2(cF, a[0], a[1], a[2], a[3], a[4], a[5]);
+                bt3v(cP, cZ, a[6], a[7], a[8], K2x, KPx);
+            }
+            // ---- dy operands and the MFMAs, one 32-channel block of the 64 at a time
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const char *dp = ldsb + XBYTES + buf * DBUF + cb * 1024 + lx;
+                f32x4 vF[4], vH[4], zH, b[9];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vF[i] = *reinterpret_cast<const f32x4 *>(dp + nuF * DNU + i * DROWB);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vH[i] = *reinterpret_cast<const f32x4 *>(dp + nuH * DNU + i * DROWB);
+                zH = *reinterpret_cast<const f32x4 *>(dp + nuH * DNU + (hh ? 3 : 0) * DROWB);
+                {
+                    f32x4 t[6];
+                    a6v(vF, t);
+#pragma unroll
+                    for (int s = 0; s < 6; ++s) b[s] = t[s];
+                }
+                a3v(vH, zH, b[6], b[7], b[8], K1d, K2d, K3d);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 9; ++s) {
+                    if (W4W_WHATIF & 1) continue;
+                    if (s < 8) {
+                        acc[s][cb] = mfma32(a[s][0], b[s][0], acc[s][cb]);
+                        acc[s][cb] = mfma32(a[s][1], b[s][1], acc[s][cb]);
+                        acc[s][cb] = mfma32(a[s][2], b[s][2], acc[s][cb]);
+                        acc[s][cb] = mfma32(a[s][3], b[s][3], acc[s][cb]);
+                        asm volatile("" : "+a"(acc[s][cb]));
+                    } else {
+                        mfma32x4_vgpr(acc[s][cb], make_float4(a[s][0], a[s][1], a[s][2], a[s][3]),
+                                      make_float4(b[s][0], b[s][1], b[s][2], b[s][3]));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            rot = rot + 4 >= 6 ? rot - 2 : rot + 4;
+            __syncthreads();                                                   // step k + 1's rows are in LDS
+        }
+    }
+
+    // ---- one slab per workgroup: [split][36 positions][Cin][Cout]
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        const int pos = wave * 9 + s;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mfma_row(r, lane);
+                slabs[(((size_t)split * 36 + pos) * Cin + c0 + m) * Cout + co0 + cb * 32 + li] = acc[s][cb][r];
+            }
+    }
+}
+
+// Slab sum + G^T . G: a workgroup owns 32 consecutive (ci, co) pairs; for each of the 36 positions it sums the slabs in the fixed
+// order of block_colsum32 (double), then its first 32 threads apply the filter transform (in double) and write dw in the reference
+// layout [Cout][Cin_real][3][3].  Position P = 9 w + s: s < 6: (xi = s, nu = nuF(w)); s >= 6: nu = nuH(w), xi = 0, 1, 2 (w even) or
+// 5, 3, 4 (w odd) -- the order of wino4.hip.
+__global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float *__restrict__ slabs, float *__restrict__ dw, int nslab,
+                                                                 int Cin, int Cin_real, int Cout) {
+    __shared__ double red[256];
+    const int pairs = Cin * Cout, total = 36 * pairs;
+    const int idx = blockIdx.x * 32 + (threadIdx.x & 31);        // over [Cin][Cout], co fastest
+    double d[6][6];
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv)
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            const int p = wv * 9 + s;
+            const int nu = s < 6 ? (wv == 0 ? 0 : wv == 1 ? 2 : wv == 2 ? 3 : 5) : (wv < 2 ? 1 : 4);
+            const int xi = s < 6 ? s : (wv & 1) ? (s == 6 ? 5 : s - 4) : s - 6;
+            d[xi][nu] = block_colsum32(slabs, nslab, (size_t)total, p * pairs + blockIdx.x * 32, p * pairs + pairs, red);
+        }
+    if ((threadIdx.x >> 5) != 0 || idx >= pairs) return;
+    const int co = idx % Cout, ci = idx / Cout;
+    if (ci >= Cin_real) return;
+    const double a_ = 0.75, b_ = 1.5, a2 = a_ * a_, b2 = b_ * b_;
+    const double na = 2.0 * a2 * (a2 - b2), nb = 2.0 * b2 * (b2 - a2);
+    const double G[6][3] = {{1.0 / (a2 * b2), 0.0, 0.0}, {1.0 / na, a_ / na, a2 / na}, {1.0 / na, -a_ / na, a2 / na},
+                            {1.0 / nb, b_ / nb, b2 / nb}, {1.0 / nb, -b_ / nb, b2 / nb}, {0.0, 0.0, 1.0}};
+    float *o = dw + ((size_t)co * Cin_real + ci) * 9;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            double s_ = 0.0;
+#pragma unroll
+            for (int xi = 0; xi < 6; ++xi) {
+                double r_ = 0.0;
+#pragma unroll
+                for (int nu = 0; nu < 6; ++nu) r_ += d[xi][nu] * G[nu][kx];
+                s_ += G[xi][ky] * r_;
+            }
+            o[ky * 3 + kx] = (float)s_;
+        }
+}
+
+// work split: items = (pair of runs, segment of tile rows); every workgroup (split) takes items split, split + nsplit, ...
+static int wino4_wgrad_geometry(int N, int H, int W, int Cin, int Cout, int *npairs_o, int *nseg_o, int *seg_steps_o, int *nitems_o,
+                                int *nblk_o) {
+    const int runsW = W / 16, npairs = (N * runsW + 1) / 2;
+    const int nblk = (Cout / 64) * (Cin / 32);
+    int nsplit = 256 / nblk;
+    if (nsplit < 1) nsplit = 1;
+    const int steps = H / 4;
+    // fewest segments per pair that give every split at least one item; segments of at least 8 tile rows
+    int nseg = (nsplit + npairs - 1) / npairs;
+    if (nseg < 1) nseg = 1;
+    int seg_steps = (steps + nseg - 1) / nseg;
+    if (seg_steps < 8) seg_steps = steps < 8 ? steps : 8;
+    nseg = (steps + seg_steps - 1) / seg_steps;
+    const int nitems = npairs * nseg;
+    if (nsplit > nitems) nsplit = nitems;
+    if (npairs_o) *npairs_o = npairs;
+    if (nseg_o) *nseg_o = nseg;
+    if (seg_steps_o) *seg_steps_o = seg_steps;
+    if (nitems_o) *nitems_o = nitems;
+    if (nblk_o) *nblk_o = nblk;
+    return nsplit;
+}
+
+}  // namespace w4
+}  // namespace adyolo
+
+using namespace adyolo;
+
+// > 0: the number of slabs the kernel writes for this shape; <= 0: shape not supported (use adyolo_wino_wgrad)
+extern "C" int adyolo_wino4_wgrad_slabs(int N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return ADYOLO_EINVAL;
+    if (Cin % 32 || Cout % 64 || W % 16 || H % 4 || H < 8) return 0;
+    if ((size_t)N * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 4 >= ((size_t)1 << 31)) return 0;       // 31-bit byte offsets
+    return w4::wino4_wgrad_geometry(N, H, W, Cin, Cout, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int adyolo_wino4_wgrad(const float *x, const float *dy, const float *in_scale, const float *in_shift, float *slabs,
+                                  float *dw, int N, int H, int W, int Cin, int Cin_real, int Cout, void *stream) {
+    ADYOLO_REQUIRE(x && dy && slabs && dw && N > 0 && H > 0 && W > 0, ADYOLO_EINVAL, "wino4_wgrad: bad arguments");
+    ADYOLO_REQUIRE(adyolo_wino4_wgrad_slabs(N, H, W, Cin, Cout) > 0 && Cin_real > 0 && Cin_real <= Cin, ADYOLO_ENOSUP,
+                   "wino4_wgrad: unsupported shape N=%d H=%d W=%d Cin=%d Cout=%d (needs Cin %% 32 == 0, Cout %% 64 == 0, W %% 16 == 0, "
+                   "H %% 4 == 0, tensors below 2 GiB)", N, H, W, Cin, Cout);
+    ADYOLO_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), ADYOLO_EINVAL, "wino4_wgrad: in_scale/in_shift come together");
+    hipStream_t st = as_stream(stream);
+    int npairs, nseg, seg_steps, nitems, nblk;
+    const int nsplit = w4::wino4_wgrad_geometry(N, H, W, Cin, Cout, &npairs, &nseg, &seg_steps, &nitems, &nblk);
+    const unsigned grid = (unsigned)(nsplit * nblk);
+    if (in_scale)
+        hipLaunchKernelGGL((w4::wino4_wgrad_kernel<true>), dim3(grid), dim3(256), 0, st, x, dy, in_scale, in_shift, slabs, N, H, W,
+                           Cin, Cout, W / 16, npairs, nseg, seg_steps, nitems, nsplit, Cin / 32, nblk);
+    else
+        hipLaunchKernelGGL((w4::wino4_wgrad_kernel<false>), dim3(grid), dim3(256), 0, st, x, dy, in_scale, in_shift, slabs, N, H, W,
+                           Cin, Cout, W / 16, npairs, nseg, seg_steps, nitems, nsplit, Cin / 32, nblk);
+    int rc = check_launch("wino4_wgrad");
+    if (rc) return rc;
+    hipLaunchKernelGGL(w4::wino4_wgrad_finish_kernel, dim3(cdiv(Cin * Cout, 32)), dim3(256), 0, st, slabs, dw, nsplit, Cin, Cin_real,
+                       Cout);
+    return check_launch("wino4_wgrad_finish");
+}

@@ -145,10 +145,12 @@ W4_THRESHOLDS = {}
 def reload_thresholds():
     """ADYOLO_W4_MIN_K (64): smallest contraction that gets the F(4x4) form packed; ADYOLO_W4_MIN_K_ADDEND (64; 128 until the
     persistent kernel of round 5): the same for launches that add a tensor in their epilogue; ADYOLO_W4_MIN_WGS (200): below
-    that many 64-channel x patch work items a launch stays on the F(2x2) kernel (two workgroups per CU)."""
+    that many 64-channel x patch work items a launch stays on the F(2x2) kernel (two workgroups per CU); ADYOLO_W4W_MIN_ROWS
+    (2048): fewest tile rows of 16-column runs (N * W / 16 * H / 4) for the F(4x4)-domain weight gradient (``wgrad_form``)."""
     W4_THRESHOLDS.update(min_k=int(os.environ.get("ADYOLO_W4_MIN_K", "64")),
                          min_k_addend=int(os.environ.get("ADYOLO_W4_MIN_K_ADDEND", "64")),
-                         min_wgs=int(os.environ.get("ADYOLO_W4_MIN_WGS", "200")))
+                         min_wgs=int(os.environ.get("ADYOLO_W4_MIN_WGS", "200")),
+                         min_wgrad_rows=int(os.environ.get("ADYOLO_W4W_MIN_ROWS", "2048")))
     return dict(W4_THRESHOLDS)
 
 
@@ -324,12 +326,20 @@ def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, 
     return (y, stats) if want_stats else y
 
 
-def wgrad_form(cin, cout, algo=None):
+def wgrad_form(cin, cout, algo=None, shape=None):
     """-> (kernel name, matrix FLOPs issued / direct-convolution FLOPs) of the weight-gradient ``conv3x3_wgrad`` launches for these
-    channel counts: the Winograd F(2x2,3x3) form (16 multiplies per 36) when both are multiples of 32, else the direct implicit
-    GEMM.  The ONE place that decides it -- bench.py reports the share from here."""
+    channel counts (and, with ``shape`` = (N, H, W), this launch): the Winograd F(4x4,3x3) domain (csrc/wino4w.hip, round 5: 9
+    multiplies per 36) under 'winograd4' when the kernel takes the shape (Cout % 64, W % 16, H % 4) and the launch has at least
+    ADYOLO_W4W_MIN_ROWS tile rows of 16-column runs (one workgroup per CU: small launches stay on the two-per-CU kernel); else
+    the F(2x2,3x3) domain (16 per 36) when both channel counts are multiples of 32; else the direct implicit GEMM.  The ONE
+    place that decides it -- ``conv3x3_wgrad`` and bench.py both ask here."""
     algo = algo or os.environ.get("ADYOLO_WGRAD_ALGO") or conv_algo()
-    if algo in ("winograd", "winograd4") and cin % 32 == 0 and cout % 32 == 0:      # (the weight gradient has the F(2x2) form only)
+    if algo == "winograd4" and shape is not None and cin % 32 == 0 and cout % 64 == 0:
+        n, h, w = shape
+        if w % 16 == 0 and h % 4 == 0 and n * (w // 16) * (h // 4) >= W4_THRESHOLDS["min_wgrad_rows"] and \
+                _lib.load().adyolo_wino4_wgrad_slabs(n, h, w, cin, cout) > 0:
+            return "wino4_wgrad_kernel", 9.0 / 36.0
+    if algo in ("winograd", "winograd4") and cin % 32 == 0 and cout % 32 == 0:
         return "wino_wgrad_kernel", 16.0 / 36.0
     return "conv3x3_wgrad_kernel", 1.0
 
@@ -343,7 +353,16 @@ def conv3x3_wgrad(x, dy, cin_real, in_affine=None, algo=None, out=None):
     cout = dy.shape[3]
     sc, sh = in_affine if in_affine is not None else (None, None)
     dw = out if out is not None else _new(x, cout, cin_real, 3, 3)      # out: e.g. the parameter's slice of the flat gradient buffer
-    if wgrad_form(cin, cout, algo)[0] == "wino_wgrad_kernel":
+    form = wgrad_form(cin, cout, algo, (n, h, w))[0]
+    if DISPATCH_LOG is not None:
+        k = (form, cin, cout, 1 if in_affine is not None else 0)
+        DISPATCH_LOG[k] = DISPATCH_LOG.get(k, 0) + 1
+    if form == "wino4_wgrad_kernel":
+        nslab = _lib.load().adyolo_wino4_wgrad_slabs(n, h, w, cin, cout)
+        slabs = _new(x, nslab, 36, cin, cout)
+        _c("adyolo_wino4_wgrad", _p(x), _p(dy), _p(sc), _p(sh), _p(slabs), _p(dw), n, h, w, cin, cin_real, cout, _stream())
+        return dw
+    if form == "wino_wgrad_kernel":
         nslab = _lib.load().adyolo_wino_wgrad_slabs(n, h, w, cin, cout)
         if nslab <= 0:
             raise _lib.AdyoloHipError("wino_wgrad_slabs rejected the shape")

@@ -536,7 +536,8 @@ def main():
 
     def wgrad_work(x, dy, cin_real, **kw):
         alg = 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * dy.shape[3] * 9 * x.shape[3]
-        return alg, alg * ops.wgrad_form(x.shape[3], dy.shape[3], kw.get("algo"))[1]
+        form, share = ops.wgrad_form(x.shape[3], dy.shape[3], kw.get("algo"), (x.shape[0], x.shape[1], x.shape[2]))
+        return alg, alg * share, form
     timer.wrap(ops, "conv3x3", "conv3x3_fwd_dgrad", conv_work)
     timer.wrap(ops, "conv3x3_wgrad", "conv3x3_wgrad", wgrad_work)
     feat_call = trainer.features.__call__
@@ -688,7 +689,7 @@ def main():
             by_name[name]["launches_per_step"] += cnt
             key = "%d->%d ops%d" % (cin, cout, epi)
             by_name[name]["by_shape"][key] = by_name[name]["by_shape"].get(key, 0) + cnt
-        dispatch = {"fwd_dgrad": by_name, "thresholds": dict(ops.W4_THRESHOLDS),
+        dispatch = {"conv3x3": by_name, "thresholds": dict(ops.W4_THRESHOLDS),
                     "env": {k: os.environ.get(k) for k in ("ADYOLO_LIB", "ADYOLO_CONV_ALGO", "ADYOLO_W4_PERSIST", "ADYOLO_W4_MIN_K",
                                                            "ADYOLO_W4_MIN_K_ADDEND", "ADYOLO_W4_MIN_WGS",
                                                            "ADYOLO_WGRAD_ALGO", "ADYOLO_GEMM_TILE")},
@@ -789,6 +790,12 @@ def main():
             by_kernel[tag] = {"launches": n_t, "avg_launch_ms": round(ms_t / max(1, n_t), 4), "share_of_step": round(ms_t / (dt * 1e3), 4),
                               "issued_tflops": round(ex_t / (ms_t * 1e-3) / 1e12, 2), "frac": round(ex_t / (ms_t * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                               "algorithmic_tflops": round(fl_t / (ms_t * 1e-3) / 1e12, 2)}
+        wg_kernels = {}
+        for tag in timer.tags("conv3x3_wgrad"):
+            n_t, ms_t, fl_t, ex_t = timer.summary("conv3x3_wgrad", tag)
+            wg_kernels[tag] = {"launches": n_t, "avg_launch_ms": round(ms_t / max(1, n_t), 4), "share_of_step": round(ms_t / (dt * 1e3), 4),
+                               "issued_tflops": round(ex_t / (ms_t * 1e-3) / 1e12, 2), "frac": round(ex_t / (ms_t * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                               "algorithmic_tflops": round(fl_t / (ms_t * 1e-3) / 1e12, 2)}
         dom = max(by_kernel, key=lambda k_: by_kernel[k_]["share_of_step"]) if by_kernel else None
         line = {
             "metric": "train-step audio-sec/s (4ch, %s+adyolo)" % args.encoder,
@@ -813,7 +820,7 @@ def main():
                 "conv3x3_fwd_dgrad": {"kernels": by_kernel, "launches": n_f, "avg_launch_ms": round(ms_f / max(1, n_f), 4),
                                       "mfma_issued_tflops": round(issued, 2), "frac_of_mfma_peak": round(issued / PEAK_FP32_MFMA_TFLOPS, 4),
                                       "algorithmic_tflops": round(algorithmic, 2), "share_of_step": round(ms_f / (dt * 1e3), 4)},
-                "conv3x3_wgrad": {"launches": n_w, "avg_launch_ms": round(ms_w / max(1, n_w), 4),
+                "conv3x3_wgrad": {"kernels": wg_kernels, "launches": n_w, "avg_launch_ms": round(ms_w / max(1, n_w), 4),
                                   "mfma_issued_tflops": round(ex_w / (ms_w * 1e-3) / 1e12, 2) if ms_w > 0 else 0.0,
                                   "frac_of_mfma_peak": round(ex_w / (ms_w * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if ms_w > 0 else 0.0,
                                   "algorithmic_tflops": round(fl_w / (ms_w * 1e-3) / 1e12, 2) if ms_w > 0 else 0.0,

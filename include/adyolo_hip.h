@@ -145,6 +145,17 @@ int adyolo_wino4_fwd(const float *x, const float *u, const float *bias, const fl
  *      one-patch-per-workgroup kernel otherwise or with ADYOLO_W4_PERSIST=0; same results within fp32 rounding.
  *      adyolo_wino4_last_form(): which one the last call launched (1 one-patch, 2 persistent, 0 none yet) -- for reporting. */
 int adyolo_wino4_last_form(void);
+/* K2w4w (round 5, csrc/wino4w.hip): the weight gradient in the Winograd F(4x4,3x3) domain,
+ *      dw = G^T [ sum over 4x4 output tiles (B^T d B) (.) (A e A^T) ] G  (36 multiplies per 16 outputs and channel pair: 9/36 of the
+ *      direct form's matrix FLOPs, 1.78x fewer MFMAs than adyolo_wino_wgrad; interpolation points of K2w4; error against a float64
+ *      weight gradient ~2e-6 of its absmax, tools/wino4w/numerics.py).  Same operator and argument meaning as adyolo_wino_wgrad
+ *      (nn.Conv2d backward-weights, src/models/backbones/resnet.py:16,18; x optionally seen through a per-channel affine with
+ *      zero padding).  Shapes: Cin % 32 == 0, Cout % 64 == 0, W % 16 == 0, H % 4 == 0, each tensor below 2 GiB --
+ *      adyolo_wino4_wgrad_slabs returns the number of [36][Cin][Cout] float32 slabs the launch needs, or 0 when the shape is
+ *      not supported (callers then use adyolo_wino_wgrad).  dw: reference layout [Cout][Cin_real][3][3]. */
+int adyolo_wino4_wgrad_slabs(int N, int H, int W, int Cin, int Cout);
+int adyolo_wino4_wgrad(const float *x, const float *dy, const float *in_scale /*or NULL*/, const float *in_shift /*or NULL*/,
+                       float *slabs, float *dw, int N, int H, int W, int Cin, int Cin_real, int Cout, void *stream);
 /* Winograd weight-gradient: dw = G^T [ sum_tiles (B^T d B)(.)(A e A^T) ] G.  slabs: [n_slabs][16][Cin][Cout] float32 with
  * n_slabs = adyolo_wino_wgrad_slabs(...); du: [16][Cin][Cout] scratch; dw: reference layout [Cout][Cin_real][3][3]. */
 int adyolo_wino_wgrad_slabs(int N, int H, int W, int Cin, int Cout);

@@ -487,7 +487,7 @@ def test_dispatch_table_at_the_bench_shape(ops):
     from adyolo_amd.features import FeatureExtractor
     from adyolo_amd.datasets import synthetic_audio, synthetic_targets
     from adyolo_amd.train import TrainStep
-    assert ops.reload_thresholds() == {"min_k": 64, "min_k_addend": 64, "min_wgs": 200}
+    assert ops.reload_thresholds() == {"min_k": 64, "min_k_addend": 64, "min_wgs": 200, "min_wgrad_rows": 2048}
     assert ops.conv_algo() == "winograd4" and os.environ.get("ADYOLO_W4_PERSIST", "1") != "0"
     b, n = 12, 24000 * 60
     torch.manual_seed(100)
@@ -504,10 +504,14 @@ def test_dispatch_table_at_the_bench_shape(ops):
     finally:
         log, ops.DISPATCH_LOG = ops.DISPATCH_LOG, None
     assert np.isfinite(loss)
-    per_kernel = {}
-    for (name, cin, cout, epi), cnt in log.items():
-        per_kernel[name] = per_kernel.get(name, 0) + cnt
-    print(sorted(log.items()))
+    per_kernel, per_wgrad = {}, {}
+    for (name, cin, cout, epi), cnt in list(log.items()):
+        if "wgrad" in name:                        # the weight-gradient launches are logged beside the forward / data-gradient ones
+            per_wgrad[name] = per_wgrad.get(name, 0) + cnt
+            del log[(name, cin, cout, epi)]
+        else:
+            per_kernel[name] = per_kernel.get(name, 0) + cnt
+    print(sorted(log.items()), per_wgrad)
     assert per_kernel == {"wino4p_fwd_kernel": 50, "wino_fwd_kernel": 14, "conv3x3_fwd_kernel": 1}, per_kernel
     # the F(2x2) launches are exactly the ones with a 32-channel side, the direct one is the stem
     assert all(min(cin, cout) == 32 for (name, cin, cout, _), _ in log.items() if name == "wino_fwd_kernel")
