@@ -30,6 +30,12 @@ namespace w4 {
 #ifndef W4W_WHATIF
 #define W4W_WHATIF 0
 #endif
+#ifndef W4W_ORDER
+#define W4W_ORDER 0       // experiment switch: where the dy operands are read (0: right before their transforms; 1: block 0 before the
+                          // mid-step barrier, block 1 before its transforms; 2: block 0 before the barrier, block 1 under block 0's MFMAs).
+                          // Same-session A/B at B = 64 (profiles/r05_w4w_order_ab.txt): 0 is 9-10 % faster than 1 and 2 without the
+                          // affine and 1-2 % with it -- reads ahead of the barrier lengthen what every wave waits for there
+#endif
 
 // A (6 x 4) along one direction on the four tiles of a run: t = A v
 __device__ __forceinline__ void a6v(const f32x4 (&v)[4], f32x4 (&t)[6]) {
@@ -154,18 +160,24 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
             xpx[17] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vR, 0, 0));
         };
         auto x_store = [&](int gy, int slot) {
-            if (AFF) {
-                // x' = scale x + shift inside the image, 0 outside (the loads returned 0 there)
-                const bool rowok = qok && gy >= 0 && gy < H;
-                const float sh = rowok ? xsh : 0.f;
-                xpx[0] = fmaf(xpx[0], xsc, edgeL ? 0.f : sh);
-#pragma unroll
-                for (int k = 1; k < 17; ++k) xpx[k] = fmaf(xpx[k], xsc, sh);
-                xpx[17] = fmaf(xpx[17], xsc, edgeR ? 0.f : sh);
-            }
             f32x4 c[6], t0_, t1_, t2_, t3_, t4_, t5_;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) c[i] = f32x4{xpx[i], xpx[4 + i], xpx[8 + i], xpx[12 + i]};
+            for (int i = 0; i < 6; ++i) c[i] = f32x4{xpx[i], xpx[4 + i], xpx[8 + i], xpx[12 + i]};     // pixel i of the run's four tiles
+            if (AFF) {
+                // x' = scale x + shift inside the image, 0 outside (the loads returned 0 there): only column -1 (pixel 0 of tile 0)
+                // and column 16 (pixel 5 of tile 3) of the run can leave the image sideways
+                const bool rowok = qok && gy >= 0 && gy < H;
+                const float sh = rowok ? xsh : 0.f;
+                const f32x4 shv = {sh, sh, sh, sh};
+                f32x4 sh0 = shv, sh5 = shv;
+                sh0[0] = edgeL ? 0.f : sh;
+                sh5[3] = edgeR ? 0.f : sh;
+                const f32x4 scv = {xsc, xsc, xsc, xsc};                      // (per lane: the lane's channel)
+                c[0] = pkfma4v(c[0], scv, sh0);
+#pragma unroll
+                for (int i = 1; i < 5; ++i) c[i] = pkfma4v(c[i], scv, shv);
+                c[5] = pkfma4v(c[5], scv, sh5);
+            }
             bt6v2(c, t0_, t1_, t2_, t3_, t4_, t5_);
             char *dst = ldsb + slot * XROWB + wxl;
             *reinterpret_cast<f32x4 *>(dst + 0 * XNU) = t0_;
@@ -216,8 +228,41 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
         int rot = 0;                                                           // slot of window row 0 of the current step
         for (int k = 0; k < nsteps; ++k) {
             const int buf = k & 1;
-            // ---- the wave's operands of the step.  x: rows of the window for its two columns
-            f32x4 a[9];
+            // ---- the wave's operands of the step.  x: rows of the window for its two columns; dy: the rows of its columns, first
+            // 32-channel block (the second block's are requested under the first block's MFMAs)
+            f32x4 a[9], b[9];
+            f32x4 vF[4], vH[4], zH;
+            auto d_reads = [&](int cb) {
+                const char *dp = ldsb + XBYTES + buf * DBUF + cb * 1024 + lx;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vF[i] = *reinterpret_cast<const f32x4 *>(dp + nuF * DNU + i * DROWB);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vH[i] = *reinterpret_cast<const f32x4 *>(dp + nuH * DNU + i * DROWB);
+                zH = *reinterpret_cast<const f32x4 *>(dp + nuH * DNU + (hh ? 3 : 0) * DROWB);
+            };
+            auto d_xform = [&]() {
+                f32x4 t[6];
+                a6v(vF, t);
+#pragma unroll
+                for (int s = 0; s < 6; ++s) b[s] = t[s];
+                a3v(vH, zH, b[6], b[7], b[8], K1d, K2d, K3d);
+            };
+            auto mfmas = [&](int cb) {
+#pragma unroll
+                for (int s = 0; s < 9; ++s) {
+                    if (W4W_WHATIF & 1) continue;
+                    if (s < 8) {
+                        acc[s][cb] = mfma32(a[s][0], b[s][0], acc[s][cb]);
+                        acc[s][cb] = mfma32(a[s][1], b[s][1], acc[s][cb]);
+                        acc[s][cb] = mfma32(a[s][2], b[s][2], acc[s][cb]);
+                        acc[s][cb] = mfma32(a[s][3], b[s][3], acc[s][cb]);
+                        asm volatile("" : "+a"(acc[s][cb]));
+                    } else {
+                        mfma32x4_vgpr(acc[s][cb], make_float4(a[s][0], a[s][1], a[s][2], a[s][3]),
+                                      make_float4(b[s][0], b[s][1], b[s][2], b[s][3]));
+                    }
+                }
+            };
             {
                 int so[6];
 #pragma unroll
@@ -236,6 +281,7 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
                 cZ[0] = *reinterpret_cast<const f32x4 *>(xp + nuH * XNU + (hh ? so[1] : so[0]));
                 cZ[1] = *reinterpret_cast<const f32x4 *>(xp + nuH * XNU + (hh ? so[3] : so[2]));
                 cZ[2] = *reinterpret_cast<const f32x4 *>(xp + nuH * XNU + (hh ? so[5] : so[4]));
+                if (W4W_ORDER >= 1) d_reads(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();                                               // every wave has read the window: its four oldest rows are free
                 // ---- staging of step k + 1 (loads requested one step ago): x rows -> the slots the window just retired
@@ -252,40 +298,18 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
                 bt6v2(cF, a[0], a[1], a[2], a[3], a[4], a[5]);
                 bt3v(cP, cZ, a[6], a[7], a[8], K2x, KPx);
             }
-            // ---- dy operands and the MFMAs, one 32-channel block of the 64 at a time
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const char *dp = ldsb + XBYTES + buf * DBUF + cb * 1024 + lx;
-                f32x4 vF[4], vH[4], zH, b[9];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) vF[i] = *reinterpret_cast<const f32x4 *>(dp + nuF * DNU + i * DROWB);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) vH[i] = *reinterpret_cast<const f32x4 *>(dp + nuH * DNU + i * DROWB);
-                zH = *reinterpret_cast<const f32x4 *>(dp + nuH * DNU + (hh ? 3 : 0) * DROWB);
-                {
-                    f32x4 t[6];
-                    a6v(vF, t);
-#pragma unroll
-                    for (int s = 0; s < 6; ++s) b[s] = t[s];
-                }
-                a3v(vH, zH, b[6], b[7], b[8], K1d, K2d, K3d);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int s = 0; s < 9; ++s) {
-                    if (W4W_WHATIF & 1) continue;
-                    if (s < 8) {
-                        acc[s][cb] = mfma32(a[s][0], b[s][0], acc[s][cb]);
-                        acc[s][cb] = mfma32(a[s][1], b[s][1], acc[s][cb]);
-                        acc[s][cb] = mfma32(a[s][2], b[s][2], acc[s][cb]);
-                        acc[s][cb] = mfma32(a[s][3], b[s][3], acc[s][cb]);
-                        asm volatile("" : "+a"(acc[s][cb]));
-                    } else {
-                        mfma32x4_vgpr(acc[s][cb], make_float4(a[s][0], a[s][1], a[s][2], a[s][3]),
-                                      make_float4(b[s][0], b[s][1], b[s][2], b[s][3]));
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            if (W4W_ORDER == 0) d_reads(0);
+            d_xform();
+            __builtin_amdgcn_sched_barrier(0);
+            if (W4W_ORDER == 2) d_reads(1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (W4W_ORDER != 2) d_reads(1);
+            d_xform();
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(1);
+            __builtin_amdgcn_sched_barrier(0);
             rot = rot + 4 >= 6 ? rot - 2 : rot + 4;
             __syncthreads();                                                   // step k + 1's rows are in LDS
         }
