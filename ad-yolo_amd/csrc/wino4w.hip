@@ -65,15 +65,20 @@ constexpr int XROWB = 1024;                 // bytes of an x row slot: 32 channe
 constexpr int XSLOTS = 6;
 constexpr int XNU = XSLOTS * XROWB;         // per nu plane
 constexpr int XBYTES = 6 * XNU;             // 36 864
-constexpr int DROWB = 2048;                 // 64 channels x 8 tiles
-constexpr int DNU = 4 * DROWB;
-constexpr int DBUF = 6 * DNU;               // 49 152
+// dy rows: 32 NB channels x 8 tiles; NB = 2 (Cout % 64 == 0) or 1 (32-channel blocks: stage 1 -- half the MFMAs per staged byte)
+template <int NB>
+struct DCfg {
+    static constexpr int DROWB = 1024 * NB;
+    static constexpr int DNU = 4 * DROWB;
+    static constexpr int DBUF = 6 * DNU;    // 49 152 | 24 576
+};
 
-template <bool AFF>
+template <bool AFF, int NB>
 __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
     const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ in_scale,
     const float *__restrict__ in_shift, float *__restrict__ slabs, int N, int H, int W, int Cin, int Cout, int runsW, int npairs,
     int nseg, int seg_steps, int nitems, int nsplit, int ciBlocks, int nblk) {
+    constexpr int DROWB = DCfg<NB>::DROWB, DNU = DCfg<NB>::DNU, DBUF = DCfg<NB>::DBUF;
     __shared__ __attribute__((aligned(16))) float lds[(XBYTES + 2 * DBUF) / 4];
     char *ldsb = reinterpret_cast<char *>(lds);
 
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
     }
     if (split >= nsplit) return;
     const int cbk = blk / ciBlocks, ibk = blk - cbk * ciBlocks;
-    const int co0 = cbk * 64, c0 = ibk * 32;
+    const int co0 = cbk * (32 * NB), c0 = ibk * 32;
 
     // ---- GEMM side: positions of the wave (wino4.hip): full column nuF (xi = 0..5 -> acc 0..5), half column nuH (acc 6..8 =
     // xi 0, 1, 2 for hh = 0, xi 5, 3, 4 for hh = 1)
@@ -105,11 +110,11 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
     const int lsw = (lh ^ ((li >> 3) & 1)) << 4;                              // tile quad of the lane's half, swizzled
     const int lx = li * 32 + lsw;                                             // lane part of an x read / a dy read inside a 32-channel block
 
-    f32x16 acc[9][2];
+    f32x16 acc[9][NB];
 #pragma unroll
     for (int s = 0; s < 9; ++s)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < NB; ++cb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[s][cb][r] = 0.f;
 
@@ -117,7 +122,9 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
     // x: channel sxc, new row (wave >> 1) * 2 + lh of the step's four, run wave & 1.   dy: channel sdc (64), rows (wave >> 1) * 2 + {0, 1}
     const int run = wave & 1;
     const int sxc = li, sxr = (wave >> 1) * 2 + lh;
-    const int sdc = lane, sdr = (wave >> 1) * 2;
+    // (NB = 1: 32 dy channels, ONE row per thread: row (wave >> 1) * 2 + lh)
+    constexpr int DP = NB == 2 ? 2 : 1;                                       // dy rows per thread
+    const int sdc = NB == 2 ? lane : li, sdr = (wave >> 1) * 2 + (NB == 2 ? 0 : lh);
     float xsc = 1.f, xsh = 0.f;
     if (AFF) {
         xsc = in_scale[c0 + sxc];
@@ -187,10 +194,10 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
             *reinterpret_cast<f32x4 *>(dst + 4 * XNU) = t4_;
             *reinterpret_cast<f32x4 *>(dst + 5 * XNU) = t5_;
         };
-        float dpx[2][16];
+        float dpx[DP][16];
         auto d_load = [&](int trow) {                                          // dy rows 4 trow + sdr, + 1 (always inside the image)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < DP; ++p) {
                 const int vrow = qok ? (int)(dbase + (unsigned)(4 * trow + sdr + p) * (unsigned)drowb) : (int)0x80000000;
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
         };
         auto d_store = [&](int buf) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < DP; ++p) {
                 f32x4 v[4], t[6];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = f32x4{dpx[p][i], dpx[p][4 + i], dpx[p][8 + i], dpx[p][12 + i]};
@@ -281,9 +288,11 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
                 cZ[0] = *reinterpret_cast<const f32x4 *>(xp + nuH * XNU + (hh ? so[1] : so[0]));
                 cZ[1] = *reinterpret_cast<const f32x4 *>(xp + nuH * XNU + (hh ? so[3] : so[2]));
                 cZ[2] = *reinterpret_cast<const f32x4 *>(xp + nuH * XNU + (hh ? so[5] : so[4]));
-                if (W4W_ORDER >= 1) d_reads(0);
+                if (W4W_ORDER == 1 || W4W_ORDER == 2) d_reads(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();                                               // every wave has read the window: its four oldest rows are free
+                if (W4W_ORDER >= 3) d_reads(0);                                // (their latency hides under the staging work)
+                __builtin_amdgcn_sched_barrier(0);
                 // ---- staging of step k + 1 (loads requested one step ago): x rows -> the slots the window just retired
                 {
                     int sl = rot + sxr;                                        // window row sxr of step k = slot of new row 2 + sxr of step k + 1
@@ -301,15 +310,17 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
             if (W4W_ORDER == 0) d_reads(0);
             d_xform();
             __builtin_amdgcn_sched_barrier(0);
-            if (W4W_ORDER == 2) d_reads(1);
+            if (NB == 2 && (W4W_ORDER == 2 || W4W_ORDER == 4)) d_reads(1);
             __builtin_amdgcn_sched_barrier(0);
             mfmas(0);
             __builtin_amdgcn_sched_barrier(0);
-            if (W4W_ORDER != 2) d_reads(1);
-            d_xform();
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas(1);
-            __builtin_amdgcn_sched_barrier(0);
+            if (NB == 2) {
+                if (W4W_ORDER != 2 && W4W_ORDER != 4) d_reads(1);
+                d_xform();
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             rot = rot + 4 >= 6 ? rot - 2 : rot + 4;
             __syncthreads();                                                   // step k + 1's rows are in LDS
         }
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
     for (int s = 0; s < 9; ++s) {
         const int pos = wave * 9 + s;
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < NB; ++cb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mfma_row(r, lane);
@@ -376,7 +387,7 @@ __global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float *__
 static int wino4_wgrad_geometry(int N, int H, int W, int Cin, int Cout, int *npairs_o, int *nseg_o, int *seg_steps_o, int *nitems_o,
                                 int *nblk_o) {
     const int runsW = W / 16, npairs = (N * runsW + 1) / 2;
-    const int nblk = (Cout / 64) * (Cin / 32);
+    const int nblk = (Cout / (Cout % 64 == 0 ? 64 : 32)) * (Cin / 32);
     int nsplit = 256 / nblk;
     if (nsplit < 1) nsplit = 1;
     const int steps = H / 4;
@@ -404,7 +415,7 @@ using namespace adyolo;
 // > 0: the number of slabs the kernel writes for this shape; <= 0: shape not supported (use adyolo_wino_wgrad)
 extern "C" int adyolo_wino4_wgrad_slabs(int N, int H, int W, int Cin, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return ADYOLO_EINVAL;
-    if (Cin % 32 || Cout % 64 || W % 16 || H % 4 || H < 8) return 0;
+    if (Cin % 32 || Cout % 32 || W % 16 || H % 4 || H < 8) return 0;
     if ((size_t)N * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 4 >= ((size_t)1 << 31)) return 0;       // 31-bit byte offsets
     return w4::wino4_wgrad_geometry(N, H, W, Cin, Cout, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
@@ -413,19 +424,22 @@ extern "C" int adyolo_wino4_wgrad(const float *x, const float *dy, const float *
                                   float *dw, int N, int H, int W, int Cin, int Cin_real, int Cout, void *stream) {
     ADYOLO_REQUIRE(x && dy && slabs && dw && N > 0 && H > 0 && W > 0, ADYOLO_EINVAL, "wino4_wgrad: bad arguments");
     ADYOLO_REQUIRE(adyolo_wino4_wgrad_slabs(N, H, W, Cin, Cout) > 0 && Cin_real > 0 && Cin_real <= Cin, ADYOLO_ENOSUP,
-                   "wino4_wgrad: unsupported shape N=%d H=%d W=%d Cin=%d Cout=%d (needs Cin %% 32 == 0, Cout %% 64 == 0, W %% 16 == 0, "
+                   "wino4_wgrad: unsupported shape N=%d H=%d W=%d Cin=%d Cout=%d (needs Cin %% 32 == 0, Cout %% 32 == 0, W %% 16 == 0, "
                    "H %% 4 == 0, tensors below 2 GiB)", N, H, W, Cin, Cout);
     ADYOLO_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), ADYOLO_EINVAL, "wino4_wgrad: in_scale/in_shift come together");
     hipStream_t st = as_stream(stream);
     int npairs, nseg, seg_steps, nitems, nblk;
     const int nsplit = w4::wino4_wgrad_geometry(N, H, W, Cin, Cout, &npairs, &nseg, &seg_steps, &nitems, &nblk);
     const unsigned grid = (unsigned)(nsplit * nblk);
-    if (in_scale)
-        hipLaunchKernelGGL((w4::wino4_wgrad_kernel<true>), dim3(grid), dim3(256), 0, st, x, dy, in_scale, in_shift, slabs, N, H, W,
-                           Cin, Cout, W / 16, npairs, nseg, seg_steps, nitems, nsplit, Cin / 32, nblk);
-    else
-        hipLaunchKernelGGL((w4::wino4_wgrad_kernel<false>), dim3(grid), dim3(256), 0, st, x, dy, in_scale, in_shift, slabs, N, H, W,
-                           Cin, Cout, W / 16, npairs, nseg, seg_steps, nitems, nsplit, Cin / 32, nblk);
+#define ADYOLO_W4W(AFF_, NB_)                                                                                          \
+    hipLaunchKernelGGL((w4::wino4_wgrad_kernel<AFF_, NB_>), dim3(grid), dim3(256), 0, st, x, dy, in_scale, in_shift, slabs, N, H, \
+                       W, Cin, Cout, W / 16, npairs, nseg, seg_steps, nitems, nsplit, Cin / 32, nblk)
+    if (Cout % 64 == 0) {
+        if (in_scale) ADYOLO_W4W(true, 2); else ADYOLO_W4W(false, 2);
+    } else {
+        if (in_scale) ADYOLO_W4W(true, 1); else ADYOLO_W4W(false, 1);
+    }
+#undef ADYOLO_W4W
     int rc = check_launch("wino4_wgrad");
     if (rc) return rc;
     hipLaunchKernelGGL(w4::wino4_wgrad_finish_kernel, dim3(cdiv(Cin * Cout, 32)), dim3(256), 0, st, slabs, dw, nsplit, Cin, Cin_real,

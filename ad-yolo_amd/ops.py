@@ -334,7 +334,7 @@ def wgrad_form(cin, cout, algo=None, shape=None):
     the F(2x2,3x3) domain (16 per 36) when both channel counts are multiples of 32; else the direct implicit GEMM.  The ONE
     place that decides it -- ``conv3x3_wgrad`` and bench.py both ask here."""
     algo = algo or os.environ.get("ADYOLO_WGRAD_ALGO") or conv_algo()
-    if algo == "winograd4" and shape is not None and cin % 32 == 0 and cout % 64 == 0:
+    if algo == "winograd4" and shape is not None and cin % 32 == 0 and cout % 32 == 0:
         n, h, w = shape
         if w % 16 == 0 and h % 4 == 0 and n * (w // 16) * (h // 4) >= W4_THRESHOLDS["min_wgrad_rows"] and \
                 _lib.load().adyolo_wino4_wgrad_slabs(n, h, w, cin, cout) > 0:

@@ -150,7 +150,7 @@ int adyolo_wino4_last_form(void);
  *      direct form's matrix FLOPs, 1.78x fewer MFMAs than adyolo_wino_wgrad; interpolation points of K2w4; error against a float64
  *      weight gradient ~2e-6 of its absmax, tools/wino4w/numerics.py).  Same operator and argument meaning as adyolo_wino_wgrad
  *      (nn.Conv2d backward-weights, src/models/backbones/resnet.py:16,18; x optionally seen through a per-channel affine with
- *      zero padding).  Shapes: Cin % 32 == 0, Cout % 64 == 0, W % 16 == 0, H % 4 == 0, each tensor below 2 GiB --
+ *      zero padding).  Shapes: Cin % 32 == 0, Cout % 32 == 0, W % 16 == 0, H % 4 == 0, each tensor below 2 GiB --
  *      adyolo_wino4_wgrad_slabs returns the number of [36][Cin][Cout] float32 slabs the launch needs, or 0 when the shape is
  *      not supported (callers then use adyolo_wino_wgrad).  dw: reference layout [Cout][Cin_real][3][3]. */
 int adyolo_wino4_wgrad_slabs(int N, int H, int W, int Cin, int Cout);

@@ -48,7 +48,7 @@ def check(n, h, w, cin, cout, affine):
     return ok
 
 
-SHAPES = {2: (1200, 32, 64, 64), 3: (600, 16, 128, 128), 4: (600, 16, 256, 256), 12: (1200, 32, 32, 64), 23: (600, 16, 64, 128),
+SHAPES = {1: (2400, 64, 32, 32), 2: (1200, 32, 64, 64), 3: (600, 16, 128, 128), 4: (600, 16, 256, 256), 12: (1200, 32, 32, 64), 23: (600, 16, 64, 128),
           34: (600, 16, 128, 256)}
 
 
@@ -85,14 +85,14 @@ def main():
     ap.add_argument("--skip-bench", action="store_true")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--stages", default="2,3,4,12,23,34")
+    ap.add_argument("--stages", default="1,2,3,4,12,23,34")
     a = ap.parse_args()
     if not a.skip_check:
         ok = True
         # (N, H, W, Cin, Cout, affine): both widths, odd run counts (a half-empty pair), several segments per pair, 1 ... 32 channel blocks
         for shp in [(2, 8, 16, 32, 64, 0), (1, 8, 16, 32, 64, 1), (3, 40, 16, 64, 64, 1), (2, 64, 32, 32, 64, 0), (5, 36, 32, 64, 128, 1),
                     (1, 100, 48, 32, 64, 1), (2, 24, 64, 64, 64, 0), (9, 600, 16, 128, 128, 1), (4, 300, 32, 64, 64, 1),
-                    (8, 152, 16, 256, 256, 0), (3, 28, 16, 96, 192, 1)]:
+                    (8, 152, 16, 256, 256, 0), (3, 28, 16, 96, 192, 1), (2, 64, 64, 32, 32, 1), (3, 20, 48, 64, 32, 0), (1, 12, 16, 32, 96, 1)]:
             ok = check(*shp) and ok
         print("CHECK %s" % ("OK" if ok else "FAIL"), flush=True)
     if not a.skip_bench:
