@@ -695,8 +695,9 @@ extern "C" int adyolo_wino4_fwd(const float *x, const float *u, const float *bia
     ADYOLO_REQUIRE(x && u && y && N > 0 && H > 0 && W > 0, ADYOLO_EINVAL, "wino4_fwd: bad arguments");
     ADYOLO_REQUIRE(!(mask_bits & ~3) && (!mask_bits || ((long)H * W * (Cout / 4)) % 64 == 0), ADYOLO_ENOSUP,
                    "wino4_fwd: mask bits need H*W*Cout/4 %% 64 == 0");
-    ADYOLO_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0 && Cin > 0 && Cout > 0 && Cin <= WMAXC, ADYOLO_ENOSUP,
-                   "wino4_fwd: Cin=%d (<= 512) must be a multiple of 32 and Cout=%d of 64", Cin, Cout);
+    ADYOLO_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0 && Cin > 0 && Cout > 0 && Cin <= WMAXC, ADYOLO_ENOSUP,
+                   "wino4_fwd: Cin=%d (<= 512) and Cout=%d must be multiples of 32", Cin, Cout);
+    const int nb = Cout % 64 == 0 ? 2 : 1;             // 32-channel output blocks per workgroup (1: persistent kernel only)
     // (31-bit byte offsets inside a sample's buffer descriptors, input and output side; 24-bit pixel indices: __mul24)
     ADYOLO_REQUIRE((size_t)(H + 2) * W * Cin * 4 < ((size_t)1 << 31) && (size_t)H * W * Cout * 4 < ((size_t)1 << 31) &&
                        (long)H * W < (1L << 23),
@@ -709,7 +710,7 @@ extern "C" int adyolo_wino4_fwd(const float *x, const float *u, const float *bia
     const int tc = wino4_tc(W), tr = 32 / tc;
     const int patchesW = cdiv(W, 4 * tc), patchesH = cdiv(H, 4 * tr);
     const int nsp = N * patchesH * patchesW;
-    const int ncb = Cout / 64;
+    const int ncb = Cout / (32 * nb);
     int xcd_div = 0, blocks = nsp * ncb;
     if (ncb <= 8 && 8 % ncb == 0) {
         xcd_div = 8 / ncb;
@@ -734,7 +735,7 @@ extern "C" int adyolo_wino4_fwd(const float *x, const float *u, const float *bia
         const int njs = cdiv(nsp, xcd_div);
         const int slots = njs < ncus / 8 ? njs : ncus / 8;
         w4::W4Launch a = {x, u, bias, addend, addend_mask, in_scale, in_shift, y, stats, stat_aux, stat_mean, stat_invstd, stat_mask,
-                          H, W, Cin, Cout, patchesW, patchesH, nsp, ncb, xcd_div, relu, mask_bits, tc, slots * 8, st};
+                          H, W, Cin, Cout, patchesW, patchesH, nsp, ncb, xcd_div, relu, mask_bits, tc, slots * 8, nb, st};
         g_wino4_last_form = 2;
         switch (epi) {
             case 0: w4::launch_wino4p<0>(a); break;
@@ -746,6 +747,9 @@ extern "C" int adyolo_wino4_fwd(const float *x, const float *u, const float *bia
         }
         return check_launch("wino4_fwd (persistent)");
     }
+    ADYOLO_REQUIRE(nb == 2, ADYOLO_ENOSUP,
+                   "wino4_fwd: Cout=%d (a multiple of 32 but not of 64) needs the persistent kernel: no bias, masks as bits, Cout / 32 in "
+                   "{1, 2, 4, 8}, operand combination %d not built", Cout, epi);
     g_wino4_last_form = 1;
 #define ADYOLO_WINO4_FWD(TC_, AFF_)                                                                                    \
     hipLaunchKernelGGL((w4::wino4_fwd_kernel<TC_, AFF_>), dim3((unsigned)blocks), dim3(256), 0, st, x, u, bias, addend,    \

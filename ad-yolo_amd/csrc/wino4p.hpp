@@ -41,7 +41,9 @@ struct CfgP {
     static constexpr int LDS_FLOATS = (XOFF + XCH > 4 * C::CBUF) ? XOFF + XCH : 4 * C::CBUF;
 };
 
-template <int TC, bool AFF, int EPI>
+// NB: 32-channel output blocks per workgroup -- 2 (Cout % 64 == 0) or 1 (32-channel layers: half the MFMAs per A fragment and per
+// staged pixel, two epilogue rounds; no one-patch counterpart)
+template <int TC, bool AFF, int EPI, int NB>
 __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
     const float *__restrict__ x, const float *__restrict__ u, const float *__restrict__ bias,
     const float *__restrict__ addend, const float *__restrict__ addend_mask, const float *__restrict__ in_scale,
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
     const int spstep = (int)(gridDim.x >> 3) * xcd_div;
     int sp = slot * xcd_div + xcd / ncb;
     if (sp >= nsp) return;
-    const int co0 = cb * 64;
+    const int co0 = cb * (32 * NB);
     auto decode = [&](int sp_, int &n_, int &ty_, int &tx_) {
         int t = sp_;
         const int pw = t % patchesW;
@@ -197,17 +199,19 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(u), 0, (int)(36 * ustride_pos * 4), 0x00020000);
     const int ulane = lane * 16;
-    const int uwave = (int)((((size_t)(wave * 9) * (Cout / 32) + (size_t)cb * 2) * nkg * 256) * 4);
+    const int uwave = (int)((((size_t)(wave * 9) * (Cout / 32) + (size_t)cb * NB) * nkg * 256) * 4);
+    // B fragment of use u of a pair (18 NB uses: u = (9 half + s) NB + nt) -- fragment (s, nt) of group 2 pr + half
     auto bload = [&](int uu, int kg) {
-        const int s = uu >> 1, nt = uu & 1;
+        const int s = uu / NB, nt = uu % NB;
         const int so = uwave + (int)((s * ustride_pos + ((size_t)nt * nkg + kg) * 256) * 4);
         const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, ulane, so, 0));
         return make_float4(v[0], v[1], v[2], v[3]);
     };
     constexpr int BR = W4_BRING;
+    constexpr int UH = 9 * NB;                            // uses per 8-channel group
     float4 bq[BR];
 #pragma unroll
-    for (int uu = 0; uu < BR; ++uu) bq[uu] = bload(uu % 18, (uu / 18) % nkg);
+    for (int uu = 0; uu < BR; ++uu) bq[uu] = bload(uu % UH, (uu / UH) % nkg);
 
     int n, ty0, tx0;
     decode(sp, n, ty0, tx0);
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
     set_off(offL, true, ty0, tx0, W);
     xbF = xbL = x + (size_t)n * xsample;
 
-    f32x16 acc[9][2];
+    f32x16 acc[9][NB];
     f32x4 pvA[6], pvB[6];
     __syncthreads();                                      // affine table visible
     // pair 0 of the first patch: all staging rounds in flight together (the accumulators are zeroed while they are)
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
 #pragma unroll
     for (int s = 0; s < 9; ++s)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NB; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[s][nt][r] = 0.f;
     st_store(pvA, 0, lds, 0);
@@ -297,8 +301,10 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
             for (int s = 0; s < 9; ++s) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    const int step = half * 18 + 2 * s + nt;
-                    const int slot_ = step % BR;
+                    const int step = half * 18 + 2 * s + nt;                   // (the 36 steps of the schedule, whatever NB: with NB = 1
+                    const bool live = nt < NB;                                 //  the odd ones carry side work and loads only)
+                    const int use = (half * 9 + s) * NB + (live ? nt : 0);
+                    const int slot_ = use % BR;
                     // ---- side work of the step
                     if (step == 2) a_xform_half();
                     if (step == 12) a_xform_full();
@@ -319,25 +325,27 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                         set_off(offL, true, nty, ntx, Wn);
                         xbL = x + (size_t)nn * xsample;
                     }
-                    if (W4P_WHATIF & 16) {
+                    if (!live) {
+                    } else if (W4P_WHATIF & 16) {
                         asm volatile("" : "+v"(a[s]));
                         asm volatile("" : "+v"(bq[slot_].x), "+v"(bq[slot_].y), "+v"(bq[slot_].z), "+v"(bq[slot_].w));
-                    } else if (s < 8) {
+                    } else if (s < 8 || NB == 1) {
+                        const int an = live ? nt : 0;
                         asm volatile("" : "+v"(a[s]));
-                        acc[s][nt] = mfma32(a[s][0], bq[slot_].x, acc[s][nt]);
-                        acc[s][nt] = mfma32(a[s][1], bq[slot_].y, acc[s][nt]);
-                        acc[s][nt] = mfma32(a[s][2], bq[slot_].z, acc[s][nt]);
-                        acc[s][nt] = mfma32(a[s][3], bq[slot_].w, acc[s][nt]);
-                        asm volatile("" : "+a"(acc[s][nt]));
+                        acc[s][an] = mfma32(a[s][0], bq[slot_].x, acc[s][an]);
+                        acc[s][an] = mfma32(a[s][1], bq[slot_].y, acc[s][an]);
+                        acc[s][an] = mfma32(a[s][2], bq[slot_].z, acc[s][an]);
+                        acc[s][an] = mfma32(a[s][3], bq[slot_].w, acc[s][an]);
+                        asm volatile("" : "+a"(acc[s][an]));
                     } else {
-                        mfma32x4_vgpr(acc[s][nt], make_float4(a[s][0], a[s][1], a[s][2], a[s][3]), bq[slot_]);
+                        mfma32x4_vgpr(acc[s][live ? nt : 0], make_float4(a[s][0], a[s][1], a[s][2], a[s][3]), bq[slot_]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     // ---- loads of the step
-                    {
-                        const int v = step + BR;
-                        const int kgv = 2 * pr + v / 18;
-                        bq[slot_] = bload(v % 18, kgv < nkg ? kgv : kgv - nkg);  // (wraps: the next patch uses the same U)
+                    if (live) {
+                        const int v = use + BR;
+                        const int kgv = 2 * pr + v / UH;
+                        bq[slot_] = bload(v % UH, kgv < nkg ? kgv : kgv - nkg);  // (wraps: the next patch uses the same U)
                     }
                     if (step == 24) {
                         __syncthreads();                                       // the next pair's image is complete
@@ -401,12 +409,13 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
         const int rrd = ((te >> 4) & 3) + 4 * (wave & 1), idx = te & 15, lhr = idx >> 3, c4 = idx & 7;
         const char *xrd = ldsb + CP::XOFF * 4 + rrd * 256 + idx * 16;
         float *xwr = lds + CP::XOFF + (wave * 9 * 8) * 64 + (te & 63);
-        f32x4 ssum[2], ssq[2];
-        ssum[0] = ssum[1] = ssq[0] = ssq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 ssum[NB], ssq[NB];
+#pragma unroll
+        for (int nt = 0; nt < NB; ++nt) ssum[nt] = ssq[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         const size_t sbase = (size_t)n * ysample;         // floats
         const __amdgpu_buffer_rsrc_t yrs = rsrc_of(karg(56) + sbase, sbytes);                    // y
 #pragma unroll
-        for (int rnd = 0; rnd < 4; ++rnd) {
+        for (int rnd = 0; rnd < 2 * NB; ++rnd) {
             const int nt = rnd >> 1, rh = rnd & 1;
             // ---- the thread's 8 pixels of the round: tile m (rows rh * 16 ..), channel quad co, output rows par and par + 2.
             // Byte offset of the channel quad inside the sample; out-of-image pixels get 0x80000000: loads give 0, stores are dropped
@@ -534,7 +543,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                     }
                 }
             }
-            if (rnd == 3) {
+            if (rnd == 2 * NB - 1) {
                 // The next patch's first pixel requests, made here -- after the last LDS reads of the epilogue, when their registers
                 // are free -- so that they land under the rest of the round: rounds 0 / 1 of its pair 1 (its pair 0 was staged by the
                 // last pair above).  Without a next patch every offset is out of range.
@@ -603,10 +612,10 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
             if (!(W4P_WHATIF & 1)) {
                 if (relu) pixels(std::true_type{}); else pixels(std::false_type{});
             }
-            if (rnd == 3) {
+            if (rnd == 2 * NB - 1) {
                 // ... and its first B fragments (L2 hits: the last pair requested them once already)
 #pragma unroll
-                for (int uu = 0; uu < BR; ++uu) bq[uu] = bload(uu % 18, (uu / 18) % nkg);
+                for (int uu = 0; uu < BR; ++uu) bq[uu] = bload(uu % UH, (uu / UH) % nkg);
             }
             tstamp(6 + rnd);
             __syncthreads();                              // the exchange region is free again
@@ -616,12 +625,12 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
             float *red = lds + CP::XOFF;                  // [2][32 groups][64]
             const int grp = (te >> 4) * 2 + lhr;
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < NB; ++nt) {
                 *reinterpret_cast<f32x4 *>(&red[(0 * 32 + grp) * 64 + nt * 32 + c4 * 4]) = ssum[nt];
                 *reinterpret_cast<f32x4 *>(&red[(1 * 32 + grp) * 64 + nt * 32 + c4 * 4]) = ssq[nt];
             }
             __syncthreads();
-            if (te < 128) {
+            if (te < 128 && (te & 63) < 32 * NB) {
                 const int c = te & 63, which = te >> 6;
                 float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
@@ -659,16 +668,23 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
 
 template <int EPI>
 void launch_wino4p(const W4Launch &a) {
-#define ADYOLO_WINO4P_FWD(TC_, AFF_)                                                                                       \
-    hipLaunchKernelGGL((wino4p_fwd_kernel<TC_, AFF_, EPI>), dim3((unsigned)a.grid), dim3(256), 0, a.st, a.x, a.u, a.bias,     \
+#define ADYOLO_WINO4P_FWD(TC_, AFF_, NB_)                                                                                  \
+    hipLaunchKernelGGL((wino4p_fwd_kernel<TC_, AFF_, EPI, NB_>), dim3((unsigned)a.grid), dim3(256), 0, a.st, a.x, a.u, a.bias, \
                        a.addend, a.addend_mask, a.in_scale, a.in_shift, a.y, a.stats, a.stat_aux, a.stat_mean,             \
                        a.stat_invstd, a.stat_mask, a.H, a.W, a.Cin, a.Cout, a.patchesW, a.patchesH, a.nsp, a.ncb,          \
                        a.xcd_div, a.relu, a.mask_bits)
-    if (a.tc == 8) {
-        if (a.in_scale) ADYOLO_WINO4P_FWD(8, true); else ADYOLO_WINO4P_FWD(8, false);
-    } else {
-        if (a.in_scale) ADYOLO_WINO4P_FWD(4, true); else ADYOLO_WINO4P_FWD(4, false);
+#define ADYOLO_WINO4P_NB(NB_)                                                                                              \
+    if (a.tc == 8) {                                                                                                       \
+        if (a.in_scale) ADYOLO_WINO4P_FWD(8, true, NB_); else ADYOLO_WINO4P_FWD(8, false, NB_);                            \
+    } else {                                                                                                               \
+        if (a.in_scale) ADYOLO_WINO4P_FWD(4, true, NB_); else ADYOLO_WINO4P_FWD(4, false, NB_);                            \
     }
+    if (a.nb == 2) {
+        ADYOLO_WINO4P_NB(2)
+    } else {
+        ADYOLO_WINO4P_NB(1)
+    }
+#undef ADYOLO_WINO4P_NB
 #undef ADYOLO_WINO4P_FWD
 }
 

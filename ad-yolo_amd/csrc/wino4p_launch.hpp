@@ -9,7 +9,7 @@ struct W4Launch {                                         // everything adyolo_w
     const float *x, *u, *bias, *addend, *addend_mask, *in_scale, *in_shift;
     float *y, *stats;
     const float *stat_aux, *stat_mean, *stat_invstd, *stat_mask;
-    int H, W, Cin, Cout, patchesW, patchesH, nsp, ncb, xcd_div, relu, mask_bits, tc, grid;
+    int H, W, Cin, Cout, patchesW, patchesH, nsp, ncb, xcd_div, relu, mask_bits, tc, grid, nb;
     hipStream_t st;
 };
 // EPI: bit 0 per-patch statistics, 1 addend, 2 addend mask (bits), 3 statistics against a BatchNorm input (stat_aux), 4 statistics

@@ -297,8 +297,10 @@ class SEBlockFn(torch.autograd.Function):
         if packs is not None:
             # (ops.DualPack -> the form this launch size runs on: F(4x4) when the grid fills the chip, else F(2x2))
             # (the data-gradient of conv1 always carries an addend -- the shortcut's gradient -- in its epilogue)
-            wpk1, wpk1d, wpk2, wpk2d = [pk.pick(n, h, w_, co, ad) if isinstance(pk, ops.DualPack) else pk
-                                        for pk, co, ad in zip(packs, (c, cin, c, c), (False, True, False, False))]
+            # (conv1's data-gradient pack is picked at the end of this forward pass, when its operand combination is known: with
+            #  32-channel output blocks only the persistent F(4x4) kernel exists, and it is built for certain combinations)
+            wpk1, wpk1d, wpk2, wpk2d = [pk.pick(n, h, w_, co, ad) if (isinstance(pk, ops.DualPack) and i != 1) else pk
+                                        for i, (pk, co, ad) in enumerate(zip(packs, (c, cin, c, c), (False, True, False, False)))]
         else:
             wpk1, wpk1d = ops.pack_w3x3(w1, cin)
             wpk2, wpk2d = ops.pack_w3x3(w2, c)
@@ -368,6 +370,19 @@ class SEBlockFn(torch.autograd.Function):
         ctx.ptrs = (w1.data_ptr(), g1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
                     (fb2.data_ptr(), fw2.data_ptr(), fb1.data_ptr(), fw1.data_ptr(), b2.data_ptr(), g2.data_ptr()))
         ctx.wshapes = (tuple(w1.shape), tuple(w2.shape))
+        if isinstance(wpk1d, ops.DualPack):
+            # the operand combination backward() will launch conv1's data-gradient with (see there): projection shortcut -> addend
+            # (+ statistics against the block above's BatchNorm input with its ReLU-mask bits); identity -> addend + mask bits +
+            # statistics / mask bits of the block above; the other combinations (the very first block's, the unfused ones) have no
+            # persistent F(4x4) form
+            lk = ctx.link_in
+            if wd is not None:
+                p_ok = lk is None or lk.ebits is not None
+            elif lk is not None:
+                p_ok = ebits is not None and lk.ebits is not None
+            else:
+                p_ok = not FUSE_DR
+            wpk1d = wpk1d.pick(n, h, w_, cin, True, p_ok)
         tensors = [p, src, scale1, cc, e, g1, mean1, invstd1, g2, b2, mean2, invstd2, ssum2, pooled, hid, s, fw1, fw2,
                    wpk1d, wpk2d, shift1]
         names = ["p", "a", "scale1", "cc", "e", "g1", "mean1", "invstd1", "g2", "b2", "mean2", "invstd2", "ssum2", "pooled",

@@ -272,12 +272,17 @@ class ForwardGraphs:
                 graph = torch.cuda.CUDAGraph()
                 with _quiet_collector(), torch.cuda.graph(graph):
                     outs = self._run(static)
-                ent = (graph, static, outs)
+                # the recorded kernels read the evaluation-mode BatchNorm affines (``_BNState.eval_affine``) by address: they were
+                # built outside the capture and belong to the modules' caches -- hold a reference for as long as the graph lives,
+                # so that a dropped or replaced cache entry cannot hand their memory to somebody else under a replay (round 5: a
+                # test that pops the caches between replays read freed memory once the allocation pattern changed)
+                keep = [m.__dict__["_adyolo_eval_affine"] for m in self.model.modules() if "_adyolo_eval_affine" in m.__dict__]
+                ent = (graph, static, outs, keep)
                 self.evictions += _lru_insert(self.entries, key, ent, MAX_GRAPHS)
                 self.captures += 1
             else:
                 self.entries.move_to_end(key)
-            graph, static, outs = ent
+            graph, static, outs = ent[0], ent[1], ent[2]
             if audio.data_ptr() != static.data_ptr():
                 static.copy_(audio, non_blocking=True)
             graph.replay()

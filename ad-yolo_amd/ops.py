@@ -143,14 +143,17 @@ W4_THRESHOLDS = {}
 
 
 def reload_thresholds():
-    """ADYOLO_W4_MIN_K (64): smallest contraction that gets the F(4x4) form packed; ADYOLO_W4_MIN_K_ADDEND (64; 128 until the
+    """ADYOLO_W4_MIN_K (64): smallest contraction that gets the F(4x4) form packed; ADYOLO_W4_MIN_K_ADDEND (32; 128 until the
     persistent kernel of round 5): the same for launches that add a tensor in their epilogue; ADYOLO_W4_MIN_WGS (200): below
     that many 64-channel x patch work items a launch stays on the F(2x2) kernel (two workgroups per CU); ADYOLO_W4W_MIN_ROWS
-    (2048): fewest tile rows of 16-column runs (N * W / 16 * H / 4) for the F(4x4)-domain weight gradient (``wgrad_form``)."""
+    (2048): fewest tile rows of 16-column runs (N * W / 16 * H / 4) for the F(4x4)-domain weight gradient (``wgrad_form``);
+    ADYOLO_W4_MIN_K_32 (32): smallest contraction for the F(4x4) form with 32-channel OUTPUT blocks (stage 1's 32 -> 32 layers
+    and the 64 -> 32 data-gradient: 1.04-1.14 x the F(2x2) kernel per launch, profiles/r05_w4p_nb1_ab.txt)."""
     W4_THRESHOLDS.update(min_k=int(os.environ.get("ADYOLO_W4_MIN_K", "64")),
-                         min_k_addend=int(os.environ.get("ADYOLO_W4_MIN_K_ADDEND", "64")),
+                         min_k_addend=int(os.environ.get("ADYOLO_W4_MIN_K_ADDEND", "32")),
                          min_wgs=int(os.environ.get("ADYOLO_W4_MIN_WGS", "200")),
-                         min_wgrad_rows=int(os.environ.get("ADYOLO_W4W_MIN_ROWS", "2048")))
+                         min_wgrad_rows=int(os.environ.get("ADYOLO_W4W_MIN_ROWS", "2048")),
+                         min_k_32=int(os.environ.get("ADYOLO_W4_MIN_K_32", "32")))
     return dict(W4_THRESHOLDS)
 
 
@@ -161,16 +164,26 @@ reload_thresholds()
 DISPATCH_LOG = None
 
 
-def _w4_eligible(k_gemm, n_gemm):
+W4P_EPIS = (0, 1, 2, 9, 27, 31)            # operand combinations the persistent F(4x4) kernel is built for (csrc/wino4p_launch.hpp)
+
+
+def _w4_eligible(k_gemm, n_gemm, allow32=False):
     """Does this GEMM direction (contraction over k_gemm channels, n_gemm output channels) get the F(4x4,3x3) form
-    (csrc/wino4.hip, wino4p.hpp) packed beside the F(2x2) one?  The kernel needs 64 output channels per workgroup and 16-channel
-    pairs of the contraction.  One workgroup per CU: it wins by more the longer the contraction -- per launch at the bench
-    shapes (round 5, persistent form) 1.4-1.6 x the F(2x2) kernel at 256 channels, 1.3-1.4 x at 128, 1.2-1.4 x at 64; DESIGN.md,
-    "F(4x4,3x3), round 5".  ADYOLO_W4_MIN_K moves the threshold (``reload_thresholds``)."""
-    return n_gemm % 64 == 0 and k_gemm % 32 == 0 and W4_THRESHOLDS["min_k"] <= k_gemm <= 512
+    (csrc/wino4.hip, wino4p.hpp) packed beside the F(2x2) one?  The kernels take 16-channel pairs of the contraction and 64
+    output channels per workgroup -- or 32 (round 5; the persistent kernel only, which deals 1 / 2 / 4 / 8 channel blocks to
+    the XCDs: ``DualPack.pick`` keeps such a launch on F(2x2) when its operand combination has no persistent form).  One
+    workgroup per CU: it wins by more the longer the contraction -- per launch at the bench shapes (round 5, persistent form)
+    1.4-1.6 x the F(2x2) kernel at 256 channels, 1.3-1.4 x at 128, 1.2-1.4 x at 64; DESIGN.md, "F(4x4,3x3), round 5".
+    ADYOLO_W4_MIN_K moves the threshold (``reload_thresholds``).  allow32: also 32-channel output blocks (``WinoPackSet``, whose
+    ``DualPack`` can fall back; plain ``pack_w3x3`` packs them only on request)."""
+    if k_gemm % 32 or k_gemm > 512:
+        return False
+    if n_gemm % 64 == 0:
+        return k_gemm >= W4_THRESHOLDS["min_k"]
+    return allow32 and n_gemm % 32 == 0 and n_gemm // 32 in (1, 2, 4, 8) and k_gemm >= W4_THRESHOLDS["min_k_32"]
 
 
-def pack_w3x3(w, cin_pad, want_dgrad=True, algo=None):
+def pack_w3x3(w, cin_pad, want_dgrad=True, algo=None, allow32=False):
     """w [Cout][Cin][3][3] -> (fwd pack, dgrad pack or None).
 
     direct:   wpk_fwd [Cout][9][cin_pad], wpk_dgrad [cin_pad][9][Cout]
@@ -182,7 +195,7 @@ def pack_w3x3(w, cin_pad, want_dgrad=True, algo=None):
     algo = algo or conv_algo()
     if algo == "winograd4" and cin_pad % 32 == 0 and cout % 32 == 0:
         # per direction: the F(4x4) form [36][N/32][K/8][256] where it applies, else the F(2x2) form
-        f4, d4 = _w4_eligible(cin_pad, cout), want_dgrad and _w4_eligible(cout, cin_pad)
+        f4, d4 = _w4_eligible(cin_pad, cout, allow32), want_dgrad and _w4_eligible(cout, cin_pad, allow32)
         uf = _new(w, 36 if f4 else 16, cout // 32, cin_pad // 8, 256)
         ud = _new(w, 36 if d4 else 16, cin_pad // 32, cout // 8, 256) if want_dgrad else None
         if f4 or d4:
@@ -211,10 +224,14 @@ class DualPack:
     def __init__(self, f4, f2):
         self.f4, self.f2 = f4, f2
 
-    def pick(self, n, h, w, cout, addend=False):
+    def pick(self, n, h, w, cout, addend=False, persistent_ok=True):
         """addend: the launch adds a tensor in its epilogue (the data-gradient of a block's first convolution); until round 5 the
-        F(2x2) kernel was the faster one there below 128 channels (ADYOLO_W4_MIN_K_ADDEND, now 64)"""
-        wgs = _lib.load().adyolo_wino4_tiles(n, h, w) * (cout // 64)
+        F(2x2) kernel was the faster one there below 128 channels (ADYOLO_W4_MIN_K_ADDEND, now 32: no effect by default).  persistent_ok: the launch's
+        operand combination has a persistent form (``W4P_EPIS``, no bias, masks as bits) -- with 32-channel output blocks
+        (cout % 64 != 0) there is no other F(4x4) kernel."""
+        if cout % 64 and not (persistent_ok and os.environ.get("ADYOLO_W4_PERSIST", "1") != "0"):
+            return self.f2
+        wgs = _lib.load().adyolo_wino4_tiles(n, h, w) * ((cout + 63) // 64)
         if wgs < W4_THRESHOLDS["min_wgs"]:
             return self.f2
         if addend and self.f4.shape[2] * 8 < W4_THRESHOLDS["min_k_addend"]:
@@ -235,7 +252,7 @@ class WinoPackSet:
         """frozen (evaluation mode): skip the launch when nothing was written to the filters since the last one
         (``PARAMS_EPOCH`` for in-place kernels, the tensors' version counters for ``copy_`` / ``load_state_dict``)."""
         w4 = conv_algo() == "winograd4"
-        key = (w4, W4_THRESHOLDS["min_k"]) + tuple(w.data_ptr() for w in weights)
+        key = (w4, W4_THRESHOLDS["min_k"], W4_THRESHOLDS["min_k_32"]) + tuple(w.data_ptr() for w in weights)
         stamp = (PARAMS_EPOCH[0],) + tuple(w._version for w in weights)
         if frozen and key == self.key and stamp == self.stamp:
             return self
@@ -250,7 +267,7 @@ class WinoPackSet:
                     raise _lib.AdyoloHipError("WinoPackSet: channel counts must be multiples of 32")
                 # per direction: the F(2x2) form always, the F(4x4) form [36][N/32][K/8][256] beside it where it applies
                 # (winograd4): ``conv3x3`` picks by the size of the launch (``DualPack``)
-                f4, d4 = w4 and _w4_eligible(cin, cout), w4 and _w4_eligible(cout, cin)
+                f4, d4 = w4 and _w4_eligible(cin, cout, True), w4 and _w4_eligible(cout, cin, True)
                 uf = _new(w, 16, cout // 32, cin // 8, 256)
                 ud = _new(w, 16, cin // 32, cout // 8, 256)
                 rows.append([w.data_ptr(), uf.data_ptr(), ud.data_ptr(), cout, cin, cin, 0, 0])
@@ -293,8 +310,15 @@ def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, 
     if stat_mask is not None and stat_mask.dtype == torch.int64:
         mbits |= 2
     n, h, w, cin = x.shape
+    # operand combination, as the persistent F(4x4) kernel's EPI bits: 1 statistics, 2 addend, 4 addend mask, 8 stat_bn, 16 stat mask
+    epi = (1 if want_stats else 0) | (2 if addend is not None else 0) | (4 if addend_mask is not None else 0) | \
+          (8 if stat_bn is not None else 0) | (16 if stat_mask is not None else 0)
+    p_ok = bias is None and epi in W4P_EPIS and (addend_mask is None or mbits & 1) and (stat_mask is None or mbits & 2)
     if isinstance(wpk, DualPack):
-        wpk = wpk.pick(n, h, w, cout, addend is not None)
+        wpk = wpk.pick(n, h, w, cout, addend is not None, p_ok)
+    elif wpk.dim() == 4 and wpk.shape[0] == 36 and cout % 64 and not p_ok:
+        raise _lib.AdyoloHipError("conv3x3: a F(4x4) pack with %d output channels needs an operand combination the persistent kernel "
+                                  "is built for (pack with ops.DualPack / WinoPackSet to fall back to F(2x2))" % cout)
     _chk(x, wpk, bias, addend, None if mbits & 1 else addend_mask, None if mbits & 2 else stat_mask)
     wino = wpk.dim() == 4
     wino4 = wino and wpk.shape[0] == 36
@@ -318,9 +342,6 @@ def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, 
             name = "wino4p_fwd_kernel" if _lib.load().adyolo_wino4_last_form() == 2 else "wino4_fwd_kernel"
         else:
             name = "wino_fwd_kernel" if wino else "conv3x3_fwd_kernel"
-        # operand combination, as the persistent kernel's EPI bits: 1 statistics, 2 addend, 4 addend mask, 8 stat_bn, 16 stat mask
-        epi = (1 if want_stats else 0) | (2 if addend is not None else 0) | (4 if addend_mask is not None else 0) | \
-              (8 if stat_bn is not None else 0) | (16 if stat_mask is not None else 0)
         k = (name, cin, cout, epi)
         DISPATCH_LOG[k] = DISPATCH_LOG.get(k, 0) + 1
     return (y, stats) if want_stats else y
