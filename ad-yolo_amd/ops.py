@@ -145,14 +145,15 @@ W4_THRESHOLDS = {}
 def reload_thresholds():
     """ADYOLO_W4_MIN_K (64): smallest contraction that gets the F(4x4) form packed; ADYOLO_W4_MIN_K_ADDEND (32; 128 until the
     persistent kernel of round 5): the same for launches that add a tensor in their epilogue; ADYOLO_W4_MIN_WGS (200): below
-    that many 64-channel x patch work items a launch stays on the F(2x2) kernel (two workgroups per CU); ADYOLO_W4W_MIN_ROWS
-    (2048): fewest tile rows of 16-column runs (N * W / 16 * H / 4) for the F(4x4)-domain weight gradient (``wgrad_form``);
+    that many 64-channel x patch work items a launch stays on the F(2x2) kernel (two workgroups per CU); ADYOLO_W4W_MIN_WORK
+    (2^24): smallest (tile rows of 16-column runs) x Cin x Cout = N W/16 H/4 Cin Cout for the F(4x4)-domain weight gradient
+    (``wgrad_form``; measured crossover with the F(2x2)-domain kernel at 15-33 M at every stage: profiles/r05_w4w_small_batches.txt);
     ADYOLO_W4_MIN_K_32 (32): smallest contraction for the F(4x4) form with 32-channel OUTPUT blocks (stage 1's 32 -> 32 layers
     and the 64 -> 32 data-gradient: 1.04-1.14 x the F(2x2) kernel per launch, profiles/r05_w4p_nb1_ab.txt)."""
     W4_THRESHOLDS.update(min_k=int(os.environ.get("ADYOLO_W4_MIN_K", "64")),
                          min_k_addend=int(os.environ.get("ADYOLO_W4_MIN_K_ADDEND", "32")),
                          min_wgs=int(os.environ.get("ADYOLO_W4_MIN_WGS", "200")),
-                         min_wgrad_rows=int(os.environ.get("ADYOLO_W4W_MIN_ROWS", "2048")),
+                         min_wgrad_work=int(os.environ.get("ADYOLO_W4W_MIN_WORK", str(1 << 24))),
                          min_k_32=int(os.environ.get("ADYOLO_W4_MIN_K_32", "32")))
     return dict(W4_THRESHOLDS)
 
@@ -350,14 +351,14 @@ def conv3x3(x, wpk, cout, bias=None, addend=None, relu=False, addend_mask=None, 
 def wgrad_form(cin, cout, algo=None, shape=None):
     """-> (kernel name, matrix FLOPs issued / direct-convolution FLOPs) of the weight-gradient ``conv3x3_wgrad`` launches for these
     channel counts (and, with ``shape`` = (N, H, W), this launch): the Winograd F(4x4,3x3) domain (csrc/wino4w.hip, round 5: 9
-    multiplies per 36) under 'winograd4' when the kernel takes the shape (Cout % 64, W % 16, H % 4) and the launch has at least
-    ADYOLO_W4W_MIN_ROWS tile rows of 16-column runs (one workgroup per CU: small launches stay on the two-per-CU kernel); else
+    multiplies per 36) under 'winograd4' when the kernel takes the shape (Cout % 32, W % 16, H % 4) and the launch is large
+    enough (ADYOLO_W4W_MIN_WORK; one workgroup per CU: small launches stay on the two-per-CU kernel); else
     the F(2x2,3x3) domain (16 per 36) when both channel counts are multiples of 32; else the direct implicit GEMM.  The ONE
     place that decides it -- ``conv3x3_wgrad`` and bench.py both ask here."""
     algo = algo or os.environ.get("ADYOLO_WGRAD_ALGO") or conv_algo()
     if algo == "winograd4" and shape is not None and cin % 32 == 0 and cout % 32 == 0:
         n, h, w = shape
-        if w % 16 == 0 and h % 4 == 0 and n * (w // 16) * (h // 4) >= W4_THRESHOLDS["min_wgrad_rows"] and \
+        if w % 16 == 0 and h % 4 == 0 and n * (w // 16) * (h // 4) * cin * cout >= W4_THRESHOLDS["min_wgrad_work"] and \
                 _lib.load().adyolo_wino4_wgrad_slabs(n, h, w, cin, cout) > 0:
             return "wino4_wgrad_kernel", 9.0 / 36.0
     if algo in ("winograd", "winograd4") and cin % 32 == 0 and cout % 32 == 0:

@@ -6,7 +6,7 @@ import argparse
 import os
 import sys
 
-os.environ["ADYOLO_W4W_MIN_ROWS"] = "1"           # the F(4x4)-domain kernel at every shape it takes
+os.environ["ADYOLO_W4W_MIN_WORK"] = "1"           # the F(4x4)-domain kernel at every shape it takes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
