@@ -36,7 +36,7 @@ SIGNATURES = {
     "adyolo_wino4_fwd": (I, [P] * 13 + [I] * 7 + [P]),
     "adyolo_wino4_last_form": (I, []),
     "adyolo_wino4_wgrad_slabs": (I, [I] * 5),
-    "adyolo_wino4_wgrad": (I, [P] * 6 + [I] * 6 + [P]),
+    "adyolo_wino4_wgrad": (I, [P] * 7 + [I] * 6 + [P]),
     "adyolo_wino_wgrad_slabs": (I, [I] * 5),
     "adyolo_wino_wgrad": (I, [P] * 7 + [I] * 6 + [P]),
     "adyolo_conv3x3_wgrad_slabs": (I, [I] * 5),

@@ -340,15 +340,27 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
     }
 }
 
-// Slab sum + G^T . G: a workgroup owns 32 consecutive (ci, co) pairs; for each of the 36 positions it sums the slabs in the fixed
-// order of block_colsum32 (double), then its first 32 threads apply the filter transform (in double) and write dw in the reference
-// layout [Cout][Cin_real][3][3].  Position P = 9 w + s: s < 6: (xi = s, nu = nuF(w)); s >= 6: nu = nuH(w), xi = 0, 1, 2 (w even) or
-// 5, 3, 4 (w odd) -- the order of wino4.hip.
-__global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float *__restrict__ slabs, float *__restrict__ dw, int nslab,
-                                                                 int Cin, int Cin_real, int Cout) {
+// Slab sum, then G^T . G -- two small launches.  (The first version did both in one kernel, 36 barrier-separated column sums per
+// workgroup: 55 us per call -- latency-bound with 8 slabs, parallelism-bound with 32 x 32 channels; profiles/r05_bench_b64x60s_*.)
+// reduce: grid (ceil(pairs / 32), 36): one position's 32 consecutive (ci, co) pairs, slabs summed in the fixed order of
+// block_colsum32 (double) -> du [36][Cin][Cout].
+__global__ __launch_bounds__(256) void wino4_wgrad_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ du, int nslab,
+                                                                 int pairs) {
     __shared__ double red[256];
-    const int pairs = Cin * Cout, total = 36 * pairs;
-    const int idx = blockIdx.x * 32 + (threadIdx.x & 31);        // over [Cin][Cout], co fastest
+    const int p = blockIdx.y, total = 36 * pairs;
+    const double s = block_colsum32(slabs, nslab, (size_t)total, p * pairs + blockIdx.x * 32, p * pairs + pairs, red);
+    const int idx = blockIdx.x * 32 + (threadIdx.x & 31);
+    if ((threadIdx.x >> 5) == 0 && idx < pairs) du[(size_t)p * pairs + idx] = (float)s;
+}
+// finish: dw[ky][kx] = sum G[xi][ky] dU[xi][nu] G[nu][kx] (in double), reference layout [Cout][Cin_real][3][3].  Position
+// P = 9 w + s: s < 6: (xi = s, nu = nuF(w)); s >= 6: nu = nuH(w), xi = 0, 1, 2 (w even) or 5, 3, 4 (w odd) -- the order of wino4.hip.
+__global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float *__restrict__ du, float *__restrict__ dw, int Cin,
+                                                                 int Cin_real, int Cout) {
+    const int pairs = Cin * Cout;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // over [Cin][Cout], co fastest
+    if (idx >= pairs) return;
+    const int co = idx % Cout, ci = idx / Cout;
+    if (ci >= Cin_real) return;
     double d[6][6];
 #pragma unroll
     for (int wv = 0; wv < 4; ++wv)
@@ -357,11 +369,8 @@ __global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float *__
             const int p = wv * 9 + s;
             const int nu = s < 6 ? (wv == 0 ? 0 : wv == 1 ? 2 : wv == 2 ? 3 : 5) : (wv < 2 ? 1 : 4);
             const int xi = s < 6 ? s : (wv & 1) ? (s == 6 ? 5 : s - 4) : s - 6;
-            d[xi][nu] = block_colsum32(slabs, nslab, (size_t)total, p * pairs + blockIdx.x * 32, p * pairs + pairs, red);
+            d[xi][nu] = (double)du[(size_t)p * pairs + idx];
         }
-    if ((threadIdx.x >> 5) != 0 || idx >= pairs) return;
-    const int co = idx % Cout, ci = idx / Cout;
-    if (ci >= Cin_real) return;
     const double a_ = 0.75, b_ = 1.5, a2 = a_ * a_, b2 = b_ * b_;
     const double na = 2.0 * a2 * (a2 - b2), nb = 2.0 * b2 * (b2 - a2);
     const double G[6][3] = {{1.0 / (a2 * b2), 0.0, 0.0}, {1.0 / na, a_ / na, a2 / na}, {1.0 / na, -a_ / na, a2 / na},
@@ -421,8 +430,8 @@ extern "C" int adyolo_wino4_wgrad_slabs(int N, int H, int W, int Cin, int Cout) 
 }
 
 extern "C" int adyolo_wino4_wgrad(const float *x, const float *dy, const float *in_scale, const float *in_shift, float *slabs,
-                                  float *dw, int N, int H, int W, int Cin, int Cin_real, int Cout, void *stream) {
-    ADYOLO_REQUIRE(x && dy && slabs && dw && N > 0 && H > 0 && W > 0, ADYOLO_EINVAL, "wino4_wgrad: bad arguments");
+                                  float *du, float *dw, int N, int H, int W, int Cin, int Cin_real, int Cout, void *stream) {
+    ADYOLO_REQUIRE(x && dy && slabs && du && dw && N > 0 && H > 0 && W > 0, ADYOLO_EINVAL, "wino4_wgrad: bad arguments");
     ADYOLO_REQUIRE(adyolo_wino4_wgrad_slabs(N, H, W, Cin, Cout) > 0 && Cin_real > 0 && Cin_real <= Cin, ADYOLO_ENOSUP,
                    "wino4_wgrad: unsupported shape N=%d H=%d W=%d Cin=%d Cout=%d (needs Cin %% 32 == 0, Cout %% 32 == 0, W %% 16 == 0, "
                    "H %% 4 == 0, tensors below 2 GiB)", N, H, W, Cin, Cout);
@@ -442,7 +451,9 @@ extern "C" int adyolo_wino4_wgrad(const float *x, const float *dy, const float *
 #undef ADYOLO_W4W
     int rc = check_launch("wino4_wgrad");
     if (rc) return rc;
-    hipLaunchKernelGGL(w4::wino4_wgrad_finish_kernel, dim3(cdiv(Cin * Cout, 32)), dim3(256), 0, st, slabs, dw, nsplit, Cin, Cin_real,
-                       Cout);
+    hipLaunchKernelGGL(w4::wino4_wgrad_reduce_kernel, dim3(cdiv(Cin * Cout, 32), 36), dim3(256), 0, st, slabs, du, nsplit, Cin * Cout);
+    rc = check_launch("wino4_wgrad_reduce");
+    if (rc) return rc;
+    hipLaunchKernelGGL(w4::wino4_wgrad_finish_kernel, dim3(cdiv(Cin * Cout, 256)), dim3(256), 0, st, du, dw, Cin, Cin_real, Cout);
     return check_launch("wino4_wgrad_finish");
 }

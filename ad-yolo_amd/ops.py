@@ -382,7 +382,8 @@ def conv3x3_wgrad(x, dy, cin_real, in_affine=None, algo=None, out=None):
     if form == "wino4_wgrad_kernel":
         nslab = _lib.load().adyolo_wino4_wgrad_slabs(n, h, w, cin, cout)
         slabs = _new(x, nslab, 36, cin, cout)
-        _c("adyolo_wino4_wgrad", _p(x), _p(dy), _p(sc), _p(sh), _p(slabs), _p(dw), n, h, w, cin, cin_real, cout, _stream())
+        du = _new(x, 36, cin, cout)
+        _c("adyolo_wino4_wgrad", _p(x), _p(dy), _p(sc), _p(sh), _p(slabs), _p(du), _p(dw), n, h, w, cin, cin_real, cout, _stream())
         return dw
     if form == "wino_wgrad_kernel":
         nslab = _lib.load().adyolo_wino_wgrad_slabs(n, h, w, cin, cout)

@@ -155,7 +155,8 @@ int adyolo_wino4_last_form(void);
  *      not supported (callers then use adyolo_wino_wgrad).  dw: reference layout [Cout][Cin_real][3][3]. */
 int adyolo_wino4_wgrad_slabs(int N, int H, int W, int Cin, int Cout);
 int adyolo_wino4_wgrad(const float *x, const float *dy, const float *in_scale /*or NULL*/, const float *in_shift /*or NULL*/,
-                       float *slabs, float *dw, int N, int H, int W, int Cin, int Cin_real, int Cout, void *stream);
+                       float *slabs, float *du /*[36][Cin][Cout] scratch*/, float *dw, int N, int H, int W, int Cin, int Cin_real,
+                       int Cout, void *stream);
 /* Winograd weight-gradient: dw = G^T [ sum_tiles (B^T d B)(.)(A e A^T) ] G.  slabs: [n_slabs][16][Cin][Cout] float32 with
  * n_slabs = adyolo_wino_wgrad_slabs(...); du: [16][Cin][Cout] scratch; dw: reference layout [Cout][Cin_real][3][3]. */
 int adyolo_wino_wgrad_slabs(int N, int H, int W, int Cin, int Cout);

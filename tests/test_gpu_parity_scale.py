@@ -478,8 +478,9 @@ def test_bench_shape_step_loss_direct_vs_winograd(ops, monkeypatch):
 
 def test_dispatch_table_at_the_bench_shape(ops):
     """Which kernel every 3x3 convolution of one training step launches at the benchmark's clip shape with the DEFAULT thresholds
-    (12 clips x 60 s: every layer takes the kernel the 64-clip batch takes -- ``ops.DualPack`` picks by launch size, and the
-    smallest F(4x4) launch of the step, the 128 -> 64 data-gradient at 600 x 16 pixels, needs 11 clips for its 200 work items).  A threshold or dispatch regression cannot hide behind green parity tests: the parity tests force
+    (16 clips x 60 s: every layer takes the kernel the 64-clip batch takes -- ``ops.DualPack`` picks by launch size: the smallest
+    F(4x4) forward launch of the step, the 128 -> 64 data-gradient at 600 x 16 pixels, needs 11 clips for its 200 work items, the
+    smallest weight gradients (32 -> 64, 64 -> 128) 14 clips for ADYOLO_W4W_MIN_WORK).  A threshold or dispatch regression cannot hide behind green parity tests: the parity tests force
     ADYOLO_W4_MIN_K=32, this one asserts the table bench.py reports as ``dispatch``.
     SE-ResNet34 (reference resnet.py:126-199): 16 blocks x 2 convolutions, forward + data-gradient = 64 launches + the 7 -> 32 stem.
     F(4x4,3x3) in its persistent form takes 62 of the 64 block launches (round 5: also stage 1's 32 -> 32 layers, with
@@ -492,7 +493,7 @@ def test_dispatch_table_at_the_bench_shape(ops):
     from adyolo_amd.train import TrainStep
     assert ops.reload_thresholds() == {"min_k": 64, "min_k_addend": 32, "min_wgs": 200, "min_wgrad_work": 1 << 24, "min_k_32": 32}
     assert ops.conv_algo() == "winograd4" and os.environ.get("ADYOLO_W4_PERSIST", "1") != "0"
-    b, n = 12, 24000 * 60
+    b, n = 16, 24000 * 60
     torch.manual_seed(100)
     prm = bench.params("cuda:0")
     model = WrapperModel((1, 7, n // 600, 64), (), prm).to("cuda:0")
@@ -520,7 +521,7 @@ def test_dispatch_table_at_the_bench_shape(ops):
     # the data-gradient of the very first block (addend + mask + statistics against the stem's BatchNorm input, no statistics
     # mask: operand combination 15, which the persistent kernel is not built for and 32-channel blocks have no other F(4x4) form)
     assert sorted((cin, cout, epi) for (name, cin, cout, epi), _ in log.items() if name == "wino_fwd_kernel") == [(32, 32, 15), (32, 64, 1)]
-    # the weight gradients: the F(4x4) domain for every block convolution (a launch needs ADYOLO_W4W_MIN_WORK: 12 clips have it,
+    # the weight gradients: the F(4x4) domain for every block convolution (a launch needs ADYOLO_W4W_MIN_WORK: 16 clips have it,
     # and so has the benchmark's batch -- asked from the one function that decides)
     assert per_wgrad == {"wino4_wgrad_kernel": 32, "conv3x3_wgrad_kernel": 1}, per_wgrad
     layers = [(32, 32, 2400, 64)] * 6 + [(32, 64, 1200, 32)] + [(64, 64, 1200, 32)] * 7 + [(64, 128, 600, 16)] + \
