@@ -768,26 +768,25 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(
     }
 }
 
-// slabs [nslab][total] -> du [total] (fixed order, partial sums in double)
-// Slab sum + G^T . G in ONE launch (round 5; two launches -- reduce, then finish through a [16][Cin][Cout] scratch -- until then:
-// 64 of the ~630 launches of a train step).  A workgroup owns 32 consecutive (ci, co) pairs: for each of the 16 positions it
-// sums the slabs in the fixed order of block_colsum32 (double accumulation, rounded to float exactly where the scratch array
-// used to be written: bit-identical results), then its first 32 threads apply the filter transform and write dw in the
-// reference layout [Cout][Cin_real][3][3].  `du` (the old scratch) is no longer touched.
-__global__ __launch_bounds__(256) void wino_wgrad_reduce_finish_kernel(const float *__restrict__ slabs, float *__restrict__ dw,
-                                                                       int nslab, int Cin, int Cin_real, int Cout) {
+// slabs [nslab][total] -> du [total] (fixed order, partial sums in double).  (Round 5 tried ONE launch for the slab sum and G^T . G --
+// a workgroup per 32 (ci, co) pairs, 16 barrier-separated column sums: bit-identical, but 34 us per call against 12 + 5 for the two
+// launches below (latency-bound with few slabs, 16 x fewer workgroups): reverted; profiles/r05_small_shapes.json of that build.)
+__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ du,
+                                                                int nslab, int total) {
     __shared__ double red[256];
-    const int pairs = Cin * Cout, total = 16 * pairs;
-    const int idx = blockIdx.x * 32 + (threadIdx.x & 31);        // over [Cin][Cout], co fastest
-    float d[4][4];
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {
-        const double sum = block_colsum32(slabs, nslab, (size_t)total, p * pairs + blockIdx.x * 32, p * pairs + pairs, red);
-        d[p >> 2][p & 3] = (float)sum;
-    }
-    if ((threadIdx.x >> 5) != 0 || idx >= pairs) return;
+    const double sum = block_colsum32(slabs, nslab, (size_t)total, blockIdx.x * 32, total, red);
+    const int idx = blockIdx.x * 32 + (threadIdx.x & 31);
+    if ((threadIdx.x >> 5) == 0 && idx < total) du[idx] = (float)sum;
+}
+__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float *__restrict__ du, float *__restrict__ dw,
+                                                                int Cin, int Cin_real, int Cout) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // over [Cin][Cout], co fastest
+    if (idx >= Cin * Cout) return;
     const int co = idx % Cout, ci = idx / Cout;
     if (ci >= Cin_real) return;
+    float d[4][4];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) d[p >> 2][p & 3] = du[(size_t)p * Cin * Cout + idx];
     float t[3][4];                                // t = G^T d
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -877,8 +876,10 @@ extern "C" int adyolo_wino_wgrad(const float *x, const float *dy, const float *i
 #undef ADYOLO_WINO_WGRAD
     int rc = check_launch("wino_wgrad");
     if (rc) return rc;
-    (void)du;                                    // (scratch of the two-launch form; kept in the signature)
-    hipLaunchKernelGGL(wino_wgrad_reduce_finish_kernel, dim3(cdiv(Cin * Cout, 32)), dim3(256), 0, st, slabs, dw, nsplit, Cin,
-                       Cin_real, Cout);
-    return check_launch("wino_wgrad_reduce_finish");
+    const int total = 16 * Cin * Cout;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, slabs, du, nsplit, total);
+    rc = check_launch("wino_wgrad_reduce");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(cdiv(Cin * Cout, 256)), dim3(256), 0, st, du, dw, Cin, Cin_real, Cout);
+    return check_launch("wino_wgrad_finish");
 }
