@@ -273,7 +273,7 @@ EXTRA_CONFIGS = {
 
 def _small_shape_kernel_ms(name):
     """-> (sum of the kernel durations of one step from the committed rocprofv3 run, the file it was read from)"""
-    for fn in ("r04_small_shapes.json", "r03_small_shapes.json"):
+    for fn in ("r05_small_shapes.json", "r04_small_shapes.json", "r03_small_shapes.json"):
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as f:
                 v = json.load(f).get(name, {}).get("kernel_ms_per_step")
