@@ -30,6 +30,10 @@ namespace w4 {
 #ifndef W4W_WHATIF
 #define W4W_WHATIF 0
 #endif
+#ifndef W4W_TIMING
+#define W4W_TIMING 0      // 1: wave 0 of one workgroup writes s_memtime stamps of the first steps of its first item to a buffer set
+                          // with adyolo_w4w_timing_buffer (results stay valid; tools/wino4w/timing.py)
+#endif
 #ifndef W4W_ORDER
 #define W4W_ORDER 0       // experiment switch: where the dy operands are read (0: right before their transforms; 1: block 0 before the
                           // mid-step barrier, block 1 before its transforms; 2: block 0 before the barrier, block 1 under block 0's MFMAs).
@@ -61,6 +65,10 @@ __device__ __forceinline__ void a3v(const f32x4 (&v)[4], const f32x4 &zrow, f32x
     t2 = fm(-1.f, o, e);
 }
 
+#if W4W_TIMING
+__device__ unsigned long long *g_w4w_stamps;
+#endif
+
 constexpr int XROWB = 1024;                 // bytes of an x row slot: 32 channels x 8 tiles
 constexpr int XSLOTS = 6;
 constexpr int XNU = XSLOTS * XROWB;         // per nu plane
@@ -85,6 +93,15 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
+#if W4W_TIMING
+    unsigned long long *stamps = g_w4w_stamps;
+    int tstep = 0;
+    auto tstamp = [&](int k) {
+        if (blockIdx.x == 8 && tid == 0 && tstep < 12) stamps[tstep * 16 + k] = __builtin_amdgcn_s_memtime();
+    };
+#else
+    auto tstamp = [&](int) {};
+#endif
     // workgroup -> (split, channel block): the 32 workgroups of an XCD are all channel blocks of 32 / nblk splits, so that one
     // XCD's L2 sees the x / dy rows of its splits once for every channel block that needs them
     int split, blk;
@@ -270,6 +287,7 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
                     }
                 }
             };
+            tstamp(0);
             {
                 int so[6];
 #pragma unroll
@@ -293,6 +311,7 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
                 __syncthreads();                                               // every wave has read the window: its four oldest rows are free
                 if (W4W_ORDER >= 3) d_reads(0);                                // (their latency hides under the staging work)
                 __builtin_amdgcn_sched_barrier(0);
+                tstamp(1);
                 // ---- staging of step k + 1 (loads requested one step ago): x rows -> the slots the window just retired
                 {
                     int sl = rot + sxr;                                        // window row sxr of step k = slot of new row 2 + sxr of step k + 1
@@ -304,25 +323,36 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
                 x_load(4 * (t0 + k + 2) + 1 + sxr);
                 d_load(min(t0 + k + 2, H / 4 - 1));
                 __builtin_amdgcn_sched_barrier(0);
+                tstamp(2);
                 bt6v2(cF, a[0], a[1], a[2], a[3], a[4], a[5]);
                 bt3v(cP, cZ, a[6], a[7], a[8], K2x, KPx);
             }
+            if (W4W_TIMING) __builtin_amdgcn_sched_barrier(0);
+            tstamp(3);
             if (W4W_ORDER == 0) d_reads(0);
             d_xform();
             __builtin_amdgcn_sched_barrier(0);
+            tstamp(4);
             if (NB == 2 && (W4W_ORDER == 2 || W4W_ORDER == 4)) d_reads(1);
             __builtin_amdgcn_sched_barrier(0);
             mfmas(0);
             __builtin_amdgcn_sched_barrier(0);
+            tstamp(5);
             if (NB == 2) {
                 if (W4W_ORDER != 2 && W4W_ORDER != 4) d_reads(1);
                 d_xform();
                 __builtin_amdgcn_sched_barrier(0);
+                tstamp(6);
                 mfmas(1);
                 __builtin_amdgcn_sched_barrier(0);
+                tstamp(7);
             }
             rot = rot + 4 >= 6 ? rot - 2 : rot + 4;
             __syncthreads();                                                   // step k + 1's rows are in LDS
+            tstamp(8);
+#if W4W_TIMING
+            ++tstep;
+#endif
         }
     }
 
@@ -420,6 +450,12 @@ static int wino4_wgrad_geometry(int N, int H, int W, int Cin, int Cout, int *npa
 }  // namespace adyolo
 
 using namespace adyolo;
+
+#if W4W_TIMING
+extern "C" int adyolo_w4w_timing_buffer(void *p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(w4::g_w4w_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // > 0: the number of slabs the kernel writes for this shape; <= 0: shape not supported (use adyolo_wino_wgrad)
 extern "C" int adyolo_wino4_wgrad_slabs(int N, int H, int W, int Cin, int Cout) {
