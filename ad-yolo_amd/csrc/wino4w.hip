@@ -12,15 +12,20 @@
 // and walks pairs of RUNS (a run = four tiles side by side = 16 output columns; with W = 16 the two runs of a pair come from two
 // samples, with W = 32 from one row) top to bottom, one tile row = 8 tiles = four MFMA k-steps per step (72 MFMAs per wave).
 // Both transforms are separable and split like the forward kernel's input transform:
-//   * W direction while staging: a thread fetches the 18 input pixels (dword loads, channel-contiguous: a lane = a channel) of one
-//     (new row, channel, run), applies the producer's BatchNorm affine, transforms the four tiles at once (<4 x float> = the four
-//     tiles: packed instructions) and writes six ds_write_b128 into C[nu][row slot][channel][8 tiles]; dy likewise (16 pixels ->
-//     D[nu][row][channel][8 tiles], 4 -> 6 points with A).  The tile index runs along a lane's registers, so a ds_read_b128
-//     yields the operand of four k-steps; the two tile quads of a channel are swapped when (channel >> 3) is odd, which keeps
-//     every 16-lane ds_read_b128 group conflict-free (wino.hip).
+//   * W direction while staging: a thread owns (new row, run, tile, channel quad): six 16-byte loads (x; four for dy) fetch the
+//     tile's pixels with the quad's four channels in one register quad (a wave-instruction moves 1 KB through the texture
+//     addresser instead of the 256 B of the first version's dword loads, which kept the addresser busy for 3 200 of a step's
+//     9 200 cycles: profiles/r05_w4w_timing.txt), the producer's BatchNorm affine and the transform run on <4 x float> = the four
+//     channels, and the TRANSPOSE the GEMM side needs -- C[nu][row slot][channel][8 tiles], the tile index along a lane's
+//     registers, so that a ds_read_b128 yields the operand of four k-steps -- happens in the LDS stores: 24 ds_write_b32 per
+//     item (a ds_write_b32 costs 4 cycles of the store path, a ds_write_b128 13).  Channel c of a row lives in 32-byte slot
+//     pi(c) = (c & ~3) | ((c + (c >> 2)) & 3): store k of the eight quads of a lane group then falls into four different
+//     bank octets (2-way conflicts, which cost a ds_write_b32 nothing) instead of one; the reads keep their conflict-free
+//     16-lane groups, pi permutes inside aligned groups of four channels.  The two tile quads of a channel are swapped when
+//     (channel >> 3) is odd (wino.hip).  dy likewise (four pixels -> D[nu][row][channel][8 tiles], 4 -> 6 points with A).
 //   * H direction in the GEMM waves: six (x) / four (dy) ds_read_b128 per column give the six A / B operand quads of the column.
-// x rows live in a six-slot ring (a step's window; the four rows a step retires are overwritten by the next step's new rows after
-// a barrier that follows the window's reads), dy rows in two buffers: 37 + 2 x 49 KB of LDS.  Slabs of dU (one per workgroup) are
+// x rows live in a ten-slot ring (the six rows of a step's window + the four new rows of the next step, stored while this step
+// computes), dy rows in two buffers: 60 + 2 x 48 KB of LDS, one barrier per step.  Slabs of dU (one per workgroup) are
 // summed in a fixed order and G^T . G applied by one small kernel (deterministic).
 #include "wino4_common.hpp"
 
@@ -33,12 +38,6 @@ namespace w4 {
 #ifndef W4W_TIMING
 #define W4W_TIMING 0      // 1: wave 0 of one workgroup writes s_memtime stamps of the first steps of its first item to a buffer set
                           // with adyolo_w4w_timing_buffer (results stay valid; tools/wino4w/timing.py)
-#endif
-#ifndef W4W_ORDER
-#define W4W_ORDER 0       // experiment switch: where the dy operands are read (0: right before their transforms; 1: block 0 before the
-                          // mid-step barrier, block 1 before its transforms; 2: block 0 before the barrier, block 1 under block 0's MFMAs).
-                          // Same-session A/B at B = 64 (profiles/r05_w4w_order_ab.txt): 0 is 9-10 % faster than 1 and 2 without the
-                          // affine and 1-2 % with it -- reads ahead of the barrier lengthen what every wave waits for there
 #endif
 
 // A (6 x 4) along one direction on the four tiles of a run: t = A v
@@ -70,7 +69,7 @@ __device__ unsigned long long *g_w4w_stamps;
 #endif
 
 constexpr int XROWB = 1024;                 // bytes of an x row slot: 32 channels x 8 tiles
-constexpr int XSLOTS = 6;
+constexpr int XSLOTS = 10;               // the six rows of a step's window + the four new rows of the next step
 constexpr int XNU = XSLOTS * XROWB;         // per nu plane
 constexpr int XBYTES = 6 * XNU;             // 36 864
 // dy rows: 32 NB channels x 8 tiles; NB = 2 (Cout % 64 == 0) or 1 (32-channel blocks: stage 1 -- half the MFMAs per staged byte)
@@ -125,7 +124,8 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
     const float K2x = hh ? A2 : B2, KPx = hh ? PB : PA;                       // x half column (bt3v)
     const float K1d = hh ? PB : PA, K2d = hh ? B2 : A2, K3d = hh ? B3 : A3;   // dy half column (a3v)
     const int lsw = (lh ^ ((li >> 3) & 1)) << 4;                              // tile quad of the lane's half, swizzled
-    const int lx = li * 32 + lsw;                                             // lane part of an x read / a dy read inside a 32-channel block
+    const int lpi = (li & ~3) | ((li + (li >> 2)) & 3);                        // slot of the lane's channel inside its row (see above)
+    const int lx = lpi * 32 + lsw;                                            // lane part of an x read / a dy read inside a 32-channel block
 
     f32x16 acc[9][NB];
 #pragma unroll
@@ -135,25 +135,26 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[s][cb][r] = 0.f;
 
-    // ---- staging roles.  A wave stages ONE run (the two runs of a pair may belong to different samples).
-    // x: channel sxc, new row (wave >> 1) * 2 + lh of the step's four, run wave & 1.   dy: channel sdc (64), rows (wave >> 1) * 2 + {0, 1}
+    // ---- staging roles.  A wave stages ONE run (the two runs of a pair may belong to different samples) and two rows:
+    // row (wave >> 1) * 2 + lh of the step's four (x: new rows; dy: rows of the tile row), tile st of the run, channel quad sq
+    // (dy: of each 32-channel block)
     const int run = wave & 1;
-    const int sxc = li, sxr = (wave >> 1) * 2 + lh;
-    // (NB = 1: 32 dy channels, ONE row per thread: row (wave >> 1) * 2 + lh)
-    constexpr int DP = NB == 2 ? 2 : 1;                                       // dy rows per thread
-    const int sdc = NB == 2 ? lane : li, sdr = (wave >> 1) * 2 + (NB == 2 ? 0 : lh);
-    float xsc = 1.f, xsh = 0.f;
+    const int sxr = (wave >> 1) * 2 + lh, sdr = sxr;
+    const int st = li >> 3, sq = li & 7;
+    f32x4 xsc = {1.f, 1.f, 1.f, 1.f}, xsh = {0.f, 0.f, 0.f, 0.f};
     if (AFF) {
-        xsc = in_scale[c0 + sxc];
-        xsh = in_shift[c0 + sxc];
+        xsc = *reinterpret_cast<const f32x4 *>(in_scale + c0 + 4 * sq);
+        xsh = *reinterpret_cast<const f32x4 *>(in_shift + c0 + 4 * sq);
     }
     const int xrowb = W * Cin * 4, drowb = W * Cout * 4, xpixb = Cin * 4, dpixb = Cout * 4;
-    // whole-tensor buffer descriptors (the host checks that both tensors stay below 4 GiB); image-border pixels / rows are
+    // whole-tensor buffer descriptors (the host checks that both tensors stay below 2 GiB); image-border pixels / rows are
     // redirected out of range (0x80000000 exceeds num_records: the load returns 0)
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, (int)((size_t)N * H * W * Cin * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dy), 0, (int)((size_t)N * H * W * Cout * 4), 0x00020000);
-    const int wxl = (sxc * 32 + ((run ^ ((sxc >> 3) & 1)) << 4));             // lane part of an x write
-    const int wdl = (sdc * 32 + ((run ^ ((sdc >> 3) & 1)) << 4));             // ... of a dy write (64 channels: two 32-channel blocks of 1 KB)
+    // lane part of the four dword stores of a transformed value (channel 4 sq + k -> slot 4 sq + ((k + sq) & 3)); x and dy alike
+    int wl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wl[k] = (4 * sq + ((k + sq) & 3)) * 32 + ((run ^ ((sq >> 1) & 1)) << 4) + st * 4;
 
     for (int item = split; item < nitems; item += nsplit) {
         const int seg = item % nseg;
@@ -164,73 +165,80 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
         const int n = qok ? q / runsW : 0, rw = qok ? q - (q / runsW) * runsW : 0;
         const int t0 = seg * seg_steps;                                       // first tile row of the segment
         const int nsteps = min(seg_steps, H / 4 - t0);
-        const unsigned xbase = (unsigned)(((size_t)n * H * W + (size_t)rw * 16) * Cin + c0) * 4u + (unsigned)sxc * 4u;
-        const unsigned dbase = (unsigned)(((size_t)n * H * W + (size_t)rw * 16) * Cout + co0) * 4u + (unsigned)sdc * 4u;
-        const bool edgeL = rw == 0, edgeR = rw == runsW - 1;
+        // byte offset of the item's first always-in-image pixel (column 16 rw + 4 st) in row 0 of the sample, at the thread's quad
+        const unsigned xbase = (unsigned)(((size_t)n * H * W + (size_t)rw * 16 + 4 * st) * Cin + c0 + 4 * sq) * 4u;
+        const unsigned dbase = (unsigned)(((size_t)n * H * W + (size_t)rw * 16 + 4 * st) * Cout + co0 + 4 * sq) * 4u;
+        // only column -1 (pixel 0 of tile 0) and column 16 (pixel 5 of tile 3) of a run can leave the image sideways
+        const bool offL = rw == 0 && st == 0, offR = rw == runsW - 1 && st == 3;
 
-        // x pixels of image row gy (any, also -1 / H), columns 16 rw - 1 .. 16 rw + 16, of the thread's channel; W-transformed
-        // -> six <4 tiles> values
-        float xpx[18];
+        // x pixels of image row gy (any, also -1 / H), columns 16 rw + 4 st - 1 .. + 4, of the thread's channel quad
+        f32x4 xpx[6];
         auto x_load = [&](int gy) {
             const bool rowok = qok && gy >= 0 && gy < H;
             const int vrow = rowok ? (int)(xbase + (unsigned)gy * (unsigned)xrowb) : (int)0x80000000;
-            // columns 0 .. 15 of the run through the scalar offset; the two neighbours (column -1 / 16) have offsets of their own
-            const int vL = (rowok && !edgeL) ? vrow - xpixb : (int)0x80000000;
-            const int vR = (rowok && !edgeR) ? vrow + 16 * xpixb : (int)0x80000000;
-            xpx[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vL, 0, 0));
+            // pixels 1 .. 4 through the scalar offset; the two outer ones have offsets of their own (the scalar offset is not
+            // part of the range check)
+            const int vL = (rowok && !offL) ? vrow - xpixb : (int)0x80000000;
+            const int vR = (rowok && !offR) ? vrow : (int)0x80000000;
+            xpx[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vL, 0, 0));
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
-                xpx[1 + k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vrow, k * xpixb, 0));
-            xpx[17] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vR, 0, 0));
+            for (int i = 1; i < 5; ++i)
+                xpx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vrow, (i - 1) * xpixb, 0));
+            xpx[5] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vR, 4 * xpixb, 0));
         };
-        auto x_store = [&](int gy, int slot) {
-            f32x4 c[6], t0_, t1_, t2_, t3_, t4_, t5_;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) c[i] = f32x4{xpx[i], xpx[4 + i], xpx[8 + i], xpx[12 + i]};     // pixel i of the run's four tiles
+        // affine + W transform, in place: xpx[nu] afterwards
+        auto x_prep = [&](int gy) {
             if (AFF) {
-                // x' = scale x + shift inside the image, 0 outside (the loads returned 0 there): only column -1 (pixel 0 of tile 0)
-                // and column 16 (pixel 5 of tile 3) of the run can leave the image sideways
+                // x' = scale x + shift inside the image, 0 outside (the loads returned 0 there)
                 const bool rowok = qok && gy >= 0 && gy < H;
-                const float sh = rowok ? xsh : 0.f;
-                const f32x4 shv = {sh, sh, sh, sh};
-                f32x4 sh0 = shv, sh5 = shv;
-                sh0[0] = edgeL ? 0.f : sh;
-                sh5[3] = edgeR ? 0.f : sh;
-                const f32x4 scv = {xsc, xsc, xsc, xsc};                      // (per lane: the lane's channel)
-                c[0] = pkfma4v(c[0], scv, sh0);
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 shv = rowok ? xsh : zero;
+                xpx[0] = pkfma4v(xpx[0], xsc, offL ? zero : shv);
 #pragma unroll
-                for (int i = 1; i < 5; ++i) c[i] = pkfma4v(c[i], scv, shv);
-                c[5] = pkfma4v(c[5], scv, sh5);
+                for (int i = 1; i < 5; ++i) xpx[i] = pkfma4v(xpx[i], xsc, shv);
+                xpx[5] = pkfma4v(xpx[5], xsc, offR ? zero : shv);
             }
-            bt6v2(c, t0_, t1_, t2_, t3_, t4_, t5_);
-            char *dst = ldsb + slot * XROWB + wxl;
-            *reinterpret_cast<f32x4 *>(dst + 0 * XNU) = t0_;
-            *reinterpret_cast<f32x4 *>(dst + 1 * XNU) = t1_;
-            *reinterpret_cast<f32x4 *>(dst + 2 * XNU) = t2_;
-            *reinterpret_cast<f32x4 *>(dst + 3 * XNU) = t3_;
-            *reinterpret_cast<f32x4 *>(dst + 4 * XNU) = t4_;
-            *reinterpret_cast<f32x4 *>(dst + 5 * XNU) = t5_;
+            bt6v(xpx);
         };
-        float dpx[DP][16];
-        auto d_load = [&](int trow) {                                          // dy rows 4 trow + sdr, + 1 (always inside the image)
+        // the four transposing stores of plane nu (wx[k]: lane part + row slot of the thread's row)
+        int wx[4];
+        auto x_wr = [&](int nu) {
 #pragma unroll
-            for (int p = 0; p < DP; ++p) {
-                const int vrow = qok ? (int)(dbase + (unsigned)(4 * trow + sdr + p) * (unsigned)drowb) : (int)0x80000000;
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    dpx[p][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, vrow, k * dpixb, 0));
-            }
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<float *>(ldsb + wx[k] + nu * XNU) = xpx[nu][k];
         };
-        auto d_store = [&](int buf) {
+        f32x4 dpx[NB][4], de, dq;
+        auto d_load = [&](int trow) {                                          // dy row 4 trow + sdr (always inside the image)
+            const int vrow = qok ? (int)(dbase + (unsigned)(4 * trow + sdr) * (unsigned)drowb) : (int)0x80000000;
 #pragma unroll
-            for (int p = 0; p < DP; ++p) {
-                f32x4 v[4], t[6];
+            for (int cb = 0; cb < NB; ++cb)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = f32x4{dpx[p][i], dpx[p][4 + i], dpx[p][8 + i], dpx[p][12 + i]};
-                a6v(v, t);
-                char *dst = ldsb + XBYTES + buf * DBUF + (sdr + p) * DROWB + wdl;
+                for (int i = 0; i < 4; ++i)
+                    dpx[cb][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, vrow, cb * 128 + i * dpixb, 0));
+        };
+        // 4 -> 6 points (a6v) in three parts, each followed by its stores: planes (0, 1), (2, 3), (4, 5).  Plane 0 / 5 are pixels
+        // 0 / 3 themselves; de / dq carry the even / odd sums from one part to the next (12 live registers instead of 24)
+        int wd[4];                                                             // lane part + row + buffer of the step's dy stores
+        auto d_put = [&](int cb, int nu, const f32x4 &v) {
 #pragma unroll
-                for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<f32x4 *>(dst + nu * DNU) = t[nu];
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<float *>(ldsb + wd[k] + cb * 1024 + nu * DNU) = v[k];
+        };
+        auto d_part = [&](int cb, int part) {
+            auto fm = [](float k, f32x4 a_, f32x4 b_) { return pkfma4(k, a_, b_); };
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4(&v)[4] = dpx[cb];
+            if (part == 0) {
+                de = fm(A2, v[2], v[0]);
+                dq = fm(A3, v[3], fm(PA, v[1], z));
+                d_put(cb, 0, v[0]);
+                d_put(cb, 1, de + dq);
+            } else if (part == 1) {
+                d_put(cb, 2, fm(-1.f, dq, de));
+                de = fm(B2, v[2], v[0]);
+                dq = fm(B3, v[3], fm(PB, v[1], z));
+                d_put(cb, 3, de + dq);
+            } else {
+                d_put(cb, 4, fm(-1.f, dq, de));
+                d_put(cb, 5, v[3]);
             }
         };
 
@@ -238,13 +246,28 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
         __syncthreads();                                                       // (the previous item's readers are done)
         x_load(4 * t0 - 1 + sxr);
         d_load(t0);
-        x_store(4 * t0 - 1 + sxr, sxr);
+        x_prep(4 * t0 - 1 + sxr);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wx[k] = wl[k] + sxr * XROWB;
+#pragma unroll
+        for (int nu = 0; nu < 6; ++nu) x_wr(nu);
         if (sxr < 2) {
             x_load(4 * t0 + 3 + sxr);
-            x_store(4 * t0 + 3 + sxr, 4 + sxr);
+            x_prep(4 * t0 + 3 + sxr);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wx[k] = wl[k] + (4 + sxr) * XROWB;
+#pragma unroll
+            for (int nu = 0; nu < 6; ++nu) x_wr(nu);
         }
-        d_store(0);
-        // requests of step 1 (its four new x rows: window rows 2 .. 5; its dy rows)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wd[k] = wl[k] + XBYTES + sdr * DROWB;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            d_part(cb, 0);
+            d_part(cb, 1);
+            d_part(cb, 2);
+        }
+        // requests of step 1 (its four new x rows: window rows 2 .. 5; its dy rows) -- stored during step 0
         x_load(4 * (t0 + 1) + 1 + sxr);
         d_load(t0 + 1);
         __syncthreads();
@@ -253,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
         for (int k = 0; k < nsteps; ++k) {
             const int buf = k & 1;
             // ---- the wave's operands of the step.  x: rows of the window for its two columns; dy: the rows of its columns, first
-            // 32-channel block (the second block's are requested under the first block's MFMAs)
+            // 32-channel block (the second block's are read under the first block's MFMAs)
             f32x4 a[9], b[9];
             f32x4 vF[4], vH[4], zH;
             auto d_reads = [&](int cb) {
@@ -271,21 +294,40 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
                 for (int s = 0; s < 6; ++s) b[s] = t[s];
                 a3v(vH, zH, b[6], b[7], b[8], K1d, K2d, K3d);
             };
-            auto mfmas = [&](int cb) {
-#pragma unroll
-                for (int s = 0; s < 9; ++s) {
-                    if (W4W_WHATIF & 1) continue;
-                    if (s < 8) {
-                        acc[s][cb] = mfma32(a[s][0], b[s][0], acc[s][cb]);
-                        acc[s][cb] = mfma32(a[s][1], b[s][1], acc[s][cb]);
-                        acc[s][cb] = mfma32(a[s][2], b[s][2], acc[s][cb]);
-                        acc[s][cb] = mfma32(a[s][3], b[s][3], acc[s][cb]);
-                        asm volatile("" : "+a"(acc[s][cb]));
-                    } else {
-                        mfma32x4_vgpr(acc[s][cb], make_float4(a[s][0], a[s][1], a[s][2], a[s][3]),
-                                      make_float4(b[s][0], b[s][1], b[s][2], b[s][3]));
-                    }
+            auto mfma4 = [&](int s, int cb) {
+                if (W4W_WHATIF & 1) return;
+                if (s < 8) {
+                    acc[s][cb] = mfma32(a[s][0], b[s][0], acc[s][cb]);
+                    acc[s][cb] = mfma32(a[s][1], b[s][1], acc[s][cb]);
+                    acc[s][cb] = mfma32(a[s][2], b[s][2], acc[s][cb]);
+                    acc[s][cb] = mfma32(a[s][3], b[s][3], acc[s][cb]);
+                    asm volatile("" : "+a"(acc[s][cb]));
+                } else {
+                    mfma32x4_vgpr(acc[s][cb], make_float4(a[s][0], a[s][1], a[s][2], a[s][3]),
+                                  make_float4(b[s][0], b[s][1], b[s][2], b[s][3]));
                 }
+            };
+            // The staging of step k + 1 (loads requested one step ago) rides between the MFMA groups of this step: its stores go to
+            // the four ring slots OUTSIDE the step's window and to the other dy buffer, so nothing orders them against this step's
+            // reads and ONE barrier per step (at its end) is enough; the LDS store path (64 B / clock / CU: ~1 150 cycles of a step)
+            // and the waits for the loads then run under the matrix work instead of in a phase of their own.  Task t of the list:
+            //   0 x affine + W transform | 1, 2, 3 x planes (0, 1) (2, 3) (4, 5), then the requests of step k + 2's x rows |
+            //   4, 5, 6 dy block 0: 4 -> 6 points and its planes, pairwise | [NB = 2] 7: this step's block-1 operands are read |
+            //   9, 10, 11 dy block 1 | last: the requests of step k + 2's dy rows
+            const int gyn = 4 * (t0 + k + 1) + 1 + sxr;
+            auto side = [&](int t) {
+                if (t == 0) x_prep(gyn);
+                if (t >= 1 && t <= 3) {
+                    x_wr(2 * (t - 1));
+                    x_wr(2 * (t - 1) + 1);
+                }
+                if (t == 3) x_load(4 * (t0 + k + 2) + 1 + sxr);                // (clamped by the row test: unused past the end)
+                if (t >= 4 && t <= 6) d_part(0, t - 4);
+                if (NB == 2) {
+                    if (t == 7) d_reads(1);
+                    if (t >= 9 && t <= 11) d_part(1, t - 9);
+                }
+                if (t == (NB == 2 ? 11 : 6)) d_load(min(t0 + k + 2, H / 4 - 1));
             };
             tstamp(0);
             {
@@ -293,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
                     int sl = rot + i;
-                    sl = sl >= 6 ? sl - 6 : sl;
+                    sl = sl >= XSLOTS ? sl - XSLOTS : sl;
                     so[i] = sl * XROWB;                                        // (uniform)
                 }
                 const char *xp = ldsb + lx;
@@ -306,50 +348,44 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
                 cZ[0] = *reinterpret_cast<const f32x4 *>(xp + nuH * XNU + (hh ? so[1] : so[0]));
                 cZ[1] = *reinterpret_cast<const f32x4 *>(xp + nuH * XNU + (hh ? so[3] : so[2]));
                 cZ[2] = *reinterpret_cast<const f32x4 *>(xp + nuH * XNU + (hh ? so[5] : so[4]));
-                if (W4W_ORDER == 1 || W4W_ORDER == 2) d_reads(0);
-                __builtin_amdgcn_sched_barrier(0);
-                __syncthreads();                                               // every wave has read the window: its four oldest rows are free
-                if (W4W_ORDER >= 3) d_reads(0);                                // (their latency hides under the staging work)
-                __builtin_amdgcn_sched_barrier(0);
-                tstamp(1);
-                // ---- staging of step k + 1 (loads requested one step ago): x rows -> the slots the window just retired
-                {
-                    int sl = rot + sxr;                                        // window row sxr of step k = slot of new row 2 + sxr of step k + 1
-                    sl = sl >= 6 ? sl - 6 : sl;
-                    x_store(4 * (t0 + k + 1) + 1 + sxr, sl);
+                d_reads(0);
+                // slots of the new rows (window rows 6 .. 9 of this step), the other dy buffer
+                int sl = rot + 6 + sxr;
+                sl = sl >= XSLOTS ? sl - XSLOTS : sl;
+#pragma unroll
+                for (int k_ = 0; k_ < 4; ++k_) {
+                    wx[k_] = wl[k_] + sl * XROWB;
+                    wd[k_] = wl[k_] + XBYTES + (buf ^ 1) * DBUF + sdr * DROWB;
                 }
-                d_store(buf ^ 1);
-                // requests of step k + 2 (clamped to the image: unused past the end)
-                x_load(4 * (t0 + k + 2) + 1 + sxr);
-                d_load(min(t0 + k + 2, H / 4 - 1));
-                __builtin_amdgcn_sched_barrier(0);
-                tstamp(2);
                 bt6v2(cF, a[0], a[1], a[2], a[3], a[4], a[5]);
                 bt3v(cP, cZ, a[6], a[7], a[8], K2x, KPx);
             }
-            if (W4W_TIMING) __builtin_amdgcn_sched_barrier(0);
-            tstamp(3);
-            if (W4W_ORDER == 0) d_reads(0);
             d_xform();
             __builtin_amdgcn_sched_barrier(0);
-            tstamp(4);
-            if (NB == 2 && (W4W_ORDER == 2 || W4W_ORDER == 4)) d_reads(1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas(0);
-            __builtin_amdgcn_sched_barrier(0);
-            tstamp(5);
+            tstamp(1);
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                side(s);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma4(s, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            tstamp(2);
             if (NB == 2) {
-                if (W4W_ORDER != 2 && W4W_ORDER != 4) d_reads(1);
                 d_xform();
                 __builtin_amdgcn_sched_barrier(0);
-                tstamp(6);
-                mfmas(1);
-                __builtin_amdgcn_sched_barrier(0);
-                tstamp(7);
+#pragma unroll
+                for (int s = 0; s < 9; ++s) {
+                    side(9 + s);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma4(s, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            rot = rot + 4 >= 6 ? rot - 2 : rot + 4;
-            __syncthreads();                                                   // step k + 1's rows are in LDS
-            tstamp(8);
+            tstamp(3);
+            rot = rot + 4 >= XSLOTS ? rot + 4 - XSLOTS : rot + 4;
+            __syncthreads();                                                   // step k + 1's rows are in LDS, this step's are read
+            tstamp(4);
 #if W4W_TIMING
             ++tstep;
 #endif

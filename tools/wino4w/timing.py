@@ -1,9 +1,8 @@
 #!/usr/bin/env python3
 """Where a workgroup of the F(4x4)-domain weight-gradient kernel spends a step: s_memtime stamps written by wave 0 of ONE
 workgroup of a launch built with -DW4W_TIMING=1 (bash tools/build_variant.sh w4w_timing wino4w.hip -DW4W_TIMING=1; run with
-ADYOLO_LIB=ad-yolo_amd/variants/lib_w4w_timing.so).  Stamps per step: 0 top, 1 window read + barrier passed, 2 staging of the next
-step done (transforms, LDS writes, load requests), 3 x operands transformed, 4 dy operands of block 0 read + transformed, 5 its 36
-MFMAs issued, 6 / 7 the same for block 1, 8 end-of-step barrier passed."""
+ADYOLO_LIB=ad-yolo_amd/variants/lib_w4w_timing.so).  Stamps per step: 0 top, 1 operands of block 0 ready (window + dy reads,
+H transforms), 2 block 0 issued (36 MFMAs with the staging tasks between them), 3 block 1, 4 end-of-step barrier passed."""
 import ctypes
 import os
 import sys
@@ -24,7 +23,7 @@ for st in (4, 2, 1):
         x = torch.randn(B, h, w, cin, device="cuda:0")
         dy = torch.randn(B, h, w, cout, device="cuda:0")
         sc, sh = torch.rand(cin, device="cuda:0") + 0.5, torch.randn(cin, device="cuda:0")
-        ns = _lib.call("adyolo_wino4_wgrad_slabs", B, h, w, cin, cout)
+        ns = _lib.load().adyolo_wino4_wgrad_slabs(B, h, w, cin, cout)
         slabs = torch.empty(ns * 36 * cin * cout, device="cuda:0")
         du = torch.empty(36 * cin * cout, device="cuda:0")
         dw = torch.empty(cout, cin, 3, 3, device="cuda:0")
@@ -38,15 +37,12 @@ for st in (4, 2, 1):
             ev1.record()
         torch.cuda.synchronize()
         t = tb.cpu().view(12, 16).double()
-        labels = ["window read + barrier", "staging", "x transform", "dy read + transform 0", "MFMA 0", "dy read + transform 1", "MFMA 1",
-                  "end barrier"]
+        labels = ["operands (LDS reads + transforms)", "block 0 (36 MFMAs + staging)", "block 1", "end barrier"]
         print("stage %d affine=%d: launch + finish %.3f ms" % (st, aff, ev0.elapsed_time(ev1)), flush=True)
         for k in range(3, 9):
             if t[k, 0] == 0 or t[k + 1, 0] == 0:
                 continue
-            nb2 = t[k, 6] != 0
-            seq = [0, 1, 2, 3, 4, 5, 6, 7, 8] if nb2 else [0, 1, 2, 3, 4, 5, 8]
-            labs = labels if nb2 else labels[:5] + labels[7:]
-            parts = ["%s %.0f" % (lab, float(t[k, b] - t[k, a])) for a, b, lab in zip(seq[:-1], seq[1:], labs)]
-            print("  step %d: %.0f ticks (to next top %.0f) | %s" % (k, float(t[k, 8] - t[k, 0]), float(t[k + 1, 0] - t[k, 0]),
+            seq = [0, 1, 2, 3, 4]
+            parts = ["%s %.0f" % (lab, float(t[k, b] - t[k, a])) for a, b, lab in zip(seq[:-1], seq[1:], labels)]
+            print("  step %d: %.0f ticks (to next top %.0f) | %s" % (k, float(t[k, 4] - t[k, 0]), float(t[k + 1, 0] - t[k, 0]),
                                                                    " | ".join(parts)), flush=True)
