@@ -202,9 +202,14 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
         };
         // the four transposing stores of plane nu (wx[k]: lane part + row slot of the thread's row)
         int wx[4];
-        auto x_wr = [&](int nu) {
+        // (planes pairwise, the two stores of a lane address next to each other: they merge into one ds_write2st64_b32 --
+        //  3 source dwords, 6 cycles of the store path instead of 2 x 4)
+        auto x_wr2 = [&](int nu) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) *reinterpret_cast<float *>(ldsb + wx[k] + nu * XNU) = xpx[nu][k];
+            for (int k = 0; k < 4; ++k) {
+                *reinterpret_cast<float *>(ldsb + wx[k] + nu * XNU) = xpx[nu][k];
+                *reinterpret_cast<float *>(ldsb + wx[k] + (nu + 1) * XNU) = xpx[nu + 1][k];
+            }
         };
         f32x4 dpx[NB][4], de, dq;
         auto d_load = [&](int trow) {                                          // dy row 4 trow + sdr (always inside the image)
@@ -218,9 +223,12 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
         // 4 -> 6 points (a6v) in three parts, each followed by its stores: planes (0, 1), (2, 3), (4, 5).  Plane 0 / 5 are pixels
         // 0 / 3 themselves; de / dq carry the even / odd sums from one part to the next (12 live registers instead of 24)
         int wd[4];                                                             // lane part + row + buffer of the step's dy stores
-        auto d_put = [&](int cb, int nu, const f32x4 &v) {
+        auto d_put2 = [&](int cb, int nu, const f32x4 &v, const f32x4 &v1) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) *reinterpret_cast<float *>(ldsb + wd[k] + cb * 1024 + nu * DNU) = v[k];
+            for (int k = 0; k < 4; ++k) {
+                *reinterpret_cast<float *>(ldsb + wd[k] + cb * 1024 + nu * DNU) = v[k];
+                *reinterpret_cast<float *>(ldsb + wd[k] + cb * 1024 + (nu + 1) * DNU) = v1[k];
+            }
         };
         auto d_part = [&](int cb, int part) {
             auto fm = [](float k, f32x4 a_, f32x4 b_) { return pkfma4(k, a_, b_); };
@@ -229,16 +237,14 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
             if (part == 0) {
                 de = fm(A2, v[2], v[0]);
                 dq = fm(A3, v[3], fm(PA, v[1], z));
-                d_put(cb, 0, v[0]);
-                d_put(cb, 1, de + dq);
+                d_put2(cb, 0, v[0], de + dq);
             } else if (part == 1) {
-                d_put(cb, 2, fm(-1.f, dq, de));
+                const f32x4 t2 = fm(-1.f, dq, de);
                 de = fm(B2, v[2], v[0]);
                 dq = fm(B3, v[3], fm(PB, v[1], z));
-                d_put(cb, 3, de + dq);
+                d_put2(cb, 2, t2, de + dq);
             } else {
-                d_put(cb, 4, fm(-1.f, dq, de));
-                d_put(cb, 5, v[3]);
+                d_put2(cb, 4, fm(-1.f, dq, de), v[3]);
             }
         };
 
@@ -250,14 +256,14 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
 #pragma unroll
         for (int k = 0; k < 4; ++k) wx[k] = wl[k] + sxr * XROWB;
 #pragma unroll
-        for (int nu = 0; nu < 6; ++nu) x_wr(nu);
+        for (int nu = 0; nu < 6; nu += 2) x_wr2(nu);
         if (sxr < 2) {
             x_load(4 * t0 + 3 + sxr);
             x_prep(4 * t0 + 3 + sxr);
 #pragma unroll
             for (int k = 0; k < 4; ++k) wx[k] = wl[k] + (4 + sxr) * XROWB;
 #pragma unroll
-            for (int nu = 0; nu < 6; ++nu) x_wr(nu);
+            for (int nu = 0; nu < 6; nu += 2) x_wr2(nu);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) wd[k] = wl[k] + XBYTES + sdr * DROWB;
@@ -279,21 +285,26 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
             // 32-channel block (the second block's are read under the first block's MFMAs)
             f32x4 a[9], b[9];
             f32x4 vF[4], vH[4], zH;
-            auto d_reads = [&](int cb) {
+            f32x4 cF[6], cP[4], cZ[3];
+            auto d_reads_full = [&](int cb) {
                 const char *dp = ldsb + XBYTES + buf * DBUF + cb * 1024 + lx;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) vF[i] = *reinterpret_cast<const f32x4 *>(dp + nuF * DNU + i * DROWB);
+            };
+            auto d_reads_half = [&](int cb) {
+                const char *dp = ldsb + XBYTES + buf * DBUF + cb * 1024 + lx;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) vH[i] = *reinterpret_cast<const f32x4 *>(dp + nuH * DNU + i * DROWB);
                 zH = *reinterpret_cast<const f32x4 *>(dp + nuH * DNU + (hh ? 3 : 0) * DROWB);
             };
-            auto d_xform = [&]() {
+            // (full column first: its MFMAs start while the half column's reads are still in flight)
+            auto d_xform_full = [&]() {
                 f32x4 t[6];
                 a6v(vF, t);
 #pragma unroll
                 for (int s = 0; s < 6; ++s) b[s] = t[s];
-                a3v(vH, zH, b[6], b[7], b[8], K1d, K2d, K3d);
             };
+            auto d_xform_half = [&]() { a3v(vH, zH, b[6], b[7], b[8], K1d, K2d, K3d); };
             auto mfma4 = [&](int s, int cb) {
                 if (W4W_WHATIF & 1) return;
                 if (s < 8) {
@@ -311,23 +322,24 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
             // the four ring slots OUTSIDE the step's window and to the other dy buffer, so nothing orders them against this step's
             // reads and ONE barrier per step (at its end) is enough; the LDS store path (64 B / clock / CU: ~1 150 cycles of a step)
             // and the waits for the loads then run under the matrix work instead of in a phase of their own.  Task t of the list:
-            //   0 x affine + W transform | 1, 2, 3 x planes (0, 1) (2, 3) (4, 5), then the requests of step k + 2's x rows |
-            //   4, 5, 6 dy block 0: 4 -> 6 points and its planes, pairwise | [NB = 2] 7: this step's block-1 operands are read |
-            //   9, 10, 11 dy block 1 | last: the requests of step k + 2's dy rows
+            //   (1: the half columns' H transforms) | 2 x affine + W transform | 3, 4, 5 x planes (0, 1) (2, 3) (4, 5), then the
+            //   requests of step k + 2's x rows | 6, 7, 8 dy block 0: 4 -> 6 points and its planes, pairwise | [NB = 2] 8: this
+            //   step's block-1 operands are read | (10: their half column) | 11, 12, 13 dy block 1 | last: the requests of step
+            //   k + 2's dy rows
             const int gyn = 4 * (t0 + k + 1) + 1 + sxr;
             auto side = [&](int t) {
-                if (t == 0) x_prep(gyn);
-                if (t >= 1 && t <= 3) {
-                    x_wr(2 * (t - 1));
-                    x_wr(2 * (t - 1) + 1);
-                }
-                if (t == 3) x_load(4 * (t0 + k + 2) + 1 + sxr);                // (clamped by the row test: unused past the end)
-                if (t >= 4 && t <= 6) d_part(0, t - 4);
+                if (t == 2) x_prep(gyn);
+                if (t >= 3 && t <= 5) x_wr2(2 * (t - 3));
+                if (t == 5) x_load(4 * (t0 + k + 2) + 1 + sxr);                // (clamped by the row test: unused past the end)
+                if (t >= 6 && t <= 8) d_part(0, t - 6);
                 if (NB == 2) {
-                    if (t == 7) d_reads(1);
-                    if (t >= 9 && t <= 11) d_part(1, t - 9);
+                    if (t == 8) {
+                        d_reads_full(1);
+                        d_reads_half(1);
+                    }
+                    if (t >= 11 && t <= 13) d_part(1, t - 11);
                 }
-                if (t == (NB == 2 ? 11 : 6)) d_load(min(t0 + k + 2, H / 4 - 1));
+                if (t == (NB == 2 ? 13 : 8)) d_load(min(t0 + k + 2, H / 4 - 1));
             };
             tstamp(0);
             {
@@ -339,16 +351,16 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
                     so[i] = sl * XROWB;                                        // (uniform)
                 }
                 const char *xp = ldsb + lx;
-                f32x4 cF[6], cP[4], cZ[3];
 #pragma unroll
                 for (int i = 0; i < 6; ++i) cF[i] = *reinterpret_cast<const f32x4 *>(xp + nuF * XNU + so[i]);
+                d_reads_full(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) cP[i] = *reinterpret_cast<const f32x4 *>(xp + nuH * XNU + so[1 + i]);
                 // rows hh, hh + 2, hh + 4 of the half column (the single term's operands)
                 cZ[0] = *reinterpret_cast<const f32x4 *>(xp + nuH * XNU + (hh ? so[1] : so[0]));
                 cZ[1] = *reinterpret_cast<const f32x4 *>(xp + nuH * XNU + (hh ? so[3] : so[2]));
                 cZ[2] = *reinterpret_cast<const f32x4 *>(xp + nuH * XNU + (hh ? so[5] : so[4]));
-                d_reads(0);
+                d_reads_half(0);
                 // slots of the new rows (window rows 6 .. 9 of this step), the other dy buffer
                 int sl = rot + 6 + sxr;
                 sl = sl >= XSLOTS ? sl - XSLOTS : sl;
@@ -358,25 +370,29 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
                     wd[k_] = wl[k_] + XBYTES + (buf ^ 1) * DBUF + sdr * DROWB;
                 }
                 bt6v2(cF, a[0], a[1], a[2], a[3], a[4], a[5]);
-                bt3v(cP, cZ, a[6], a[7], a[8], K2x, KPx);
             }
-            d_xform();
+            d_xform_full();
             __builtin_amdgcn_sched_barrier(0);
             tstamp(1);
 #pragma unroll
             for (int s = 0; s < 9; ++s) {
                 side(s);
+                if (s == 1) {
+                    bt3v(cP, cZ, a[6], a[7], a[8], K2x, KPx);
+                    d_xform_half();
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 mfma4(s, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             tstamp(2);
             if (NB == 2) {
-                d_xform();
+                d_xform_full();
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s = 0; s < 9; ++s) {
                     side(9 + s);
+                    if (s == 1) d_xform_half();
                     __builtin_amdgcn_sched_barrier(0);
                     mfma4(s, 1);
                     __builtin_amdgcn_sched_barrier(0);
