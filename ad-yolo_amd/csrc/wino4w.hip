@@ -278,89 +278,132 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
         d_load(t0 + 1);
         __syncthreads();
 
+        // ---- the step loop.  The wave's operands of a step: x rows of the window for its two columns (a), dy rows of its columns
+        // (b: first 32-channel block, then the second); H transforms here, in the GEMM waves.
+        f32x4 a[9], b[9];
+        f32x4 vF[4], vH[4], zH;
+        f32x4 cF[6], cP[4], cZ[3];
+        auto d_reads_full = [&](int buf_, int cb) {
+            const char *dp = ldsb + XBYTES + buf_ * DBUF + cb * 1024 + lx;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vF[i] = *reinterpret_cast<const f32x4 *>(dp + nuF * DNU + i * DROWB);
+        };
+        auto d_reads_half = [&](int buf_, int cb) {
+            const char *dp = ldsb + XBYTES + buf_ * DBUF + cb * 1024 + lx;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vH[i] = *reinterpret_cast<const f32x4 *>(dp + nuH * DNU + i * DROWB);
+            zH = *reinterpret_cast<const f32x4 *>(dp + nuH * DNU + (hh ? 3 : 0) * DROWB);
+        };
+        auto d_xform_full = [&]() {
+            f32x4 t[6];
+            a6v(vF, t);
+#pragma unroll
+            for (int s = 0; s < 6; ++s) b[s] = t[s];
+        };
+        auto d_xform_half = [&]() { a3v(vH, zH, b[6], b[7], b[8], K1d, K2d, K3d); };
+        // window reads of a step whose window row 0 sits in ring slot rot_: the full column, the half column
+        auto x_reads_full = [&](int rot_) {
+            const char *xp = ldsb + lx + nuF * XNU;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                int sl = rot_ + i;
+                sl = sl >= XSLOTS ? sl - XSLOTS : sl;
+                cF[i] = *reinterpret_cast<const f32x4 *>(xp + sl * XROWB);
+            }
+        };
+        auto x_reads_half = [&](int rot_) {
+            int so[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                int sl = rot_ + i;
+                sl = sl >= XSLOTS ? sl - XSLOTS : sl;
+                so[i] = sl * XROWB;                                            // (uniform)
+            }
+            const char *xp = ldsb + lx + nuH * XNU;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cP[i] = *reinterpret_cast<const f32x4 *>(xp + so[1 + i]);
+            // rows hh, hh + 2, hh + 4 of the half column (the single term's operands)
+            cZ[0] = *reinterpret_cast<const f32x4 *>(xp + (hh ? so[1] : so[0]));
+            cZ[1] = *reinterpret_cast<const f32x4 *>(xp + (hh ? so[3] : so[2]));
+            cZ[2] = *reinterpret_cast<const f32x4 *>(xp + (hh ? so[5] : so[4]));
+        };
+        auto mfma4 = [&](int s, int cb) {
+            if (W4W_WHATIF & 1) return;
+            if (s < 8) {
+                acc[s][cb] = mfma32(a[s][0], b[s][0], acc[s][cb]);
+                acc[s][cb] = mfma32(a[s][1], b[s][1], acc[s][cb]);
+                acc[s][cb] = mfma32(a[s][2], b[s][2], acc[s][cb]);
+                acc[s][cb] = mfma32(a[s][3], b[s][3], acc[s][cb]);
+                asm volatile("" : "+a"(acc[s][cb]));
+            } else {
+                mfma32x4_vgpr(acc[s][cb], make_float4(a[s][0], a[s][1], a[s][2], a[s][3]),
+                              make_float4(b[s][0], b[s][1], b[s][2], b[s][3]));
+            }
+        };
+        // The staging of step k + 1 (loads requested one step ago) rides between the MFMA groups of step k: its stores go to the
+        // four ring slots OUTSIDE the step's window and to the other dy buffer, so nothing orders them against this step's reads
+        // and ONE barrier per step is enough; the LDS store path (64 B / clock / CU: ~1 150 cycles of a step) and the waits for
+        // the loads then run under the matrix work instead of in a phase of their own.  Side task t of a step (between MFMA
+        // groups t - 1 and t; NB = 2: 18 groups, NB = 1: 9):
+        //   1 the half columns' H transforms | 2 x affine + W transform | 3, 4, 5 x planes (0, 1) (2, 3) (4, 5), then the requests
+        //   of step k + 2's x rows | 6, 7, 8 dy block 0: 4 -> 6 points and its planes, pairwise
+        //   NB = 2: 8 also: this step's block-1 operands are read | 10 their half column | 11, 12, 13 dy block 1, then the
+        //   requests of step k + 2's dy rows | 14 THE BARRIER (step k + 1's rows are in LDS; every read of this step's is done) |
+        //   15 step k + 1's full columns are read (the registers of a[0 .. 5], b[0 .. 5] are free from group 14 on) | 16 their H
+        //   transforms | 17 its half columns are read -- the next step starts with its operands in registers
+        //   NB = 1: the barrier ends the step, the operands are read and transformed behind it
         int rot = 0;                                                           // slot of window row 0 of the current step
+        auto next_rot = [&](int r_) { return r_ + 4 >= XSLOTS ? r_ + 4 - XSLOTS : r_ + 4; };
+        auto top_full = [&](int rot_, int buf_) {
+            x_reads_full(rot_);
+            d_reads_full(buf_, 0);
+        };
+        auto top_half = [&](int rot_, int buf_) {
+            x_reads_half(rot_);
+            d_reads_half(buf_, 0);
+        };
+        auto top_xform = [&]() {
+            bt6v2(cF, a[0], a[1], a[2], a[3], a[4], a[5]);
+            d_xform_full();
+        };
+        if (NB == 2) {
+            top_full(0, 0);
+            top_half(0, 0);
+            top_xform();
+        }
         for (int k = 0; k < nsteps; ++k) {
             const int buf = k & 1;
-            // ---- the wave's operands of the step.  x: rows of the window for its two columns; dy: the rows of its columns, first
-            // 32-channel block (the second block's are read under the first block's MFMAs)
-            f32x4 a[9], b[9];
-            f32x4 vF[4], vH[4], zH;
-            f32x4 cF[6], cP[4], cZ[3];
-            auto d_reads_full = [&](int cb) {
-                const char *dp = ldsb + XBYTES + buf * DBUF + cb * 1024 + lx;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) vF[i] = *reinterpret_cast<const f32x4 *>(dp + nuF * DNU + i * DROWB);
-            };
-            auto d_reads_half = [&](int cb) {
-                const char *dp = ldsb + XBYTES + buf * DBUF + cb * 1024 + lx;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) vH[i] = *reinterpret_cast<const f32x4 *>(dp + nuH * DNU + i * DROWB);
-                zH = *reinterpret_cast<const f32x4 *>(dp + nuH * DNU + (hh ? 3 : 0) * DROWB);
-            };
-            // (full column first: its MFMAs start while the half column's reads are still in flight)
-            auto d_xform_full = [&]() {
-                f32x4 t[6];
-                a6v(vF, t);
-#pragma unroll
-                for (int s = 0; s < 6; ++s) b[s] = t[s];
-            };
-            auto d_xform_half = [&]() { a3v(vH, zH, b[6], b[7], b[8], K1d, K2d, K3d); };
-            auto mfma4 = [&](int s, int cb) {
-                if (W4W_WHATIF & 1) return;
-                if (s < 8) {
-                    acc[s][cb] = mfma32(a[s][0], b[s][0], acc[s][cb]);
-                    acc[s][cb] = mfma32(a[s][1], b[s][1], acc[s][cb]);
-                    acc[s][cb] = mfma32(a[s][2], b[s][2], acc[s][cb]);
-                    acc[s][cb] = mfma32(a[s][3], b[s][3], acc[s][cb]);
-                    asm volatile("" : "+a"(acc[s][cb]));
-                } else {
-                    mfma32x4_vgpr(acc[s][cb], make_float4(a[s][0], a[s][1], a[s][2], a[s][3]),
-                                  make_float4(b[s][0], b[s][1], b[s][2], b[s][3]));
-                }
-            };
-            // The staging of step k + 1 (loads requested one step ago) rides between the MFMA groups of this step: its stores go to
-            // the four ring slots OUTSIDE the step's window and to the other dy buffer, so nothing orders them against this step's
-            // reads and ONE barrier per step (at its end) is enough; the LDS store path (64 B / clock / CU: ~1 150 cycles of a step)
-            // and the waits for the loads then run under the matrix work instead of in a phase of their own.  Task t of the list:
-            //   (1: the half columns' H transforms) | 2 x affine + W transform | 3, 4, 5 x planes (0, 1) (2, 3) (4, 5), then the
-            //   requests of step k + 2's x rows | 6, 7, 8 dy block 0: 4 -> 6 points and its planes, pairwise | [NB = 2] 8: this
-            //   step's block-1 operands are read | (10: their half column) | 11, 12, 13 dy block 1 | last: the requests of step
-            //   k + 2's dy rows
             const int gyn = 4 * (t0 + k + 1) + 1 + sxr;
+            const int rotn = next_rot(rot);
             auto side = [&](int t) {
+                if (t == 1) {
+                    bt3v(cP, cZ, a[6], a[7], a[8], K2x, KPx);
+                    d_xform_half();
+                }
                 if (t == 2) x_prep(gyn);
                 if (t >= 3 && t <= 5) x_wr2(2 * (t - 3));
                 if (t == 5) x_load(4 * (t0 + k + 2) + 1 + sxr);                // (clamped by the row test: unused past the end)
                 if (t >= 6 && t <= 8) d_part(0, t - 6);
                 if (NB == 2) {
                     if (t == 8) {
-                        d_reads_full(1);
-                        d_reads_half(1);
+                        d_reads_full(buf, 1);
+                        d_reads_half(buf, 1);
                     }
+                    if (t == 10) d_xform_half();
                     if (t >= 11 && t <= 13) d_part(1, t - 11);
+                    if (t == 14) __syncthreads();
+                    if (t == 15) top_full(rotn, buf ^ 1);
+                    if (t == 16) top_xform();
+                    if (t == 17) top_half(rotn, buf ^ 1);
                 }
                 if (t == (NB == 2 ? 13 : 8)) d_load(min(t0 + k + 2, H / 4 - 1));
             };
             tstamp(0);
+            if (NB == 1) {
+                top_full(rot, buf);
+                top_half(rot, buf);
+            }
             {
-                int so[6];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    int sl = rot + i;
-                    sl = sl >= XSLOTS ? sl - XSLOTS : sl;
-                    so[i] = sl * XROWB;                                        // (uniform)
-                }
-                const char *xp = ldsb + lx;
-#pragma unroll
-                for (int i = 0; i < 6; ++i) cF[i] = *reinterpret_cast<const f32x4 *>(xp + nuF * XNU + so[i]);
-                d_reads_full(0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) cP[i] = *reinterpret_cast<const f32x4 *>(xp + nuH * XNU + so[1 + i]);
-                // rows hh, hh + 2, hh + 4 of the half column (the single term's operands)
-                cZ[0] = *reinterpret_cast<const f32x4 *>(xp + nuH * XNU + (hh ? so[1] : so[0]));
-                cZ[1] = *reinterpret_cast<const f32x4 *>(xp + nuH * XNU + (hh ? so[3] : so[2]));
-                cZ[2] = *reinterpret_cast<const f32x4 *>(xp + nuH * XNU + (hh ? so[5] : so[4]));
-                d_reads_half(0);
                 // slots of the new rows (window rows 6 .. 9 of this step), the other dy buffer
                 int sl = rot + 6 + sxr;
                 sl = sl >= XSLOTS ? sl - XSLOTS : sl;
@@ -369,18 +412,13 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
                     wx[k_] = wl[k_] + sl * XROWB;
                     wd[k_] = wl[k_] + XBYTES + (buf ^ 1) * DBUF + sdr * DROWB;
                 }
-                bt6v2(cF, a[0], a[1], a[2], a[3], a[4], a[5]);
             }
-            d_xform_full();
+            if (NB == 1) top_xform();
             __builtin_amdgcn_sched_barrier(0);
             tstamp(1);
 #pragma unroll
             for (int s = 0; s < 9; ++s) {
                 side(s);
-                if (s == 1) {
-                    bt3v(cP, cZ, a[6], a[7], a[8], K2x, KPx);
-                    d_xform_half();
-                }
                 __builtin_amdgcn_sched_barrier(0);
                 mfma4(s, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -392,15 +430,14 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
 #pragma unroll
                 for (int s = 0; s < 9; ++s) {
                     side(9 + s);
-                    if (s == 1) d_xform_half();
                     __builtin_amdgcn_sched_barrier(0);
                     mfma4(s, 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             tstamp(3);
-            rot = rot + 4 >= XSLOTS ? rot + 4 - XSLOTS : rot + 4;
-            __syncthreads();                                                   // step k + 1's rows are in LDS, this step's are read
+            rot = rotn;
+            if (NB == 1) __syncthreads();                                      // step k + 1's rows are in LDS, this step's are read
             tstamp(4);
 #if W4W_TIMING
             ++tstep;
