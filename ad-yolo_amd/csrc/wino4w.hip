@@ -33,7 +33,7 @@ namespace adyolo {
 namespace w4 {
 
 #ifndef W4W_WHATIF
-#define W4W_WHATIF 0
+#define W4W_WHATIF 0      // timing-only builds (results invalid): bit 0 no MFMAs, bit 1 no staging (loads, transforms, stores)
 #endif
 #ifndef W4W_TIMING
 #define W4W_TIMING 0      // 1: wave 0 of one workgroup writes s_memtime stamps of the first steps of its first item to a buffer set
@@ -173,18 +173,24 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
 
         // x pixels of image row gy (any, also -1 / H), columns 16 rw + 4 st - 1 .. + 4, of the thread's channel quad
         f32x4 xpx[6];
-        auto x_load = [&](int gy) {
+        // (pixels i0 .. i1 - 1: the step loop issues them two at a time, between different MFMA groups -- a burst of 16-byte loads
+        //  from all four waves queues up behind the 64 B / clock of the L1 and stalls the issuing wave)
+        auto x_load = [&](int gy, int i0 = 0, int i1 = 6) {
             const bool rowok = qok && gy >= 0 && gy < H;
             const int vrow = rowok ? (int)(xbase + (unsigned)gy * (unsigned)xrowb) : (int)0x80000000;
             // pixels 1 .. 4 through the scalar offset; the two outer ones have offsets of their own (the scalar offset is not
             // part of the range check)
             const int vL = (rowok && !offL) ? vrow - xpixb : (int)0x80000000;
             const int vR = (rowok && !offR) ? vrow : (int)0x80000000;
-            xpx[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vL, 0, 0));
 #pragma unroll
-            for (int i = 1; i < 5; ++i)
-                xpx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vrow, (i - 1) * xpixb, 0));
-            xpx[5] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vR, 4 * xpixb, 0));
+            for (int i = i0; i < i1; ++i) {
+                if (i == 0)
+                    xpx[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vL, 0, 0));
+                else if (i == 5)
+                    xpx[5] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vR, 4 * xpixb, 0));
+                else
+                    xpx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vrow, (i - 1) * xpixb, 0));
+            }
         };
         // affine + W transform, in place: xpx[nu] afterwards
         auto x_prep = [&](int gy) {
@@ -212,12 +218,12 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
             }
         };
         f32x4 dpx[NB][4], de, dq;
-        auto d_load = [&](int trow) {                                          // dy row 4 trow + sdr (always inside the image)
+        auto d_load = [&](int trow, int cb0 = 0, int cb1 = NB, int i0 = 0, int i1 = 4) {   // dy row 4 trow + sdr (always inside the image)
             const int vrow = qok ? (int)(dbase + (unsigned)(4 * trow + sdr) * (unsigned)drowb) : (int)0x80000000;
 #pragma unroll
-            for (int cb = 0; cb < NB; ++cb)
+            for (int cb = cb0; cb < cb1; ++cb)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = i0; i < i1; ++i)
                     dpx[cb][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, vrow, cb * 128 + i * dpixb, 0));
         };
         // 4 -> 6 points (a6v) in three parts, each followed by its stores: planes (0, 1), (2, 3), (4, 5).  Plane 0 / 5 are pixels
@@ -376,27 +382,41 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
             const int gyn = 4 * (t0 + k + 1) + 1 + sxr;
             const int rotn = next_rot(rot);
             auto side = [&](int t) {
+                if ((W4W_WHATIF & 2) && t != 1 && t != 8 && t != 10 && t < 14) return;        // timing only: no staging
                 if (t == 1) {
                     bt3v(cP, cZ, a[6], a[7], a[8], K2x, KPx);
                     d_xform_half();
                 }
                 if (t == 2) x_prep(gyn);
                 if (t >= 3 && t <= 5) x_wr2(2 * (t - 3));
-                if (t == 5) x_load(4 * (t0 + k + 2) + 1 + sxr);                // (clamped by the row test: unused past the end)
+                // (requests of step k + 2, two at a time as their registers retire; rows past the end: clamped / out of range, unused)
+                const int gy2 = 4 * (t0 + k + 2) + 1 + sxr, tr2 = min(t0 + k + 2, H / 4 - 1);
+                if (t >= 4 && t <= 6) x_load(gy2, 2 * (t - 4), 2 * (t - 4) + 2);
                 if (t >= 6 && t <= 8) d_part(0, t - 6);
                 if (NB == 2) {
                     if (t == 8) {
                         d_reads_full(buf, 1);
                         d_reads_half(buf, 1);
                     }
-                    if (t == 10) d_xform_half();
+                    if (t == 9) d_load(tr2, 0, 1, 0, 2);
+                    if (t == 10) {
+                        d_xform_half();
+                        d_load(tr2, 0, 1, 2, 4);
+                    }
                     if (t >= 11 && t <= 13) d_part(1, t - 11);
                     if (t == 14) __syncthreads();
-                    if (t == 15) top_full(rotn, buf ^ 1);
-                    if (t == 16) top_xform();
+                    if (t == 15) {
+                        top_full(rotn, buf ^ 1);
+                        d_load(tr2, 1, 2, 0, 2);
+                    }
+                    if (t == 16) {
+                        top_xform();
+                        d_load(tr2, 1, 2, 2, 4);
+                    }
                     if (t == 17) top_half(rotn, buf ^ 1);
+                } else {
+                    if (t == 8) d_load(tr2);
                 }
-                if (t == (NB == 2 ? 13 : 8)) d_load(min(t0 + k + 2, H / 4 - 1));
             };
             tstamp(0);
             if (NB == 1) {
