@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     // ---- loads of the step
-                    if (live) {
+                    if (live && !(W4P_WHATIF & 64)) {
                         const int v = use + BR;
                         const int kgv = 2 * pr + v / UH;
                         bq[slot_] = bload(v % UH, kgv < nkg ? kgv : kgv - nkg);  // (wraps: the next patch uses the same U)
@@ -355,9 +355,11 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                     if (step == 16) a_reads_half(1);
                     if (step == 28) a_reads_full(0);                           // (bases: the next pair's already)
                     if (step == 32) a_reads_half(0);
-                    if (step == 25) st_load(pvA, 0, prn2, true);
-                    if (step == 16) st_load(pvB, 1, prn2, true);
-                    if (step == 8) st_load(pvA, 2, prn, lwave);
+                    if (!(W4P_WHATIF & 128)) {
+                        if (step == 25) st_load(pvA, 0, prn2, true);
+                        if (step == 16) st_load(pvB, 1, prn2, true);
+                        if (step == 8) st_load(pvA, 2, prn, lwave);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }

@@ -351,13 +351,14 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
         // and ONE barrier per step is enough; the LDS store path (64 B / clock / CU: ~1 150 cycles of a step) and the waits for
         // the loads then run under the matrix work instead of in a phase of their own.  Side task t of a step (between MFMA
         // groups t - 1 and t; NB = 2: 18 groups, NB = 1: 9):
-        //   1 the half columns' H transforms | 2 x affine + W transform | 3, 4, 5 x planes (0, 1) (2, 3) (4, 5), then the requests
-        //   of step k + 2's x rows | 6, 7, 8 dy block 0: 4 -> 6 points and its planes, pairwise
-        //   NB = 2: 8 also: this step's block-1 operands are read | 10 their half column | 11, 12, 13 dy block 1, then the
-        //   requests of step k + 2's dy rows | 14 THE BARRIER (step k + 1's rows are in LDS; every read of this step's is done) |
+        //   NB = 2: 1 the half columns' H transforms | 2 x affine + W transform | 3, 4, 5 x planes (0, 1) (2, 3) (4, 5) | 4, 5, 6 the
+        //   requests of step k + 2's x rows, two at a time as their registers retire | 6, 7, 8 dy block 0: 4 -> 6 points and its
+        //   planes, pairwise | 8 also: this step's block-1 operands are read | 9, 10 requests of dy block 0 | 10 block 1's half
+        //   column | 11, 12, 13 dy block 1 | 14 THE BARRIER (step k + 1's rows are in LDS; every read of this step's is done) |
         //   15 step k + 1's full columns are read (the registers of a[0 .. 5], b[0 .. 5] are free from group 14 on) | 16 their H
         //   transforms | 17 its half columns are read -- the next step starts with its operands in registers
-        //   NB = 1: the barrier ends the step, the operands are read and transformed behind it
+        //   NB = 1: the same in nine groups: 0 x transform | 1, 2, 3 x planes | 3, 4, 5 dy | 6 the barrier and the full-column
+        //   reads | 7 their transforms | 8 the half-column reads
         int rot = 0;                                                           // slot of window row 0 of the current step
         auto next_rot = [&](int r_) { return r_ + 4 >= XSLOTS ? r_ + 4 - XSLOTS : r_ + 4; };
         auto top_full = [&](int rot_, int buf_) {
@@ -372,28 +373,26 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
             bt6v2(cF, a[0], a[1], a[2], a[3], a[4], a[5]);
             d_xform_full();
         };
-        if (NB == 2) {
-            top_full(0, 0);
-            top_half(0, 0);
-            top_xform();
-        }
+        top_full(0, 0);
+        top_half(0, 0);
+        top_xform();
         for (int k = 0; k < nsteps; ++k) {
             const int buf = k & 1;
             const int gyn = 4 * (t0 + k + 1) + 1 + sxr;
             const int rotn = next_rot(rot);
             auto side = [&](int t) {
-                if ((W4W_WHATIF & 2) && t != 1 && t != 8 && t != 10 && t < 14) return;        // timing only: no staging
+                // (requests of step k + 2, two at a time as their registers retire; rows past the end: clamped / out of range, unused)
+                const int gy2 = 4 * (t0 + k + 2) + 1 + sxr, tr2 = min(t0 + k + 2, H / 4 - 1);
                 if (t == 1) {
                     bt3v(cP, cZ, a[6], a[7], a[8], K2x, KPx);
                     d_xform_half();
                 }
-                if (t == 2) x_prep(gyn);
-                if (t >= 3 && t <= 5) x_wr2(2 * (t - 3));
-                // (requests of step k + 2, two at a time as their registers retire; rows past the end: clamped / out of range, unused)
-                const int gy2 = 4 * (t0 + k + 2) + 1 + sxr, tr2 = min(t0 + k + 2, H / 4 - 1);
-                if (t >= 4 && t <= 6) x_load(gy2, 2 * (t - 4), 2 * (t - 4) + 2);
-                if (t >= 6 && t <= 8) d_part(0, t - 6);
                 if (NB == 2) {
+                    if ((W4W_WHATIF & 2) && t != 1 && t != 8 && t != 10 && t < 14) return;    // timing only: no staging
+                    if (t == 2) x_prep(gyn);
+                    if (t >= 3 && t <= 5) x_wr2(2 * (t - 3));
+                    if (t >= 4 && t <= 6) x_load(gy2, 2 * (t - 4), 2 * (t - 4) + 2);
+                    if (t >= 6 && t <= 8) d_part(0, t - 6);
                     if (t == 8) {
                         d_reads_full(buf, 1);
                         d_reads_half(buf, 1);
@@ -415,14 +414,20 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
                     }
                     if (t == 17) top_half(rotn, buf ^ 1);
                 } else {
-                    if (t == 8) d_load(tr2);
+                    if (t == 0) x_prep(gyn);
+                    if (t >= 1 && t <= 3) x_wr2(2 * (t - 1));
+                    if (t >= 2 && t <= 4) x_load(gy2, 2 * (t - 2), 2 * (t - 2) + 2);
+                    if (t >= 3 && t <= 5) d_part(0, t - 3);
+                    if (t == 5) d_load(tr2);
+                    if (t == 6) {
+                        __syncthreads();
+                        top_full(rotn, buf ^ 1);
+                    }
+                    if (t == 7) top_xform();
+                    if (t == 8) top_half(rotn, buf ^ 1);
                 }
             };
             tstamp(0);
-            if (NB == 1) {
-                top_full(rot, buf);
-                top_half(rot, buf);
-            }
             {
                 // slots of the new rows (window rows 6 .. 9 of this step), the other dy buffer
                 int sl = rot + 6 + sxr;
@@ -433,7 +438,6 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
                     wd[k_] = wl[k_] + XBYTES + (buf ^ 1) * DBUF + sdr * DROWB;
                 }
             }
-            if (NB == 1) top_xform();
             __builtin_amdgcn_sched_barrier(0);
             tstamp(1);
 #pragma unroll
@@ -457,7 +461,6 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
             }
             tstamp(3);
             rot = rotn;
-            if (NB == 1) __syncthreads();                                      // step k + 1's rows are in LDS, this step's are read
             tstamp(4);
 #if W4W_TIMING
             ++tstep;
