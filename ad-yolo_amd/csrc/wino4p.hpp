@@ -27,7 +27,8 @@
 #endif
 #ifndef W4P_WHATIF
 #define W4P_WHATIF 0      // timing-only builds (results invalid): bit 0 no reader half of the epilogue rounds, 1 no writer half, 2 no
-                          // output stores, 3 no xi pass (LDS reads), 4 no MFMAs, 5 no nu pass
+                          // output stores, 3 no xi pass (LDS reads), 4 no MFMAs, 5 no nu pass, 6 no B refills in the pair loop, 7 no staging
+                          // loads in it (profiles/r05_w4p_whatif_loads.txt)
 #endif
 
 namespace adyolo {
