@@ -542,12 +542,27 @@ static int wino4_wgrad_geometry(int N, int H, int W, int Cin, int Cout, int *npa
     int nsplit = 256 / nblk;
     if (nsplit < 1) nsplit = 1;
     const int steps = H / 4;
-    // fewest segments per pair that give every split at least one item; segments of at least 8 tile rows
-    int nseg = (nsplit + npairs - 1) / npairs;
-    if (nseg < 1) nseg = 1;
-    int seg_steps = (steps + nseg - 1) / nseg;
-    if (seg_steps < 8) seg_steps = steps < 8 ? steps : 8;
-    nseg = (steps + seg_steps - 1) / seg_steps;
+    // Segments per pair: the count that minimises the longest workgroup's work -- ceil(items / splits) items of seg_steps steps
+    // plus a prologue worth about two steps each -- among the counts that leave segments of at least 8 tile rows.  (The first
+    // version took the fewest segments that gave every split an item: 3 pairs x 3 segments on 8 splits left one workgroup
+    // with two items beside seven with one.)
+    int nseg = 1, seg_steps = steps;
+    {
+        long best = -1;
+        const int maxseg = steps >= 16 ? steps / 8 : 1;
+        for (int c = 1; c <= maxseg; ++c) {
+            const int ss = (steps + c - 1) / c;
+            const int ns = (steps + ss - 1) / ss;                  // segments that are not empty
+            const long items = (long)npairs * ns;
+            const int sp = nsplit < items ? nsplit : (int)items;
+            const long cost = ((items + sp - 1) / sp) * (long)(ss + 2);
+            if (best < 0 || cost < best) {
+                best = cost;
+                nseg = ns;
+                seg_steps = ss;
+            }
+        }
+    }
     const int nitems = npairs * nseg;
     if (nsplit > nitems) nsplit = nitems;
     if (npairs_o) *npairs_o = npairs;

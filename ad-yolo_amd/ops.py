@@ -146,14 +146,16 @@ def reload_thresholds():
     """ADYOLO_W4_MIN_K (64): smallest contraction that gets the F(4x4) form packed; ADYOLO_W4_MIN_K_ADDEND (32; 128 until the
     persistent kernel of round 5): the same for launches that add a tensor in their epilogue; ADYOLO_W4_MIN_WGS (200): below
     that many 64-channel x patch work items a launch stays on the F(2x2) kernel (two workgroups per CU); ADYOLO_W4W_MIN_WORK
-    (2^24): smallest (tile rows of 16-column runs) x Cin x Cout = N W/16 H/4 Cin Cout for the F(4x4)-domain weight gradient
-    (``wgrad_form``; measured crossover with the F(2x2)-domain kernel at 15-33 M at every stage: profiles/r05_w4w_small_batches.txt);
+    (6 M): smallest (tile rows of 16-column runs) x Cin x Cout = N W/16 H/4 Cin Cout for the F(4x4)-domain weight gradient
+    (``wgrad_form``; measured crossover with the F(2x2)-domain kernel at 3.3-6.5 M at every stage since the kernel stages between
+    its MFMA groups -- 16 x 20 s: 1.18-1.41 x at every block shape, 8 x 20 s: 0.8-0.9 x at the 3.3 M stage transitions, 1.0-1.3 x
+    from 6.5 M on: profiles/r05_w4w_small_shapes.txt; 2^24 with the first version of the kernel);
     ADYOLO_W4_MIN_K_32 (32): smallest contraction for the F(4x4) form with 32-channel OUTPUT blocks (stage 1's 32 -> 32 layers
     and the 64 -> 32 data-gradient: 1.04-1.14 x the F(2x2) kernel per launch, profiles/r05_w4p_nb1_ab.txt)."""
     W4_THRESHOLDS.update(min_k=int(os.environ.get("ADYOLO_W4_MIN_K", "64")),
                          min_k_addend=int(os.environ.get("ADYOLO_W4_MIN_K_ADDEND", "32")),
                          min_wgs=int(os.environ.get("ADYOLO_W4_MIN_WGS", "200")),
-                         min_wgrad_work=int(os.environ.get("ADYOLO_W4W_MIN_WORK", str(1 << 24))),
+                         min_wgrad_work=int(os.environ.get("ADYOLO_W4W_MIN_WORK", "6000000")),
                          min_k_32=int(os.environ.get("ADYOLO_W4_MIN_K_32", "32")))
     return dict(W4_THRESHOLDS)
 

@@ -491,7 +491,7 @@ def test_dispatch_table_at_the_bench_shape(ops):
     from adyolo_amd.features import FeatureExtractor
     from adyolo_amd.datasets import synthetic_audio, synthetic_targets
     from adyolo_amd.train import TrainStep
-    assert ops.reload_thresholds() == {"min_k": 64, "min_k_addend": 32, "min_wgs": 200, "min_wgrad_work": 1 << 24, "min_k_32": 32}
+    assert ops.reload_thresholds() == {"min_k": 64, "min_k_addend": 32, "min_wgs": 200, "min_wgrad_work": 6000000, "min_k_32": 32}
     assert ops.conv_algo() == "winograd4" and os.environ.get("ADYOLO_W4_PERSIST", "1") != "0"
     b, n = 16, 24000 * 60
     torch.manual_seed(100)

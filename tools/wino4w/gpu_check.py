@@ -52,9 +52,10 @@ SHAPES = {1: (2400, 64, 32, 32), 2: (1200, 32, 64, 64), 3: (600, 16, 128, 128), 
           34: (600, 16, 128, 256)}
 
 
-def bench(batch, iters, stages):
+def bench(batch, iters, stages, frames=2400):
     for st in stages:
         h, w, cin, cout = SHAPES[st]
+        h = h * frames // 2400
         x = torch.randn(batch, h, w, cin, device=DEV)
         dy = torch.randn(batch, h, w, cout, device=DEV)
         aff = (torch.rand(cin, device=DEV) + 0.5, torch.randn(cin, device=DEV))
@@ -86,6 +87,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--stages", default="1,2,3,4,12,23,34")
+    ap.add_argument("--frames", type=int, default=2400, help="input frames of the timed shapes (2400 = 60 s clips, 800 = 20 s)")
     a = ap.parse_args()
     if not a.skip_check:
         ok = True
@@ -96,7 +98,7 @@ def main():
             ok = check(*shp) and ok
         print("CHECK %s" % ("OK" if ok else "FAIL"), flush=True)
     if not a.skip_bench:
-        bench(a.batch, a.iters, [int(s) for s in a.stages.split(",")])
+        bench(a.batch, a.iters, [int(s) for s in a.stages.split(",")], a.frames)
 
 
 if __name__ == "__main__":
