@@ -25,6 +25,10 @@
 #define W4P_TIMING 0      // 1: one workgroup writes s_memtime stamps of its first patches to the stat_mean pointer (results stay valid
                           // for plain launches; tools/wino4/persist_timing.py)
 #endif
+#ifndef W4P_HOIST
+#define W4P_HOIST 1       // 0: the next patch's first requests from inside the last epilogue round (the first form), 1: before the epilogue's
+                          // first store unless an addend AND the BatchNorm-input statistics are fused (no registers for it there), 2: always
+#endif
 #ifndef W4P_WHATIF
 #define W4P_WHATIF 0      // timing-only builds (results invalid): bit 0 no reader half of the epilogue rounds, 1 no writer half, 2 no
                           // output stores, 3 no xi pass (LDS reads), 4 no MFMAs, 5 no nu pass, 6 no B refills in the pair loop, 7 no staging
@@ -401,6 +405,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
         // pointer arguments are read from the kernel-argument segment through an opaque copy of its address (offsets: the
         // kernel's signature), so that neither occupies registers across the pair loop.
         constexpr bool ST = (EPI & 1) != 0, AD = (EPI & 2) != 0, MK = (EPI & 4) != 0, AUX = (EPI & 8) != 0, SMK = (EPI & 16) != 0;
+        constexpr bool HOIST = W4P_HOIST == 2 || (W4P_HOIST == 1 && !(AD && AUX));
         typedef const char __attribute__((address_space(4))) *kargp_t;
         kargp_t kp = (kargp_t)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kp));
@@ -484,6 +489,15 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
 #pragma unroll
                     for (int b = 0; b < 4; ++b) ax[e][b] = load4(xrs_, off[e][b]);
             }
+            if (HOIST && rnd == 0) {
+                // (every launch but the identity / projection data-gradients with statistics: the next patch's first pixel requests go out before the epilogue's first store --
+                //  behind the stores of three rounds the twelve requests took 2 000-4 000 cycles to issue, the stores drain at
+                //  ~10 B / clock / CU; those two keep the late form, the 48 registers are not there: profiles/r05_w4p_hoisted_requests_ab.txt)
+                set_off(offF, false, nty, ntx, Wn);
+                xbF = x + (size_t)nn * xsample;
+                st_load(pvA, 0, 1, true);
+                st_load(pvB, 1, 1, true);
+            }
             __builtin_amdgcn_sched_barrier(0);
             // ---- writer: raw accumulators (rows rh * 8 .. + 7 of the 32 x 32 tile) of the wave's nine positions, straight from
             // the AccVGPRs; the registers are zeroed for the next patch while the stores drain
@@ -546,16 +560,18 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                     }
                 }
             }
-            if (rnd == 2 * NB - 1) {
+            if (rnd == (HOIST ? -1 : 2 * NB - 1)) {
                 // The next patch's first pixel requests, made here -- after the last LDS reads of the epilogue, when their registers
                 // are free -- so that they land under the rest of the round: rounds 0 / 1 of its pair 1 (its pair 0 was staged by the
                 // last pair above).  Without a next patch every offset is out of range.
                 __builtin_amdgcn_sched_barrier(0);
                 set_off(offF, false, nty, ntx, Wn);
                 xbF = x + (size_t)nn * xsample;
+                if (W4P_TIMING) tstamp(12);
                 st_load(pvA, 0, 1, true);
                 st_load(pvB, 1, 1, true);
                 __builtin_amdgcn_sched_barrier(0);
+                if (W4P_TIMING) tstamp(13);
             }
             // ---- nu direction and the pixels (ReLU: one wave-uniform branch per round around two copies of the loop)
             f32x4 smean = {0.f, 0.f, 0.f, 0.f}, sinv = smean;
@@ -615,6 +631,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
             if (!(W4P_WHATIF & 1)) {
                 if (relu) pixels(std::true_type{}); else pixels(std::false_type{});
             }
+            if (W4P_TIMING && rnd == 2 * NB - 1) tstamp(14);
             if (rnd == 2 * NB - 1) {
                 // ... and its first B fragments (L2 hits: the last pair requested them once already)
 #pragma unroll

@@ -11,8 +11,8 @@ import torch  # noqa: E402
 import adyolo_amd  # noqa: F401,E402
 from adyolo_amd import ops, _lib  # noqa: E402
 
-SHAPES = {2: (1200, 32, 64, 64), 3: (600, 16, 128, 128), 4: (600, 16, 256, 256)}
-for st in (2, 3, 4):
+SHAPES = {1: (2400, 64, 32, 32), 2: (1200, 32, 64, 64), 3: (600, 16, 128, 128), 4: (600, 16, 256, 256)}
+for st in (1, 2, 3, 4):
     h, w, cin, cout = SHAPES[st]
     x = torch.randn(64, h, w, cin, device="cuda:0")
     wt = torch.randn(cout, cin, 3, 3, device="cuda:0") * 0.05
@@ -36,4 +36,9 @@ for st in (2, 3, 4):
         for a, b, lab in zip(seq[:-1], seq[1:], labels):
             parts.append("%s %.0f" % (lab, float(t[p, b] - t[p, a])))
         parts.append("to next loop %.0f" % float(t[p + 1, 0] - t[p, 11]))
+        if t[p, 12] > 0:
+            last = 9 if t[p, 9] > 0 else 7                   # reader stamp of the last round (NB = 2: 9, NB = 1: 7)
+            w = 5 if t[p, 5] > 0 else 3
+            parts.append("LAST ROUND: xi pass %.0f, next-patch loads issued %.0f, pixels %.0f, B reload issued %.0f" % (
+                float(t[p, 12] - t[p, w]), float(t[p, 13] - t[p, 12]), float(t[p, 14] - t[p, 13]), float(t[p, last] - t[p, 14])))
         print("stage %d patch %d: period %.0f ticks | %s" % (st, p, period, " | ".join(parts)), flush=True)
