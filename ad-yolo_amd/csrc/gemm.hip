@@ -9,6 +9,9 @@
 namespace adyolo {
 
 constexpr int GBM = 128, GBN = 64, GBK = 32;
+#ifndef GEMM_PF
+#define GEMM_PF 1          // K tiles requested ahead of the one being staged (1 or 2)
+#endif
 
 // batched mode: blockIdx.z = outer * inner_count + inner; operand offsets = outer * o? + inner * i? (floats)
 struct GemmBatch {
@@ -175,8 +178,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void gemm_kern
         }
     }
     // software pipeline: the next K tile is fetched into registers while the current one feeds the matrix cores
-    float4 ra[4], rb[2];
-    auto fetch = [&](int k0) {
+    // (GEMM_PF register sets: the tile being staged and, with 2, the one after it -- requested two K tiles ahead)
+    auto fetch = [&](float4 (&ra)[4], float4 (&rb)[2], int k0) {
         if (fastA) {
             const int sa = TA ? k0 * lda * 4 : k0 * 4;
 #pragma unroll
@@ -316,8 +319,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void gemm_kern
             }
         }
     };
-    if (kbeg < kend) fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+    auto stage = [&](const float4 (&ra)[4], const float4 (&rb)[2]) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -332,7 +334,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void gemm_kern
             else *reinterpret_cast<float4 *>(&Bs[(idx / (BN / 4)) * B_LD + (idx % (BN / 4)) * 4]) = rb[i];
         }
         __syncthreads();
-        if (k0 + GBK < kend) fetch(k0 + GBK);
+    };
+    auto compute = [&]() {
 #pragma unroll
         for (int s = 0; s < GBK / 8; ++s) {
             float a[SM][4], b[SN][4];
@@ -366,7 +369,30 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void gemm_kern
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[sm][nt] = mfma32(a[sm][q], b[nt][q], acc[sm][nt]);
         }
+    };
+#if GEMM_PF == 2
+    float4 ra0[4], rb0[2], ra1[4], rb1[2];
+    if (kbeg < kend) fetch(ra0, rb0, kbeg);
+    if (kbeg + GBK < kend) fetch(ra1, rb1, kbeg + GBK);
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * GBK) {
+        stage(ra0, rb0);
+        if (k0 + 2 * GBK < kend) fetch(ra0, rb0, k0 + 2 * GBK);
+        compute();
+        if (k0 + GBK < kend) {
+            stage(ra1, rb1);
+            if (k0 + 3 * GBK < kend) fetch(ra1, rb1, k0 + 3 * GBK);
+            compute();
+        }
     }
+#else
+    float4 ra0[4], rb0[2];
+    if (kbeg < kend) fetch(ra0, rb0, kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+        stage(ra0, rb0);
+        if (k0 + GBK < kend) fetch(ra0, rb0, k0 + GBK);
+        compute();
+    }
+#endif
 #pragma unroll
     for (int sm = 0; sm < SM; ++sm)
 #pragma unroll

@@ -28,7 +28,7 @@ def _w4_thresholds_follow_the_environment(monkeypatch):
 
     def setenv(name, value, *a, **kw):
         real_setenv(name, value, *a, **kw)
-        if name.startswith("ADYOLO_W4_") and "adyolo_amd" in sys.modules:
+        if name.startswith("ADYOLO_W4") and "adyolo_amd" in sys.modules:       # (ADYOLO_W4_* and ADYOLO_W4W_*)
             from adyolo_amd import ops
             ops.reload_thresholds()
     monkeypatch.setenv = setenv

@@ -136,6 +136,34 @@ def test_conv3x3_dgrad_wgrad(ops, monkeypatch, n, h, w, cin, cout, algo):
         assert_close(nchw(dx), x.grad, 2e-5, "conv3x3 dgrad (%s)" % algo)
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,affine", [
+    (2, 8, 16, 32, 64, 0), (1, 8, 16, 32, 64, 1),           # one pair / half a pair, a single step
+    (3, 40, 16, 64, 64, 1), (5, 36, 32, 64, 128, 1),         # odd run counts: the last pair is half empty
+    (2, 64, 32, 32, 64, 0), (1, 100, 48, 32, 64, 1), (2, 24, 64, 64, 64, 0),      # widths of 2, 3, 4 runs
+    (4, 300, 32, 64, 64, 1), (6, 132, 16, 256, 256, 0),      # several segments per pair, several items per workgroup
+    (3, 28, 16, 96, 192, 1),                                 # 3 x 3 channel blocks
+    (2, 64, 64, 32, 32, 1), (3, 20, 48, 64, 32, 0), (1, 12, 16, 32, 96, 1),       # 32-channel output blocks (NB = 1)
+])
+def test_wino4_wgrad_every_geometry(ops, monkeypatch, n, h, w, cin, cout, affine):
+    """The F(4x4)-domain weight-gradient kernel (csrc/wino4w.hip) forced onto shapes far below its dispatch threshold: every
+    branch of its work split (pairs of runs, segments, half-empty pairs), both block widths and the fused BatchNorm affine,
+    against a float64 weight gradient.  Measured: <= 1.6e-6 of absmax (tools/wino4w/gpu_check.py)."""
+    monkeypatch.setenv("ADYOLO_W4W_MIN_WORK", "1")
+    assert ops.wgrad_form(cin, cout, "winograd4", (n, h, w))[0] == "wino4_wgrad_kernel"
+    g = torch.Generator().manual_seed(n * 100 + h + cin)
+    x = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64) * 0.7 + 0.3
+    dy = torch.randn(n, cout, h, w, generator=g, dtype=torch.float64) * 1e-2
+    scale, shift = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g)
+    xa = x * scale.double()[None, :, None, None] + shift.double()[None, :, None, None] if affine else x
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xa, wt, None, padding=1).backward(dy)
+    dw = ops.conv3x3_wgrad(dev(nhwc(x.float())), dev(nhwc(dy.float())), cin,
+                           in_affine=(dev(scale), dev(shift)) if affine else None, algo="winograd4")
+    torch.cuda.synchronize()
+    err = float((dw.double().cpu() - wt.grad).abs().max()) / float(wt.grad.abs().max())
+    assert err < 2e-5, "F(4x4)-domain wgrad: %.2e of absmax" % err
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout", [(2, 20, 64, 32, 32), (3, 17, 16, 64, 128), (2, 9, 32, 32, 64), (2, 37, 16, 128, 64)])
 @pytest.mark.parametrize("algo", ["direct", "winograd", "winograd4"])
 def test_conv3x3_fused_affine_mask_stats(ops, monkeypatch, n, h, w, cin, cout, algo):
