@@ -32,7 +32,7 @@
 #ifndef W4P_WHATIF
 #define W4P_WHATIF 0      // timing-only builds (results invalid): bit 0 no reader half of the epilogue rounds, 1 no writer half, 2 no
                           // output stores, 3 no xi pass (LDS reads), 4 no MFMAs, 5 no nu pass, 6 no B refills in the pair loop, 7 no staging
-                          // loads in it (profiles/r05_w4p_whatif_loads.txt)
+                          // loads in it (profiles/r05_w4p_whatif_loads.txt), 8 no ReLU-mask bit loads in the epilogue
 #endif
 
 namespace adyolo {
@@ -458,7 +458,9 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                         const int q = off[e][b] >> 4;
                         const int wo = off[e][b] >= 0 ? (q >> 6) * 32 + ((q >> 5) & 1) * 4 : (int)0x80000000;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) mk[e][b][k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, wo, k * 8, 0);
+                        for (int k = 0; k < 4; ++k)
+                            mk[e][b][k] = (W4P_WHATIF & 256) ? 0xffffffffu + (unsigned)wo * 0u
+                                                             : (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, wo, k * 8, 0);
                     }
             };
             auto squeeze = [&](const unsigned (&mk)[2][4][4]) {
