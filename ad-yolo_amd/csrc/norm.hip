@@ -8,6 +8,29 @@
 
 namespace adyolo {
 
+#ifndef ADYOLO_EW_NT
+#define ADYOLO_EW_NT 1      // the streamed tensors of the elementwise / reduction passes (0.3-1.3 GB each, read or written once per pass:
+                            // no cache level holds them until their next use) are read and written with the non-temporal hint:
+                            // the three big passes 0.67-0.72 -> 0.73-0.78 of 8 TB/s, -2.1 ms per step (profiles/r05_nt_ab.txt)
+#endif
+__device__ __forceinline__ float4 ew_ld(const float4 *p) {
+#if ADYOLO_EW_NT
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void ew_st(float4 *p, const float4 &v) {
+#if ADYOLO_EW_NT
+    const f32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(p));
+#else
+    *p = v;
+#endif
+}
+
+
 // ---- generic two-value column reduction over rows of a [N][HW][C] tensor ---------------------------------
 // grid (G, N); partial layout [2][N*G][C]
 template <class F>
@@ -51,7 +74,7 @@ __global__ __launch_bounds__(256) void reduce2_partial_kernel(F f, float *__rest
 struct StatsF {          // (x, x^2)
     const float *x; int HW, C;
     __device__ void operator()(int n, int r, int cx, float4 &a, float4 &b) const {
-        a = *reinterpret_cast<const float4 *>(x + ((size_t)n * HW + r) * C + cx * 4);
+        a = ew_ld(reinterpret_cast<const float4 *>(x + ((size_t)n * HW + r) * C + cx * 4));
         b = make_float4(a.x * a.x, a.y * a.y, a.z * a.z, a.w * a.w);
     }
 };
@@ -59,8 +82,8 @@ struct BnBwdF {          // (dy, dy * xhat)
     const float *dy, *x, *mean, *invstd; int HW, C;
     __device__ void operator()(int n, int r, int cx, float4 &a, float4 &b) const {
         const size_t o = ((size_t)n * HW + r) * C + cx * 4;
-        a = *reinterpret_cast<const float4 *>(dy + o);
-        const float4 xv = *reinterpret_cast<const float4 *>(x + o);
+        a = ew_ld(reinterpret_cast<const float4 *>(dy + o));
+        const float4 xv = ew_ld(reinterpret_cast<const float4 *>(x + o));
         const float4 m = *reinterpret_cast<const float4 *>(mean + cx * 4);
         const float4 is = *reinterpret_cast<const float4 *>(invstd + cx * 4);
         b = make_float4(a.x * (xv.x - m.x) * is.x, a.y * (xv.y - m.y) * is.y, a.z * (xv.z - m.z) * is.z,
@@ -71,15 +94,15 @@ struct SeBwdF {          // g = de * (e > 0): (g, g * xhat(c)); the mask comes f
     const float *de, *e, *c, *mean, *invstd; const unsigned long long *mask; int HW, C;
     __device__ void operator()(int n, int r, int cx, float4 &a, float4 &b) const {
         const size_t o = ((size_t)n * HW + r) * C + cx * 4;
-        const float4 d = *reinterpret_cast<const float4 *>(de + o);
-        const float4 cv = *reinterpret_cast<const float4 *>(c + o);
+        const float4 d = ew_ld(reinterpret_cast<const float4 *>(de + o));
+        const float4 cv = ew_ld(reinterpret_cast<const float4 *>(c + o));
         const float4 m = *reinterpret_cast<const float4 *>(mean + cx * 4);
         const float4 is = *reinterpret_cast<const float4 *>(invstd + cx * 4);
         bool px, py, pz, pw;
         if (mask) {
             mask_bits4(mask, o >> 2, px, py, pz, pw);
         } else {
-            const float4 ev = *reinterpret_cast<const float4 *>(e + o);
+            const float4 ev = ew_ld(reinterpret_cast<const float4 *>(e + o));
             px = ev.x > 0.f; py = ev.y > 0.f; pz = ev.z > 0.f; pw = ev.w > 0.f;
         }
         a = make_float4(px ? d.x : 0.f, py ? d.y : 0.f, pz ? d.z : 0.f, pw ? d.w : 0.f);
@@ -202,6 +225,7 @@ __global__ __launch_bounds__(256) void affine_kernel(const float *__restrict__ x
 #endif
 constexpr int EW_U = ADYOLO_EW_U;
 
+
 template <bool INV>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ gamma,
@@ -247,14 +271,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
             for (int u = 0; u < EW_U; ++u) {
                 const long i = i0 + u * 256;
                 if (i < n4) {
-                    d[u] = dy4[i];
-                    xv[u] = x4[i];
+                    d[u] = ew_ld(&dy4[i]);
+                    xv[u] = ew_ld(&x4[i]);
                 }
             }
 #pragma unroll
             for (int u = 0; u < EW_U; ++u) {
                 const long i = i0 + u * 256;
-                if (i < n4) dx4[i] = one(d[u], xv[u]);
+                if (i < n4) ew_st(&dx4[i], one(d[u], xv[u]));
             }
         }
     } else {
@@ -352,7 +376,7 @@ __global__ __launch_bounds__(256) void se_tail_fwd_kernel(
         o.y = fmaxf((cv.y * sc.y + sh.y) * sv.y + rv.y, 0.f);
         o.z = fmaxf((cv.z * sc.z + sh.z) * sv.z + rv.z, 0.f);
         o.w = fmaxf((cv.w * sc.w + sh.w) * sv.w + rv.w, 0.f);
-        e4[i] = o;
+        ew_st(&e4[i], o);
         if (mask) {      // the whole wave is here: i runs over 64-aligned groups of 64 and hw4 % 64 == 0
             const unsigned long long bx = __ballot(o.x > 0.f), by = __ballot(o.y > 0.f);
             const unsigned long long bz = __ballot(o.z > 0.f), bw = __ballot(o.w > 0.f);
@@ -369,8 +393,8 @@ __global__ __launch_bounds__(256) void se_tail_fwd_kernel(
             for (int u = 0; u < EW_U; ++u) {
                 const long i = i0 + u * 256;
                 if (i < hw4) {
-                    cv[u] = c4[i];
-                    rv[u] = r4[i];
+                    cv[u] = ew_ld(&c4[i]);
+                    rv[u] = ew_ld(&r4[i]);
                 }
             }
 #pragma unroll
@@ -481,7 +505,7 @@ __global__ __launch_bounds__(256) void se_tail_bwd_apply_kernel(
         o.y = ga.y * is.y * (g.y * sv.y + dp.y * invHW - a.y * invR - (cv.y - m.y) * is.y * b.y * invR);
         o.z = ga.z * is.z * (g.z * sv.z + dp.z * invHW - a.z * invR - (cv.z - m.z) * is.z * b.z * invR);
         o.w = ga.w * is.w * (g.w * sv.w + dp.w * invHW - a.w * invR - (cv.w - m.w) * is.w * b.w * invR);
-        dc4[i] = o;
+        ew_st(&dc4[i], o);
         if (dr4) dr4[i] = g;
     };
     if (INV) {
@@ -494,8 +518,8 @@ __global__ __launch_bounds__(256) void se_tail_bwd_apply_kernel(
             for (int u = 0; u < EW_U; ++u) {
                 const long i = i0 + u * 256;
                 if (i < hw4) {
-                    d[u] = de4[i];
-                    cv[u] = c4[i];
+                    d[u] = ew_ld(&de4[i]);
+                    cv[u] = ew_ld(&c4[i]);
                     if (mask) {
                         mask_bits4(mask, base + i, px[u], py[u], pz[u], pw[u]);
                     } else {
@@ -537,7 +561,7 @@ __global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float *__restri
         const int ho = (int)(p % Ho);
         const long n = p / Ho;
         const float4 *src = reinterpret_cast<const float4 *>(x) + (((size_t)n * H + 2 * ho) * W + 2 * wo) * c4n + cx;
-        const float4 a = src[0], b = src[c4n], c = src[(size_t)W * c4n], d = src[(size_t)W * c4n + c4n];
+        const float4 a = ew_ld(src), b = ew_ld(src + c4n), c = ew_ld(src + (size_t)W * c4n), d = ew_ld(src + (size_t)W * c4n + c4n);
         reinterpret_cast<float4 *>(y)[i] = make_float4(0.25f * (a.x + b.x + c.x + d.x), 0.25f * (a.y + b.y + c.y + d.y),
                                                        0.25f * (a.z + b.z + c.z + d.z), 0.25f * (a.w + b.w + c.w + d.w));
     }
@@ -554,7 +578,7 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float *__restri
         const int h = (int)(p % H);
         const long n = p / H;
         const float4 g = reinterpret_cast<const float4 *>(dy)[(((size_t)n * Ho + (h >> 1)) * Wo + (w >> 1)) * c4n + cx];
-        reinterpret_cast<float4 *>(dx)[i] = make_float4(0.25f * g.x, 0.25f * g.y, 0.25f * g.z, 0.25f * g.w);
+        ew_st(&reinterpret_cast<float4 *>(dx)[i], make_float4(0.25f * g.x, 0.25f * g.y, 0.25f * g.z, 0.25f * g.w));
     }
 }
 

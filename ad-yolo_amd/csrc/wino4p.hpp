@@ -29,6 +29,13 @@
 #define W4P_HOIST 1       // 0: the next patch's first requests from inside the last epilogue round (the first form), 1: before the epilogue's
                           // first store unless an addend AND the BatchNorm-input statistics are fused (no registers for it there), 2: always
 #endif
+#ifndef W4P_ST_AUX
+#define W4P_ST_AUX 2      // cache-policy bits of the output stores: 2 = non-temporal (the 0.3-1.3 GB outputs are read by the NEXT kernel:
+                          // no cache holds them; per launch -1 %, step -0.65 ms with the consumers' lost hits: profiles/r05_nt_ab.txt)
+#endif
+#ifndef W4P_OP_AUX
+#define W4P_OP_AUX 0      // ... of the fused operands' loads (addend, statistics input: each read once; 2 measured no gain)
+#endif
 #ifndef W4P_WHATIF
 #define W4P_WHATIF 0      // timing-only builds (results invalid): bit 0 no reader half of the epilogue rounds, 1 no writer half, 2 no
                           // output stores, 3 no xi pass (LDS reads), 4 no MFMAs, 5 no nu pass, 6 no B refills in the pair loop, 7 no staging
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ptr), 0, bytes, 0x00020000);
     };
     auto load4 = [&](const __amdgpu_buffer_rsrc_t &rs, int o_) {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o_, 0, 0));
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o_, 0, W4P_OP_AUX));
     };
 
     make_o(tid + opaque0());
@@ -615,7 +622,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                             for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
                         }
                         if (!(W4P_WHATIF & 4) || (e == 0 && b == 0))
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yrs, off[e][b], 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yrs, off[e][b], 0, W4P_ST_AUX);
                         if (ST) {
                             // out-of-image pixels and masked-out components count 0
                             const unsigned kin = ~(unsigned)(off[e][b] >> 31);
