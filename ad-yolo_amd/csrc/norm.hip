@@ -9,12 +9,12 @@
 namespace adyolo {
 
 #ifndef ADYOLO_EW_NT
-#define ADYOLO_EW_NT 1      // the streamed tensors of the elementwise / reduction passes (0.3-1.3 GB each, read or written once per pass:
+#define ADYOLO_EW_NT 3      // (bit 0: loads, bit 1: stores) the streamed tensors of the elementwise / reduction passes (0.3-1.3 GB each, read or written once per pass:
                             // no cache level holds them until their next use) are read and written with the non-temporal hint:
                             // the three big passes 0.67-0.72 -> 0.73-0.78 of 8 TB/s, -2.1 ms per step (profiles/r05_nt_ab.txt)
 #endif
 __device__ __forceinline__ float4 ew_ld(const float4 *p) {
-#if ADYOLO_EW_NT
+#if ADYOLO_EW_NT & 1
     const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
     return make_float4(v[0], v[1], v[2], v[3]);
 #else
@@ -22,7 +22,7 @@ __device__ __forceinline__ float4 ew_ld(const float4 *p) {
 #endif
 }
 __device__ __forceinline__ void ew_st(float4 *p, const float4 &v) {
-#if ADYOLO_EW_NT
+#if ADYOLO_EW_NT & 2
     const f32x4 t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(p));
 #else

@@ -35,6 +35,9 @@ namespace w4 {
 #ifndef W4W_WHATIF
 #define W4W_WHATIF 0      // timing-only builds (results invalid): bit 0 no MFMAs, bit 1 no staging (loads, transforms, stores)
 #endif
+#ifndef W4W_LD_AUX
+#define W4W_LD_AUX 0       // cache-policy bits of the x / dy loads (2 = non-temporal; A/B switch)
+#endif
 #ifndef W4W_TIMING
 #define W4W_TIMING 0      // 1: wave 0 of one workgroup writes s_memtime stamps of the first steps of its first item to a buffer set
                           // with adyolo_w4w_timing_buffer (results stay valid; tools/wino4w/timing.py)
@@ -185,11 +188,11 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
 #pragma unroll
             for (int i = i0; i < i1; ++i) {
                 if (i == 0)
-                    xpx[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vL, 0, 0));
+                    xpx[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vL, 0, W4W_LD_AUX));
                 else if (i == 5)
-                    xpx[5] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vR, 4 * xpixb, 0));
+                    xpx[5] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vR, 4 * xpixb, W4W_LD_AUX));
                 else
-                    xpx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vrow, (i - 1) * xpixb, 0));
+                    xpx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vrow, (i - 1) * xpixb, W4W_LD_AUX));
             }
         };
         // affine + W transform, in place: xpx[nu] afterwards
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
             for (int cb = cb0; cb < cb1; ++cb)
 #pragma unroll
                 for (int i = i0; i < i1; ++i)
-                    dpx[cb][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, vrow, cb * 128 + i * dpixb, 0));
+                    dpx[cb][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, vrow, cb * 128 + i * dpixb, W4W_LD_AUX));
         };
         // 4 -> 6 points (a6v) in three parts, each followed by its stores: planes (0, 1), (2, 3), (4, 5).  Plane 0 / 5 are pixels
         // 0 / 3 themselves; de / dq carry the even / odd sums from one part to the next (12 live registers instead of 24)
