@@ -33,6 +33,9 @@
 #define W4P_ST_AUX 2      // cache-policy bits of the output stores: 2 = non-temporal (the 0.3-1.3 GB outputs are read by the NEXT kernel:
                           // no cache holds them; per launch -1 %, step -0.65 ms with the consumers' lost hits: profiles/r05_nt_ab.txt)
 #endif
+#ifndef W4P_X_AUX
+#define W4P_X_AUX 0       // ... of the staged input's loads (A/B switch)
+#endif
 #ifndef W4P_OP_AUX
 #define W4P_OP_AUX 0      // ... of the fused operands' loads (addend, statistics input: each read once; 2 measured no gain)
 #endif
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int vo = round == 0 ? offF[j] : round == 1 ? offF[j] + RS * rowb : (on ? offL[j] : (int)0x80000000);
-            p[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, pr * 64, 0));
+            p[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, pr * 64, W4P_X_AUX));
         }
     };
     // (the pixels in flight are ext-vector values, not float4 structs: with the struct form the SLP vectoriser paired component
