@@ -320,6 +320,11 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                     const bool live = nt < NB;                                 //  the odd ones carry side work and loads only)
                     const int use = (half * 9 + s) * NB + (live ? nt : 0);
                     const int slot_ = use % BR;
+                    if (W4P_TIMING && (step % 6) == 0 && pr < 2) {
+                        if (blockIdx.x == 8 && tid == 0 && tpatch >= 1 && tpatch < 4)
+                            reinterpret_cast<unsigned long long *>(const_cast<float *>(stat_mean))[(6 + tpatch) * 16 + pr * 6 + step / 6] =
+                                __builtin_amdgcn_s_memtime();
+                    }
                     // ---- side work of the step
                     if (step == 2) a_xform_half();
                     if (step == 12) a_xform_full();

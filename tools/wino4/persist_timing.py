@@ -18,13 +18,13 @@ for st in (1, 2, 3, 4):
     wt = torch.randn(cout, cin, 3, 3, device="cuda:0") * 0.05
     wpk, _ = ops.pack_w3x3(wt, cin, want_dgrad=False, algo="winograd4")
     y = torch.empty(64, h, w, cout, device="cuda:0")
-    tb = torch.zeros(6 * 16, dtype=torch.int64, device="cuda:0")
+    tb = torch.zeros(12 * 16, dtype=torch.int64, device="cuda:0")
     s = torch.cuda.current_stream().cuda_stream
     for _ in range(2):
         _lib.call("adyolo_wino4_fwd", x.data_ptr(), wpk.data_ptr(), None, None, None, None, None, y.data_ptr(), None, None,
                   tb.data_ptr(), None, None, 64, h, w, cin, cout, 0, 0, s)
     torch.cuda.synchronize()
-    t = tb.cpu().view(6, 16).double()
+    t = tb.cpu().view(12, 16).double()
     # s_memtime ticks: everything relative to the stamp before it
     for p in range(1, 5):
         if t[p, 0] == 0 or t[p + 1, 0] == 0:
@@ -42,3 +42,8 @@ for st in (1, 2, 3, 4):
             parts.append("LAST ROUND: xi pass %.0f, next-patch loads issued %.0f, pixels %.0f, B reload issued %.0f" % (
                 float(t[p, 12] - t[p, w]), float(t[p, 13] - t[p, 12]), float(t[p, 14] - t[p, 13]), float(t[p, last] - t[p, 14])))
         print("stage %d patch %d: period %.0f ticks | %s" % (st, p, period, " | ".join(parts)), flush=True)
+        if p < 4 and t[6 + p, 0] > 0:
+            q = t[6 + p]
+            print("    pair loop, steps 0-6-12-18-24-30 of pair 0 | pair 1: %s | %s | pair 0 -> pair 1: %.0f" % (
+                " ".join("%.0f" % float(q[i + 1] - q[i]) for i in range(5)), " ".join("%.0f" % float(q[6 + i + 1] - q[6 + i]) for i in range(5)),
+                float(q[6] - q[0])), flush=True)
