@@ -9,6 +9,12 @@
 namespace adyolo {
 
 constexpr int GBM = 128, GBN = 64, GBK = 32;
+#ifndef GEMM_WHATIF
+#define GEMM_WHATIF 0        // timing-only builds (results invalid)
+#endif
+#ifndef GEMM_ST_NT
+#define GEMM_ST_NT 0         // 1: the vectorised epilogue's stores carry the non-temporal hint (A/B switch)
+#endif
 #ifndef GEMM_PF
 #define GEMM_PF 1          // K tiles requested ahead of the one being staged (1 or 2)
 #endif
@@ -44,8 +50,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void gemm_kern
     static_assert(BM * 8 == 4 * NTHR && BN * 8 == 2 * NTHR, "staging: 4 + 2 float4 per thread and K tile");
     constexpr int A_LD = TA ? (BM + 4) : (GBK + 4);
     constexpr int B_LD = TB ? (BN + 4) : (GBK + 4);
-    __shared__ __attribute__((aligned(16))) float As[TA ? GBK * (BM + 4) : BM * (GBK + 4)];
-    __shared__ __attribute__((aligned(16))) float Bs[TB ? GBK * (BN + 4) : BN * (GBK + 4)];
+    // One LDS array: the two operand tiles of the K loop, and after it (SM == 1) the per-wave transposition buffer of the
+    // vectorised epilogue -- [32 rows][32 SN + 4] floats per wave
+    constexpr int A_FLOATS = TA ? GBK * (BM + 4) : BM * (GBK + 4), B_FLOATS = TB ? GBK * (BN + 4) : BN * (GBK + 4);
+    constexpr bool VEPI = SM == 1 && !TA;               // (the transposed-A forms are the split-K weight gradients: measured 3-7 % slower with it)
+    constexpr int T_LD = 32 * SN + 4, T_FLOATS = VEPI ? WM * WN * 32 * T_LD : 0;
+    constexpr int SMEM_FLOATS = A_FLOATS + B_FLOATS > T_FLOATS ? A_FLOATS + B_FLOATS : T_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    float *As = smem, *Bs = smem + A_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const int li = lane & 31, lh = lane >> 5;
@@ -393,6 +405,52 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void gemm_kern
         compute();
     }
 #endif
+    // Vectorised epilogue (round 5): a wave's 32 x 32 SN block goes through LDS once (the MFMA result layout has a lane own ONE
+    // column: 16 dword stores per accumulator, 256 bytes per wave-instruction) and leaves as 16-byte stores, 4 rows x 256 bytes per
+    // wave-instruction -- 8 stores per lane instead of 32.  The dword form cost 9-43 % of a launch on the short-K shapes
+    // (profiles/r05_gemm_epilogue_ab.txt: what-if without stores, then this).  Needs N, the leading dimension and the pointers
+    // 16-byte aligned; anything else takes the scalar form below.
+    const size_t out_ld = slab_stride ? (size_t)slab_ld : (size_t)ldc;
+    const bool vec = VEPI && !(GEMM_WHATIF & 2) && !slab_stride && (N & 3) == 0 && (out_ld & 3) == 0 &&
+                     (reinterpret_cast<size_t>(C) & 15) == 0 && (!bias || (reinterpret_cast<size_t>(bias) & 15) == 0);
+    if (VEPI && vec) {
+        __syncthreads();                                  // every wave is done with the operand tiles
+        float *T = smem + wave * 32 * T_LD;
+#pragma unroll
+        for (int nt = 0; nt < SN; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[mfma_row(r, lane) * T_LD + nt * 32 + li] = acc[0][nt][r];
+        constexpr int Q = 8 * SN, RPI = 64 / Q;           // float4 per row, rows per wave-instruction
+        const int c4 = lane % Q, rsub = lane / Q;
+        const int nn = n0 + wn * 32 * SN + c4 * 4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias && !slab_stride && nn < N) bv = *reinterpret_cast<const float4 *>(bias + nn);
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int row = it * RPI + rsub;
+            const int m = m0 + wm * 32 + row;
+            float4 v = *reinterpret_cast<const float4 *>(&T[row * T_LD + c4 * 4]);
+            if (m < M && nn < N) {
+                if (slab_stride) {
+                    *reinterpret_cast<float4 *>(C + (size_t)z * slab_stride + (size_t)m * slab_ld + nn) = v;
+                } else {
+                    float4 *o = reinterpret_cast<float4 *>(C + (size_t)m * ldc + nn);
+                    v = make_float4(v.x * bt.alpha + bv.x, v.y * bt.alpha + bv.y, v.z * bt.alpha + bv.z, v.w * bt.alpha + bv.w);
+                    if (accumulate) {
+                        const float4 c0 = *o;
+                        v = make_float4(v.x + c0.x, v.y + c0.y, v.z + c0.z, v.w + c0.w);
+                    }
+#if GEMM_ST_NT
+                    const f32x4 t = {v.x, v.y, v.z, v.w};
+                    __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(o));
+#else
+                    *o = v;
+#endif
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int sm = 0; sm < SM; ++sm)
 #pragma unroll
@@ -401,7 +459,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void gemm_kern
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * SM + sm) * 32 + mfma_row(r, lane);
-                if (m < M && nn < N) {
+                if (m < M && nn < N && (!(GEMM_WHATIF & 1) || r == 0)) {      // (what-if bit 0: one store per accumulator tile)
                     if (slab_stride) {
                         C[(size_t)z * slab_stride + (size_t)m * slab_ld + nn] = acc[sm][nt][r];
                     } else {
