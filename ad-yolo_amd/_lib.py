@@ -103,6 +103,10 @@ SIGNATURES = {
     "adyolo_softmax_bwd": (I, [P, P, P, L, I, F, P]),
     "adyolo_avgpool1d_fwd": (I, [P, P, I, I, I, I, F, P]),
     "adyolo_avgpool1d_bwd": (I, [P, P, I, I, I, I, F, P]),
+    "adyolo_wino1d_in": (I, [P, P, I, I, I, P]),
+    "adyolo_wino1d_out": (I, [P, P, I, I, I, P]),
+    "adyolo_wino1d_dy": (I, [P, P, I, I, I, P]),
+    "adyolo_wino1d_filter": (I, [P, P, I, I, I, P]),
     "adyolo_ln_fwd": (I, [P] * 4 + [L, I, F, P]),
     "adyolo_ln_bwd": (I, [P] * 7 + [L, I, F, P]),
     "adyolo_attn_fwd": (I, [P] * 5 + [I, I, I, I, F, F, ctypes.c_uint32, P, P]),

@@ -706,6 +706,41 @@ class ConvFn(torch.autograd.Function):
         return dx, dw, None, None
 
 
+class Conv3x1WinoFn(torch.autograd.Function):
+    """3 x 1 convolution along H (stride 1, padding 1) on a map ONE bin wide -- x [N][H][1][Cin], w [Cout][Cin][3][1] -- as a 1-D
+    Winograd F(4, 3): half the matrix FLOPs of the implicit-GEMM form (``csrc/wino1d.hip``; the deep stages of the
+    ResNet-Conformer, reference resnet_conformer.py:353-393).  Keeps the transformed input V for the weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        n, h, _, cin = x.shape
+        cout = w.shape[0]
+        w3 = _c(w).view(cout, cin, 3)
+        y, v = ops.wino1d_conv(_c(x).view(n, h, cin), ops.wino1d_filter(w3, cout, cin, 0), n, h, cin, cout)
+        ctx.save_for_backward(v, w3)
+        ctx.geom = (n, h, cin, cout)
+        ctx.w = w                              # (storage address / shape for GradSink)
+        return y.view(n, h, 1, cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        v, w3 = ctx.saved_tensors
+        n, h, cin, cout = ctx.geom
+        dy3 = _c(dy).view(n, h, cout)
+        sunk = SINK.params(ctx.w)
+        dw = ops.wino1d_wgrad(v, dy3, n, h, cin, cout, out=sunk[0].view(cout, cin, 3) if sunk is not None else None)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx, _ = ops.wino1d_conv(dy3, ops.wino1d_filter(w3, cout, cin, 1), n, h, cout, cin)
+            dx = dx.view(n, h, 1, cin)
+        if sunk is not None:
+            SINK.done_params(ctx.w)
+            dw = None
+        else:
+            dw = dw.view(cout, cin, 3, 1)
+        return dx, dw
+
+
 class Conv3x3S1Fn(torch.autograd.Function):
     """Stride-1 3x3 convolution on the implicit-GEMM kernel (K2), no fusion."""
 

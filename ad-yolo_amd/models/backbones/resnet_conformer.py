@@ -50,12 +50,17 @@ def _conv3x3_s1(x, w):
     The filter rearrangements are differentiable torch views / copies of the (tiny) weight, so the untouched taps get
     exactly zero gradient, as in the reference."""
     n, h, wd, cin = x.shape
+    cout = w.shape[0]
     if wd == 1:
-        return Fn.ConvFn.apply(x, w[:, :, :, 1:2].contiguous(), (1, 1), (1, 0))
+        w1 = w[:, :, :, 1:2].contiguous()
+        if ops.wino1d_ok(n, h, cin, cout):        # long time axis: 1-D Winograd F(4, 3), half the matrix work (csrc/wino1d.hip)
+            return Fn.Conv3x1WinoFn.apply(x, w1)
+        return Fn.ConvFn.apply(x, w1, (1, 1), (1, 0))
     if wd == 2:
-        cout = w.shape[0]
         w2 = torch.stack((w[..., 1:3], w[..., 0:2]), 0)                     # [wo][co][ci][kh][wi]
         w2 = w2.permute(0, 1, 4, 2, 3).reshape(2 * cout, 2 * cin, 3, 1)
+        if ops.wino1d_ok(n, h, 2 * cin, 2 * cout):
+            return Fn.Conv3x1WinoFn.apply(x.view(n, h, 1, 2 * cin), w2).view(n, h, 2, cout)
         return Fn.ConvFn.apply(x.view(n, h, 1, 2 * cin), w2, (1, 1), (1, 0)).view(n, h, 2, cout)
     if wd <= 4:
         return Fn.ConvFn.apply(x, w, (1, 1), (1, 1))

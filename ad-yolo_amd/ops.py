@@ -864,6 +864,45 @@ def conv_out_hw(h, w, kh, kw, sh, sw, ph, pw):
     return (h + 2 * ph - kh) // sh + 1, (w + 2 * pw - kw) // sw + 1
 
 
+# ---------------------------------------------------------------------------------------------- 1-D Winograd F(4, 3) (K9w)
+def wino1d_ok(n, h, cin, cout):
+    """The 3 x 1 convolution along H (x [N][H][1][Cin]) takes the 1-D Winograd form: whole output tiles, GEMM-friendly channel
+    counts and enough rows to fill the chip with the six position GEMMs (``ADYOLO_WINO1D=0`` switches it off)."""
+    return (os.environ.get("ADYOLO_WINO1D", "1") != "0" and h % 4 == 0 and cin % 64 == 0 and cout % 64 == 0
+            and n * (h // 4) >= 2048)
+
+
+def wino1d_conv(x3, u, n, h, cin, cout):
+    """x3 [N][H][Cin], u [6][Cout][Cin] (``wino1d_filter`` mode 0 / 1) -> (y [N][H][Cout], V [6][N T][Cin])."""
+    rows = n * (h // 4)
+    v = _new(x3, 6, rows, cin)
+    _c("adyolo_wino1d_in", _p(x3), _p(v), n, h, cin, _stream())
+    m = _new(x3, 6, rows, cout)
+    gemm_batched(v, u, m, rows, cout, cin, cin, cin, cout, False, False, 6, 1, rows * cin, 0, cout * cin, 0, rows * cout, 0)
+    y = _new(x3, n, h, cout)
+    _c("adyolo_wino1d_out", _p(m), _p(y), n, h, cout, _stream())
+    return y, v
+
+
+def wino1d_filter(w3, cout, cin, mode):
+    """w3 [Cout][Cin][3] -> U [6][Cout][Cin] (mode 0) or [6][Cin][Cout] (mode 1: data gradient)."""
+    u = _new(w3, 6, cin if mode else cout, cout if mode else cin)
+    _c("adyolo_wino1d_filter", _p(w3), _p(u), cout, cin, mode, _stream())
+    return u
+
+
+def wino1d_wgrad(v, dy3, n, h, cin, cout, out=None):
+    """v [6][N T][Cin] (the forward's transformed input), dy3 [N][H][Cout] -> dw [Cout][Cin][3] (into ``out`` when given)."""
+    rows = n * (h // 4)
+    e = _new(dy3, 6, rows, cout)
+    _c("adyolo_wino1d_dy", _p(dy3), _p(e), n, h, cout, _stream())
+    du = _new(dy3, 6, cout, cin)
+    gemm_batched(e, v, du, cout, cin, rows, cout, cin, cin, True, True, 6, 1, rows * cout, 0, rows * cin, 0, cout * cin, 0)
+    dw = out if out is not None else _new(dy3, cout, cin, 3)
+    _c("adyolo_wino1d_filter", _p(dw), _p(du), cout, cin, 2, _stream())
+    return dw
+
+
 def conv_gemm(mode, src, other, n, h, w, cin, cout, kh, kw, sh, sw, ph, pw):
     """General strided convolution as an implicit GEMM (no column buffer), channels-last.
     mode 0: src x [N][H][W][Cin], other wk = pack_wk(w) -> y [N][Ho][Wo][Cout]

@@ -436,6 +436,23 @@ int adyolo_softmax_fwd(const float *s, float *p, long rows, int L, float scale, 
 int adyolo_softmax_bwd(const float *dp, const float *p, float *ds, long rows, int L, float scale, void *stream);
 int adyolo_avgpool1d_fwd(const float *x, float *y, int B, int T, int C, int k, float fac, void *stream);
 int adyolo_avgpool1d_bwd(const float *dy, float *dx, int B, int T, int C, int k, float fac, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K9w  1-D Winograd F(4, 3) along the time axis for the stride-1 3x3 convolutions of the ResNet-Conformer's deep stages, whose
+ *      maps are 1 bin wide (or 2 bins, folded into the channels): there torchvision BasicBlock's convolution (reference
+ *      resnet_conformer.py:353-393) IS a 3 x 1 one.  H % 4 == 0, C % 4 == 0; T = H / 4 tiles per sample.
+ *   wino1d_in     : x  [N][H][C] -> V [6][N T][C]  (B^T over the rows 4 t - 1 .. 4 t + 4; rows outside the sample are zeros)
+ *   wino1d_out    : M  [6][N T][C] -> y [N][H][C]  (A^T)
+ *   wino1d_dy     : dy [N][H][C] -> E [6][N T][C]  (A: the output gradient in the transform domain, for the weight gradient)
+ *   wino1d_filter : mode 0  U[p][co][ci] = sum_k G[p][k] w[co][ci][k]        (forward)
+ *                   mode 1  U[p][ci][co] = sum_k G[p][k] w[co][ci][2 - k]    (data gradient)
+ *                   mode 2  w[co][ci][k] = sum_p G[p][k] U[p][co][ci]        (weight gradient from dU; writes w)
+ *   The six position GEMMs between them are ONE adyolo_gemm_batched launch each way (M[p] = V[p] U[p]^T, dU[p] = E[p]^T V[p]).
+ * ---------------------------------------------------------------------------------------------- */
+int adyolo_wino1d_in(const float *x, float *V, int N, int H, int C, void *stream);
+int adyolo_wino1d_out(const float *M, float *y, int N, int H, int C, void *stream);
+int adyolo_wino1d_dy(const float *dy, float *E, int N, int H, int C, void *stream);
+int adyolo_wino1d_filter(float *w, float *U, int Cout, int Cin, int mode, void *stream);
 int adyolo_ln_fwd(const float *x, const float *gamma, const float *beta, float *y, long R, int C, float eps,
                   void *stream);
 int adyolo_ln_bwd(const float *dy, const float *x, const float *gamma, float *dx, float *dgamma, float *dbeta,

@@ -195,6 +195,27 @@ def test_conv3x3_fused_affine_mask_stats(ops, monkeypatch, n, h, w, cin, cout, a
     assert_close(dw, wr.grad, 2e-5, "wgrad through the fused affine")
 
 
+@pytest.mark.parametrize("n,h,cin,cout", [(2, 40, 64, 128), (1, 8, 128, 64), (3, 100, 64, 64), (5, 4, 192, 64)])
+def test_conv3x1_winograd_1d(ops, n, h, cin, cout):
+    """1-D Winograd F(4, 3) along the time axis (csrc/wino1d.hip, the ResNet-Conformer's one-bin-wide stages): forward, data
+    gradient and weight gradient of the 3 x 1 convolution against float64; zero padding at both ends of every sample."""
+    from adyolo_amd import functional as Fn
+    g = torch.Generator().manual_seed(11 * n + h + cin)
+    x = torch.randn(n, cin, h, 1, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(cout, cin, 3, 1, generator=g, dtype=torch.float64) / np.sqrt(3 * cin)).requires_grad_(True)
+    dy = torch.randn(n, cout, h, 1, generator=g, dtype=torch.float64)
+    y_ref = F.conv2d(x, w, None, padding=(1, 0))
+    y_ref.backward(dy)
+    xg = dev(nhwc(x.detach().float())).requires_grad_(True)
+    wg = dev(w.detach().float()).requires_grad_(True)
+    y = Fn.Conv3x1WinoFn.apply(xg, wg)
+    y.backward(dev(nhwc(dy.float())))
+    torch.cuda.synchronize()
+    for got, ref, what in ((nchw(y), y_ref, "y"), (nchw(xg.grad), x.grad, "dx"), (wg.grad, w.grad, "dw")):
+        err = float((got.detach().double().cpu() - ref.detach()).abs().max()) / float(ref.detach().abs().max())
+        assert err < 2e-5, "1-D Winograd %s: %.2e of absmax" % (what, err)
+
+
 # ------------------------------------------------------------------------------------------------ gemm
 @pytest.mark.parametrize("m,n,k,ta,tb,bias,splits", [
     (300, 2400, 256, False, False, True, 1),      # head
