@@ -602,6 +602,9 @@ extern "C" int adyolo_wino4_wgrad(const float *x, const float *dy, const float *
                    "wino4_wgrad: unsupported shape N=%d H=%d W=%d Cin=%d Cout=%d (needs Cin %% 32 == 0, Cout %% 32 == 0, W %% 16 == 0, "
                    "H %% 4 == 0, tensors below 2 GiB)", N, H, W, Cin, Cout);
     ADYOLO_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), ADYOLO_EINVAL, "wino4_wgrad: in_scale/in_shift come together");
+    // (16-byte loads of pixel quads and of the affine's channel quads)
+    ADYOLO_REQUIRE(((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(dy) | reinterpret_cast<size_t>(in_scale) |
+                     reinterpret_cast<size_t>(in_shift)) & 15) == 0, ADYOLO_ENOSUP, "wino4_wgrad: x, dy, in_scale, in_shift must be 16-byte aligned");
     hipStream_t st = as_stream(stream);
     int npairs, nseg, seg_steps, nitems, nblk;
     const int nsplit = w4::wino4_wgrad_geometry(N, H, W, Cin, Cout, &npairs, &nseg, &seg_steps, &nitems, &nblk);
