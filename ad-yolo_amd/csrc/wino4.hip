@@ -707,10 +707,16 @@ extern "C" int adyolo_wino4_fwd(const float *x, const float *u, const float *bia
     ADYOLO_REQUIRE(!stat_aux || (stats && stat_mean && stat_invstd), ADYOLO_EINVAL,
                    "wino4_fwd: stat_aux needs stats, stat_mean and stat_invstd");
     ADYOLO_REQUIRE(!stat_mask || stats, ADYOLO_EINVAL, "wino4_fwd: stat_mask needs stats");
-    const int tc = wino4_tc(W), tr = 32 / tc;
+    const int ncb = Cout / (32 * nb);
+    // Narrow maps (W <= 8: the middle stages of the ResNet-Conformer, 800 frames x 4 or 8 bins): plain launches take patches ONE
+    // or TWO tiles wide (128 x 4 / 64 x 8 pixels) on the persistent kernel instead of padding a 16-pixel-wide patch 4 or 2 times
+    // over (ADYOLO_W4_NARROW=0: the 16-wide patch)
+    const char *pe_ = getenv("ADYOLO_W4_PERSIST"), *ne_ = getenv("ADYOLO_W4_NARROW");
+    const bool narrow = W <= 8 && !stats && !addend && !addend_mask && !stat_aux && !stat_mask && !bias && !in_scale && nb == 2 &&
+                        ncb <= 8 && 8 % ncb == 0 && !(pe_ && pe_[0] == '0') && !(ne_ && ne_[0] == '0');
+    const int tc = narrow ? (W <= 4 ? 1 : 2) : wino4_tc(W), tr = 32 / tc;
     const int patchesW = cdiv(W, 4 * tc), patchesH = cdiv(H, 4 * tr);
     const int nsp = N * patchesH * patchesW;
-    const int ncb = Cout / (32 * nb);
     int xcd_div = 0, blocks = nsp * ncb;
     if (ncb <= 8 && 8 % ncb == 0) {
         xcd_div = 8 / ncb;

@@ -17,7 +17,7 @@ typedef unsigned int u32x4_t __attribute__((__vector_size__(16)));
 template <int TC>
 struct Cfg {
     static constexpr int TR = 32 / TC;                  // tile rows of a workgroup
-    static constexpr int LOG_TC = TC == 4 ? 2 : 3;
+    static constexpr int LOG_TC = TC == 1 ? 0 : TC == 2 ? 1 : TC == 4 ? 2 : 3;
     static constexpr int PR = 4 * TR + 2;               // patch rows
     static constexpr int PS = PR * TC + 2;              // plane stride in 16-byte slots (== 2 mod 8: conflict-free writes)
     static constexpr int CBS = 12 * PS + 4;             // slots per 8-channel buffer: 6 nu x 2 channel quads (== 4 mod 8)

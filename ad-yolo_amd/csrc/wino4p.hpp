@@ -716,6 +716,13 @@ void launch_wino4p(const W4Launch &a) {
     } else {                                                                                                               \
         if (a.in_scale) ADYOLO_WINO4P_FWD(4, true, NB_); else ADYOLO_WINO4P_FWD(4, false, NB_);                            \
     }
+    // narrow maps (W <= 8: the middle stages of the ResNet-Conformer): patches one or two tiles wide, plain launches only
+    if constexpr (EPI == 0) {
+        if (a.tc == 1 || a.tc == 2) {
+            if (a.tc == 1) ADYOLO_WINO4P_FWD(1, false, 2); else ADYOLO_WINO4P_FWD(2, false, 2);
+            return;
+        }
+    }
     if (a.nb == 2) {
         ADYOLO_WINO4P_NB(2)
     } else {

@@ -741,6 +741,36 @@ class Conv3x1WinoFn(torch.autograd.Function):
         return dx, dw
 
 
+class Conv3x3NarrowFn(torch.autograd.Function):
+    """Stride-1 3x3 convolution on a map 3 or 4 bins wide (the ResNet-Conformer's 128-channel stage, reference
+    resnet_conformer.py:353-393): forward and data gradient on the persistent F(4x4) kernel with patches ONE tile wide (128 x 4
+    pixels: no padded tiles, a quarter of the implicit GEMM's matrix work), weight gradient on the implicit GEMM (the
+    Winograd-domain weight-gradient kernels walk 16-column runs)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        n, h, ww, cin = x.shape
+        cout = w.shape[0]
+        wpk, wpkd = ops.pack_w3x3(w, cin)
+        ctx.geom = (n, h, ww, cin, cout, 3, 3, 1, 1, 1, 1)
+        ctx.save_for_backward(x, wpkd)
+        ctx.w = w                              # (storage address / shape for GradSink)
+        return ops.conv3x3(x, wpk, cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wpkd = ctx.saved_tensors
+        n, h, ww, cin, cout = ctx.geom[:5]
+        dy = _c(dy)
+        sunk = SINK.params(ctx.w)
+        dw = ops.unpack_wk(ops.conv_gemm(2, x, dy, *ctx.geom), cout, cin, 3, 3, out=sunk[0] if sunk is not None else None)
+        dx = ops.conv3x3(dy, wpkd, cin) if ctx.needs_input_grad[0] else None
+        if sunk is not None:
+            SINK.done_params(ctx.w)
+            dw = None
+        return dx, dw
+
+
 class Conv3x3S1Fn(torch.autograd.Function):
     """Stride-1 3x3 convolution on the implicit-GEMM kernel (K2), no fusion."""
 

@@ -40,9 +40,10 @@ def _dropout_residual(y, z, a, p, training, rng):
 
 
 def _conv3x3_s1(x, w):
-    """Stride-1 3x3 convolution.  Winograd kernels on wide maps; the deep stages of this ResNet have strided the
-    frequency axis down to 4, 2 and 1 bins, where an 8 x 16-pixel Winograd patch would be 75-94 % padding, so those run on
-    the implicit-GEMM convolution, without the taps that only ever meet the zero padding:
+    """Stride-1 3x3 convolution.  Winograd kernels on wide maps (8 bins: patches two tiles wide); the deep stages of this ResNet
+    have strided the frequency axis down to 4, 2 and 1 bins: 4 bins take the F(4x4) kernel with patches ONE tile wide (round 5),
+    2 and 1 bins ARE 3 x 1 convolutions along time (1-D Winograd F(4, 3) when the time axis is long, csrc/wino1d.hip; else the
+    implicit-GEMM convolution without the taps that only ever meet the zero padding):
     W == 1: only the centre kernel column meets data, the convolution IS the 3 x 1 one on w[:, :, :, 1:2];
     W == 2: every (input bin, output bin) pair is within one tap, so the two bins fold into the channel axis
             (free views [N][H][1][2 C]) and the convolution IS a 3 x 1 one with the 2 Cout x 2 Cin block filter
@@ -63,6 +64,8 @@ def _conv3x3_s1(x, w):
             return Fn.Conv3x1WinoFn.apply(x.view(n, h, 1, 2 * cin), w2).view(n, h, 2, cout)
         return Fn.ConvFn.apply(x.view(n, h, 1, 2 * cin), w2, (1, 1), (1, 0)).view(n, h, 2, cout)
     if wd <= 4:
+        if ops.w4_narrow_ok(cin, cout):           # F(4x4) with patches one tile wide for forward / data gradient (wino4p.hpp)
+            return Fn.Conv3x3NarrowFn.apply(x, w)
         return Fn.ConvFn.apply(x, w, (1, 1), (1, 1))
     return Fn.Conv3x3S1Fn.apply(x, w)
 

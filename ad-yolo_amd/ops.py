@@ -170,6 +170,14 @@ DISPATCH_LOG = None
 W4P_EPIS = (0, 1, 2, 9, 27, 31)            # operand combinations the persistent F(4x4) kernel is built for (csrc/wino4p_launch.hpp)
 
 
+def w4_narrow_ok(cin, cout):
+    """A stride-1 3x3 convolution on a map at most 8 bins wide gets the persistent F(4x4) kernel with patches one / two tiles
+    wide (``adyolo_wino4_fwd``, plain launches, 64-channel output blocks in both directions) -- the ResNet-Conformer's middle
+    stages: 2.9 x the implicit GEMM at 32 x 800 x 4 x 128 (tools/wino4/narrow_check.py)."""
+    return (conv_algo() == "winograd4" and cin % 64 == 0 and cout % 64 == 0 and _w4_eligible(cin, cout) and _w4_eligible(cout, cin)
+            and os.environ.get("ADYOLO_W4_NARROW", "1") != "0")
+
+
 def _w4_eligible(k_gemm, n_gemm, allow32=False):
     """Does this GEMM direction (contraction over k_gemm channels, n_gemm output channels) get the F(4x4,3x3) form
     (csrc/wino4.hip, wino4p.hpp) packed beside the F(2x2) one?  The kernels take 16-channel pairs of the contraction and 64

@@ -216,6 +216,31 @@ def test_conv3x1_winograd_1d(ops, n, h, cin, cout):
         assert err < 2e-5, "1-D Winograd %s: %.2e of absmax" % (what, err)
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 70, 4, 64, 64), (3, 133, 8, 64, 128), (1, 128, 4, 128, 64), (2, 9, 8, 64, 64), (2, 260, 3, 64, 64),
+                                            (2, 100, 7, 128, 128)])
+def test_conv3x3_narrow_maps_on_the_persistent_kernel(ops, monkeypatch, n, h, w, cin, cout):
+    """Maps at most 8 bins wide (the ResNet-Conformer's middle stages): plain launches of adyolo_wino4_fwd take patches one / two
+    tiles wide on the persistent kernel.  Forward, data gradient (F(4x4)) and weight gradient (implicit GEMM) of
+    functional.Conv3x3NarrowFn against float64, ragged heights and widths included."""
+    from adyolo_amd import functional as Fn
+    g = torch.Generator().manual_seed(h * 3 + w + cin)
+    x = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64) / np.sqrt(9 * cin)).requires_grad_(True)
+    dy = torch.randn(n, cout, h, w, generator=g, dtype=torch.float64)
+    y_ref = F.conv2d(x, wt, None, padding=1)
+    y_ref.backward(dy)
+    assert ops.w4_narrow_ok(cin, cout)
+    xg = dev(nhwc(x.detach().float())).requires_grad_(True)
+    wg = dev(wt.detach().float()).requires_grad_(True)
+    y = Fn.Conv3x3NarrowFn.apply(xg, wg)
+    assert ops._lib.load().adyolo_wino4_last_form() == 2, "not the persistent kernel"
+    y.backward(dev(nhwc(dy.float())))
+    torch.cuda.synchronize()
+    for got, ref, what in ((nchw(y), y_ref, "y"), (nchw(xg.grad), x.grad, "dx"), (wg.grad, wt.grad, "dw")):
+        err = float((got.detach().double().cpu() - ref.detach()).abs().max()) / float(ref.detach().abs().max())
+        assert err < 2e-5, "narrow-map 3x3 convolution %s: %.2e of absmax" % (what, err)
+
+
 # ------------------------------------------------------------------------------------------------ gemm
 @pytest.mark.parametrize("m,n,k,ta,tb,bias,splits", [
     (300, 2400, 256, False, False, True, 1),      # head
