@@ -164,15 +164,35 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
         const int pair = item / nseg;
         // the wave's run of the pair: run index q over (sample, 16-column run inside a row); an odd total leaves the last pair half empty
         const int q = 2 * pair + run;
-        const bool qok = q < N * runsW;
-        const int n = qok ? q / runsW : 0, rw = qok ? q - (q / runsW) * runsW : 0;
+        // Narrow maps (runsW < 0: W = 4 or 8, -runsW tiles per image row -- the ResNet-Conformer's middle stages): a run is made
+        // of 4 / tW SAMPLES side by side, the thread's tile st belongs to sample q (4 / tW) + st / tW, tile column st % tW; every
+        // tile then touches the image's left and / or right border
+        const int tW = runsW < 0 ? -runsW : 0;
+        bool qok, offL, offR;
+        int n, col0;                                                          // sample, first always-in-image column of the thread's tile
+        if (tW) {
+            const int sh = tW == 1 ? 0 : 1;
+            n = q * (4 >> sh) + (st >> sh);
+            const int tcol = st & (tW - 1);
+            qok = n < N;
+            n = qok ? n : 0;
+            col0 = 4 * tcol;
+            offL = tcol == 0;
+            offR = tcol == tW - 1;
+        } else {
+            qok = q < N * runsW;
+            n = qok ? q / runsW : 0;
+            const int rw = qok ? q - (q / runsW) * runsW : 0;
+            col0 = rw * 16 + 4 * st;
+            // only column -1 (pixel 0 of tile 0) and column 16 (pixel 5 of tile 3) of a run can leave the image sideways
+            offL = rw == 0 && st == 0;
+            offR = rw == runsW - 1 && st == 3;
+        }
         const int t0 = seg * seg_steps;                                       // first tile row of the segment
         const int nsteps = min(seg_steps, H / 4 - t0);
-        // byte offset of the item's first always-in-image pixel (column 16 rw + 4 st) in row 0 of the sample, at the thread's quad
-        const unsigned xbase = (unsigned)(((size_t)n * H * W + (size_t)rw * 16 + 4 * st) * Cin + c0 + 4 * sq) * 4u;
-        const unsigned dbase = (unsigned)(((size_t)n * H * W + (size_t)rw * 16 + 4 * st) * Cout + co0 + 4 * sq) * 4u;
-        // only column -1 (pixel 0 of tile 0) and column 16 (pixel 5 of tile 3) of a run can leave the image sideways
-        const bool offL = rw == 0 && st == 0, offR = rw == runsW - 1 && st == 3;
+        // byte offset of the item's first always-in-image pixel (column col0) in row 0 of the sample, at the thread's quad
+        const unsigned xbase = (unsigned)(((size_t)n * H * W + (size_t)col0) * Cin + c0 + 4 * sq) * 4u;
+        const unsigned dbase = (unsigned)(((size_t)n * H * W + (size_t)col0) * Cout + co0 + 4 * sq) * 4u;
 
         // x pixels of image row gy (any, also -1 / H), columns 16 rw + 4 st - 1 .. + 4, of the thread's channel quad
         f32x4 xpx[6];
@@ -540,7 +560,8 @@ __global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const float *__
 // work split: items = (pair of runs, segment of tile rows); every workgroup (split) takes items split, split + nsplit, ...
 static int wino4_wgrad_geometry(int N, int H, int W, int Cin, int Cout, int *npairs_o, int *nseg_o, int *seg_steps_o, int *nitems_o,
                                 int *nblk_o) {
-    const int runsW = W / 16, npairs = (N * runsW + 1) / 2;
+    // (narrow maps, W = 4 / 8: a run is 4 / (W / 4) samples side by side)
+    const int nruns = W >= 16 ? N * (W / 16) : cdiv(N, 16 / W), npairs = (nruns + 1) / 2;
     const int nblk = (Cout / (Cout % 64 == 0 ? 64 : 32)) * (Cin / 32);
     int nsplit = 256 / nblk;
     if (nsplit < 1) nsplit = 1;
@@ -590,7 +611,7 @@ extern "C" int adyolo_w4w_timing_buffer(void *p) {
 // > 0: the number of slabs the kernel writes for this shape; <= 0: shape not supported (use adyolo_wino_wgrad)
 extern "C" int adyolo_wino4_wgrad_slabs(int N, int H, int W, int Cin, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return ADYOLO_EINVAL;
-    if (Cin % 32 || Cout % 32 || W % 16 || H % 4 || H < 8) return 0;
+    if (Cin % 32 || Cout % 32 || (W % 16 && W != 4 && W != 8) || H % 4 || H < 8) return 0;
     if ((size_t)N * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 4 >= ((size_t)1 << 31)) return 0;       // 31-bit byte offsets
     return w4::wino4_wgrad_geometry(N, H, W, Cin, Cout, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
@@ -599,7 +620,7 @@ extern "C" int adyolo_wino4_wgrad(const float *x, const float *dy, const float *
                                   float *du, float *dw, int N, int H, int W, int Cin, int Cin_real, int Cout, void *stream) {
     ADYOLO_REQUIRE(x && dy && slabs && du && dw && N > 0 && H > 0 && W > 0, ADYOLO_EINVAL, "wino4_wgrad: bad arguments");
     ADYOLO_REQUIRE(adyolo_wino4_wgrad_slabs(N, H, W, Cin, Cout) > 0 && Cin_real > 0 && Cin_real <= Cin, ADYOLO_ENOSUP,
-                   "wino4_wgrad: unsupported shape N=%d H=%d W=%d Cin=%d Cout=%d (needs Cin %% 32 == 0, Cout %% 32 == 0, W %% 16 == 0, "
+                   "wino4_wgrad: unsupported shape N=%d H=%d W=%d Cin=%d Cout=%d (needs Cin %% 32 == 0, Cout %% 32 == 0, W %% 16 == 0 or W = 4 | 8, "
                    "H %% 4 == 0, tensors below 2 GiB)", N, H, W, Cin, Cout);
     ADYOLO_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), ADYOLO_EINVAL, "wino4_wgrad: in_scale/in_shift come together");
     // (16-byte loads of pixel quads and of the affine's channel quads)
@@ -611,7 +632,7 @@ extern "C" int adyolo_wino4_wgrad(const float *x, const float *dy, const float *
     const unsigned grid = (unsigned)(nsplit * nblk);
 #define ADYOLO_W4W(AFF_, NB_)                                                                                          \
     hipLaunchKernelGGL((w4::wino4_wgrad_kernel<AFF_, NB_>), dim3(grid), dim3(256), 0, st, x, dy, in_scale, in_shift, slabs, N, H, \
-                       W, Cin, Cout, W / 16, npairs, nseg, seg_steps, nitems, nsplit, Cin / 32, nblk)
+                       W, Cin, Cout, W >= 16 ? W / 16 : -(W / 4), npairs, nseg, seg_steps, nitems, nsplit, Cin / 32, nblk)
     if (Cout % 64 == 0) {
         if (in_scale) ADYOLO_W4W(true, 2); else ADYOLO_W4W(false, 2);
     } else {

@@ -744,8 +744,8 @@ class Conv3x1WinoFn(torch.autograd.Function):
 class Conv3x3NarrowFn(torch.autograd.Function):
     """Stride-1 3x3 convolution on a map 3 or 4 bins wide (the ResNet-Conformer's 128-channel stage, reference
     resnet_conformer.py:353-393): forward and data gradient on the persistent F(4x4) kernel with patches ONE tile wide (128 x 4
-    pixels: no padded tiles, a quarter of the implicit GEMM's matrix work), weight gradient on the implicit GEMM (the
-    Winograd-domain weight-gradient kernels walk 16-column runs)."""
+    pixels: no padded tiles, a quarter of the implicit GEMM's matrix work), weight gradient in the F(4x4) domain with runs made
+    of four samples side by side (``csrc/wino4w.hip``), or on the implicit GEMM below its dispatch threshold."""
 
     @staticmethod
     def forward(ctx, x, w):
@@ -763,7 +763,11 @@ class Conv3x3NarrowFn(torch.autograd.Function):
         n, h, ww, cin, cout = ctx.geom[:5]
         dy = _c(dy)
         sunk = SINK.params(ctx.w)
-        dw = ops.unpack_wk(ops.conv_gemm(2, x, dy, *ctx.geom), cout, cin, 3, 3, out=sunk[0] if sunk is not None else None)
+        if ops.wgrad_form(cin, cout, None, (n, h, ww))[0] == "wino4_wgrad_kernel":
+            # (round 5: the F(4x4)-domain kernel builds its 4-tile runs from 4 / (W / 4) samples side by side on these maps)
+            dw = ops.conv3x3_wgrad(x, dy, cin, out=sunk[0] if sunk is not None else None)
+        else:
+            dw = ops.unpack_wk(ops.conv_gemm(2, x, dy, *ctx.geom), cout, cin, 3, 3, out=sunk[0] if sunk is not None else None)
         dx = ops.conv3x3(dy, wpkd, cin) if ctx.needs_input_grad[0] else None
         if sunk is not None:
             SINK.done_params(ctx.w)

@@ -368,7 +368,7 @@ def wgrad_form(cin, cout, algo=None, shape=None):
     algo = algo or os.environ.get("ADYOLO_WGRAD_ALGO") or conv_algo()
     if algo == "winograd4" and shape is not None and cin % 32 == 0 and cout % 32 == 0:
         n, h, w = shape
-        if w % 16 == 0 and h % 4 == 0 and n * (w // 16) * (h // 4) * cin * cout >= W4_THRESHOLDS["min_wgrad_work"] and \
+        if (w % 16 == 0 or w in (4, 8)) and h % 4 == 0 and n * w // 16 * (h // 4) * cin * cout >= W4_THRESHOLDS["min_wgrad_work"] and \
                 _lib.load().adyolo_wino4_wgrad_slabs(n, h, w, cin, cout) > 0:
             return "wino4_wgrad_kernel", 9.0 / 36.0
     if algo in ("winograd", "winograd4") and cin % 32 == 0 and cout % 32 == 0:

@@ -143,6 +143,7 @@ def test_conv3x3_dgrad_wgrad(ops, monkeypatch, n, h, w, cin, cout, algo):
     (4, 300, 32, 64, 64, 1), (6, 132, 16, 256, 256, 0),      # several segments per pair, several items per workgroup
     (3, 28, 16, 96, 192, 1),                                 # 3 x 3 channel blocks
     (2, 64, 64, 32, 32, 1), (3, 20, 48, 64, 32, 0), (1, 12, 16, 32, 96, 1),       # 32-channel output blocks (NB = 1)
+    (5, 36, 4, 64, 64, 1), (7, 64, 4, 128, 128, 0), (3, 40, 8, 64, 128, 0), (2, 24, 8, 64, 64, 1), (9, 16, 4, 32, 32, 1),   # narrow maps: runs of 4 / 2 samples
 ])
 def test_wino4_wgrad_every_geometry(ops, monkeypatch, n, h, w, cin, cout, affine):
     """The F(4x4)-domain weight-gradient kernel (csrc/wino4w.hip) forced onto shapes far below its dispatch threshold: every
