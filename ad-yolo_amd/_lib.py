@@ -35,6 +35,7 @@ SIGNATURES = {
     "adyolo_wino4_tiles": (I, [I] * 3),
     "adyolo_wino4_fwd": (I, [P] * 13 + [I] * 7 + [P]),
     "adyolo_wino4_last_form": (I, []),
+    "adyolo_reload_switches": (I, []),
     "adyolo_wino4_wgrad_slabs": (I, [I] * 5),
     "adyolo_wino4_wgrad": (I, [P] * 7 + [I] * 6 + [P]),
     "adyolo_wino_wgrad_slabs": (I, [I] * 5),
@@ -152,6 +153,10 @@ def load():
         raise AdyoloHipError("libadyolo_hip.so ABI version %d != 1" % ver)
     _lib = lib
     return lib
+
+
+def loaded():
+    return _lib is not None
 
 
 def call(name, *args):

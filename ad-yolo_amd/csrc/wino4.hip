@@ -656,6 +656,18 @@ static int g_wino4_last_form = 0;          // 1: the last adyolo_wino4_fwd launc
 
 extern "C" int adyolo_wino4_last_form(void) { return g_wino4_last_form; }
 
+// The two environment switches adyolo_wino4_fwd consults, read ONCE (first launch) and again only by adyolo_reload_switches()
+// (ops.reload_thresholds(): the host code and the library move together; round 5 ADVICE -- they used to be three getenv calls
+// in every launch).  bit 0: persistent kernel, bit 1: narrow patches; -1: not read yet.
+static int g_w4_switches = -1;
+static int w4_read_switches() {
+    const char *pe = getenv("ADYOLO_W4_PERSIST"), *ne = getenv("ADYOLO_W4_NARROW");
+    g_w4_switches = ((pe && pe[0] == '0') ? 0 : 1) | ((ne && ne[0] == '0') ? 0 : 2);
+    return g_w4_switches;
+}
+static inline int w4_switches() { return g_w4_switches >= 0 ? g_w4_switches : w4_read_switches(); }
+extern "C" int adyolo_reload_switches(void) { return w4_read_switches(); }
+
 extern "C" int adyolo_wino4_tiles(int N, int H, int W) {
     if (N <= 0 || H <= 0 || W <= 0) return ADYOLO_EINVAL;
     const int tc = wino4_tc(W), tr = 32 / tc;
@@ -711,9 +723,9 @@ extern "C" int adyolo_wino4_fwd(const float *x, const float *u, const float *bia
     // Narrow maps (W <= 8: the middle stages of the ResNet-Conformer, 800 frames x 4 or 8 bins): plain launches take patches ONE
     // or TWO tiles wide (128 x 4 / 64 x 8 pixels) on the persistent kernel instead of padding a 16-pixel-wide patch 4 or 2 times
     // over (ADYOLO_W4_NARROW=0: the 16-wide patch)
-    const char *pe_ = getenv("ADYOLO_W4_PERSIST"), *ne_ = getenv("ADYOLO_W4_NARROW");
+    const int sw = w4_switches();
     const bool narrow = W <= 8 && !stats && !addend && !addend_mask && !stat_aux && !stat_mask && !bias && !in_scale && nb == 2 &&
-                        ncb <= 8 && 8 % ncb == 0 && !(pe_ && pe_[0] == '0') && !(ne_ && ne_[0] == '0');
+                        ncb <= 8 && 8 % ncb == 0 && (sw & 3) == 3;
     const int tc = narrow ? (W <= 4 ? 1 : 2) : wino4_tc(W), tr = 32 / tc;
     const int patchesW = cdiv(W, 4 * tc), patchesH = cdiv(H, 4 * tr);
     const int nsp = N * patchesH * patchesW;
@@ -726,10 +738,9 @@ extern "C" int adyolo_wino4_fwd(const float *x, const float *u, const float *bia
     // Persistent form (round 5, wino4p.hpp): one workgroup per CU walks the patches of its XCD slot.  Needs the XCD dealing
     // (Cout / 64 in {1, 2, 4, 8}), no bias, masks given as bits, and one of the operand combinations it is instantiated for (the
     // ones the SE-ResNet block launches); everything else, and ADYOLO_W4_PERSIST=0, takes the one-patch-per-workgroup kernel below.
-    const char *pe = getenv("ADYOLO_W4_PERSIST");
     const int epi = (stats ? 1 : 0) | (addend ? 2 : 0) | (addend_mask ? 4 : 0) | (stat_aux ? 8 : 0) | (stat_mask ? 16 : 0);
     const bool bits_ok = (!addend_mask || (mask_bits & 1)) && (!stat_mask || (mask_bits & 2));
-    if (xcd_div > 0 && bits_ok && !bias && !(pe && pe[0] == '0') && (epi == 0 || epi == 1 || epi == 2 || epi == 9 || epi == 27 || epi == 31)) {
+    if (xcd_div > 0 && bits_ok && !bias && (sw & 1) && (epi == 0 || epi == 1 || epi == 2 || epi == 9 || epi == 27 || epi == 31)) {
         static int ncus = 0;
         if (ncus == 0) {
             int dev = 0, v = 0;

@@ -56,6 +56,30 @@ struct CfgP {
     static constexpr int LDS_FLOATS = (XOFF + XCH > 4 * C::CBUF) ? XOFF + XCH : 4 * C::CBUF;
 };
 
+// Byte offsets of the pointer arguments the epilogue reads back from the kernel-argument segment (``karg`` below: an opaque
+// load instead of a value that would stay live across the pair loop).  They are CHECKED against the kernel's real signature by
+// the static_asserts after the kernel (KargLayout walks the parameter types with their alignments): adding, removing or
+// reordering a parameter without moving these fails to compile (round 5, ADVICE).
+enum : int {
+    KA_ADDEND = 24, KA_ADDEND_MASK = 32, KA_Y = 56, KA_STATS = 64, KA_STAT_AUX = 72, KA_STAT_MEAN = 80, KA_STAT_INVSTD = 88,
+    KA_STAT_MASK = 96
+};
+template <typename F>
+struct KargLayout;
+template <typename... A>
+struct KargLayout<void (*)(A...)> {
+    static constexpr int count = (int)sizeof...(A);
+    static constexpr size_t offset(int idx) {
+        constexpr size_t sz[] = {sizeof(A)...}, al[] = {alignof(A)...};
+        size_t off = 0;
+        for (int i = 0; i <= idx; ++i) {
+            off = (off + al[i] - 1) / al[i] * al[i];
+            if (i < idx) off += sz[i];
+        }
+        return off;
+    }
+};
+
 // NB: 32-channel output blocks per workgroup -- 2 (Cout % 64 == 0) or 1 (32-channel layers: half the MFMAs per A fragment and per
 // staged pixel, two epilogue rounds; no one-patch counterpart)
 template <int TC, bool AFF, int EPI, int NB>
@@ -436,7 +460,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
 #pragma unroll
         for (int nt = 0; nt < NB; ++nt) ssum[nt] = ssq[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         const size_t sbase = (size_t)n * ysample;         // floats
-        const __amdgpu_buffer_rsrc_t yrs = rsrc_of(karg(56) + sbase, sbytes);                    // y
+        const __amdgpu_buffer_rsrc_t yrs = rsrc_of(karg(KA_Y) + sbase, sbytes);                 // y
 #pragma unroll
         for (int rnd = 0; rnd < 2 * NB; ++rnd) {
             const int nt = rnd >> 1, rh = rnd & 1;
@@ -491,16 +515,16 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                 return r;
             };
             if (AD) {
-                const __amdgpu_buffer_rsrc_t ars = rsrc_of(karg(24) + sbase, sbytes);           // addend
+                const __amdgpu_buffer_rsrc_t ars = rsrc_of(karg(KA_ADDEND) + sbase, sbytes);    // addend
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
 #pragma unroll
                     for (int b = 0; b < 4; ++b) ad[e][b] = load4(ars, off[e][b]);
-                if (MK) keep(karg(32), amk_raw);                                                  // addend_mask
+                if (MK) keep(karg(KA_ADDEND_MASK), amk_raw);                                      // addend_mask
             }
-            if (SMK) keep(karg(96), smk_raw);                                                     // stat_mask
+            if (SMK) keep(karg(KA_STAT_MASK), smk_raw);                                           // stat_mask
             if (AUX) {
-                const __amdgpu_buffer_rsrc_t xrs_ = rsrc_of(karg(72) + sbase, sbytes);           // stat_aux
+                const __amdgpu_buffer_rsrc_t xrs_ = rsrc_of(karg(KA_STAT_AUX) + sbase, sbytes);  // stat_aux
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -593,8 +617,8 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
             // ---- nu direction and the pixels (ReLU: one wave-uniform branch per round around two copies of the loop)
             f32x4 smean = {0.f, 0.f, 0.f, 0.f}, sinv = smean;
             if (AUX) {
-                smean = *reinterpret_cast<const f32x4 *>(karg(80) + co);                          // stat_mean, stat_invstd
-                sinv = *reinterpret_cast<const f32x4 *>(karg(88) + co);
+                smean = *reinterpret_cast<const f32x4 *>(karg(KA_STAT_MEAN) + co);                // stat_mean, stat_invstd
+                sinv = *reinterpret_cast<const f32x4 *>(karg(KA_STAT_INVSTD) + co);
             }
             auto andf = [](float v, unsigned k) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & k); };
             auto pixels = [&](auto RL_) {
@@ -677,7 +701,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                     s2 += red[(which * 32 + gI + 2) * 64 + c];
                     s3 += red[(which * 32 + gI + 3) * 64 + c];
                 }
-                karg(64)[(size_t)which * nsp * Cout + (size_t)sp * Cout + co0 + c] = (s0 + s1) + (s2 + s3);     // stats
+                karg(KA_STATS)[(size_t)which * nsp * Cout + (size_t)sp * Cout + co0 + c] = (s0 + s1) + (s2 + s3);     // stats
             }
             __syncthreads();
         }
@@ -702,6 +726,18 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
 }
 
 
+// the kernarg offsets above against the signature (the same for every instantiation): parameter index -> byte offset
+namespace kargcheck {
+using KL = KargLayout<decltype(&wino4p_fwd_kernel<4, false, 0, 2>)>;
+static_assert(KL::count == 24, "wino4p_fwd_kernel: parameter list changed -- revisit the KA_* offsets and W4Launch");
+static_assert(KL::offset(3) == KA_ADDEND && KL::offset(4) == KA_ADDEND_MASK, "KA_ADDEND / KA_ADDEND_MASK != kernarg layout");
+static_assert(KL::offset(7) == KA_Y && KL::offset(8) == KA_STATS, "KA_Y / KA_STATS != kernarg layout");
+static_assert(KL::offset(9) == KA_STAT_AUX && KL::offset(10) == KA_STAT_MEAN && KL::offset(11) == KA_STAT_INVSTD &&
+                  KL::offset(12) == KA_STAT_MASK, "KA_STAT_* != kernarg layout");
+// ... and that those parameters ARE the pointers the names say (a swap of two same-typed pointers cannot be seen by the
+// compiler; the launch macro below passes W4Launch members by NAME in signature order, and tests/test_gpu_kernels.py runs
+// every operand combination against float64)
+}  // namespace kargcheck
 
 template <int EPI>
 void launch_wino4p(const W4Launch &a) {

@@ -78,6 +78,7 @@ class StepGraphs:
         self.evictions = 0
         self.streams = _rng.streams(trainer.model)
         self.captures = self.replays = self.eager_steps = 0
+        self.switches = ops.switch_stamp()     # the recorded steps' kernel choice: graphs recorded under another table are dropped
 
     # ---------------------------------------------------------------------------------------- input handling
     @staticmethod
@@ -159,10 +160,38 @@ class StepGraphs:
         warnings.warn("adyolo: train step not hipGraph-capturable (%s); running it eagerly" % why)
         self.eager_only.add(key)
 
+    @staticmethod
+    def _capture_related(e):
+        """Is ``e`` an error CAUSED by recording (the step itself is fine when launched eagerly)?  ``NotImplementedError``: a
+        host-computed value asked for under capture (``rng.DropoutStream``); a ``RuntimeError`` whose text names the capture -- HIP's
+        "operation not permitted when stream is capturing" / "... capture invalidated", torch's "... during CUDA graph capture".
+        Everything else (out of memory, a bug in a kernel wrapper, a failing assertion) is NOT: falling back to eager launches
+        for it would turn a real failure into a silent, permanent slowdown (round 5, ADVICE) -- it propagates."""
+        if isinstance(e, NotImplementedError):
+            return True
+        oom = getattr(torch, "OutOfMemoryError", ())
+        return isinstance(e, RuntimeError) and not isinstance(e, oom) and "captur" in str(e).lower()
+
+    def _reset_step_state(self):
+        """Host-side state a step that died half way (inside backward, inside the optimizer) can leave behind, put back before the
+        step runs again: the gradient sink (views / reducer hook), pending BatchNorm counter bumps, the reducer's bucket
+        counters.  (The RNG offsets and the optimizer's step count are restored by ``_capture`` itself; the block links that
+        carry per-patch sums and ReLU-mask bits between blocks are made anew by every forward pass.)"""
+        Fn.SINK.end()
+        del Fn._COUNTER_SCOPE[:]
+        red = getattr(self.trainer, "reducer", None)
+        if red is not None and getattr(red, "active", False):
+            red.reset()
+
     def step(self, audio, target):
         tr = self.trainer
         target = target.to(torch.float32)
         key = self._key(audio, target)
+        sw = ops.switch_stamp()
+        if sw != self.switches:                # ``ops.reload_thresholds()`` / ADYOLO_CONV_ALGO moved the dispatch: record again
+            self.entries.clear()
+            self.seen.clear()
+            self.switches = sw
         if key in self.eager_only:
             self.eager_steps += 1
             return tr.step_eager(audio, target)
@@ -182,9 +211,14 @@ class StepGraphs:
             try:
                 ent = self._capture(key, audio, target)
             except Exception as e:                                               # noqa: BLE001
-                # second line of defence (round 4: NotImplementedError from a host draw inside the capture; round 5: ANY
-                # exception raised while recording, e.g. a RuntimeError from HIP): ``_capture`` has put the host-side state
-                # back, make sure the stream is not left capturing, remember the shape as eager-only and run the step eagerly
+                # second line of defence.  ``_capture`` has ended the capture and put the RNG offsets / step count back; whatever
+                # else the half-recorded step touched on the host is reset here.  Only an error CAUSED by recording makes the
+                # shape eager-only (round 4: NotImplementedError from a host draw; round 5: a RuntimeError that names the
+                # capture); anything else -- out of memory, a real bug -- is re-raised to the caller with the trainer left usable
+                self._reset_step_state()
+                if not self._capture_related(e):
+                    self.seen[key] = n                                           # (the next call at this shape tries again)
+                    raise
                 self._mark_eager(key, "%s: %s" % (type(e).__name__, e))
                 self.eager_steps += 1
                 return tr.step_eager(audio, target)
@@ -221,7 +255,9 @@ class ForwardGraphs:
         """What the recorded graphs depend on besides the input shape: the parameter / buffer epoch of in-place kernels
         (``ops.PARAMS_EPOCH``), the version counters of every parameter and buffer (``p.copy_()``, a torch optimizer step or an
         EMA swap in evaluation mode bump these, not the epoch -- the eager caches honour them, a recorded graph would replay
-        stale affines and packed filters; round 4, ADVICE) and the arithmetic switches read at pack time."""
+        stale affines and packed filters; round 4, ADVICE) and the dispatch switch table (``ops.switch_stamp``: the algorithm, the
+        F(4x4) thresholds and the persistent / narrow / 1-D switches -- a graph recorded before ``ops.reload_thresholds()`` moved
+        one would keep the old kernel choice; round 5, ADVICE)."""
         # (the tensor list is cached: walking the module tree costs ~0.3 ms per call, a tenth of a one-clip forward.  It is rebuilt
         #  whenever ops.PARAMS_EPOCH moved since it was made -- .to(), load_state_dict(assign=True) and every in-place kernel bump
         #  the epoch, and after a replaced Parameter object later copy_() / optimizer writes land in the NEW objects, whose version
@@ -233,7 +269,7 @@ class ForwardGraphs:
         ver = 0
         for t in ts:
             ver += t._version
-        return (ops.PARAMS_EPOCH[0], ver, len(ts), ops.conv_algo())
+        return (ops.PARAMS_EPOCH[0], ver, len(ts), ops.switch_stamp())
 
     def _ntensors_check(self):
         """every 256 calls the cached tensor list is rebuilt (a module that replaced a parameter object without moving the model)"""

@@ -137,9 +137,14 @@ def conv_algo():
     return a
 
 
-# Dispatch thresholds of the F(4x4,3x3) kernel, read from the environment ONCE (at import, and again by ``reload_thresholds()``
-# -- tests and A/B tools that move them call it); ``conv3x3`` consults the cached values on every launch.
+# Dispatch switches of the 3x3 convolutions, read from the environment ONCE -- at import, and again by ``reload_thresholds()``
+# (tests and A/B tools that move one call it; README "Switches") -- into ONE table that every launch consults: the numeric
+# thresholds AND the on / off switches (round 5 ADVICE: ADYOLO_W4_PERSIST / _NARROW / ADYOLO_WINO1D used to be read per launch,
+# three getenv calls inside every adyolo_wino4_fwd, while the thresholds were frozen).  The library keeps its own copy of the two
+# switches it consults (csrc/wino4.hip, read at its first launch), refreshed by the same call.  ADYOLO_CONV_ALGO stays a
+# per-call read (``conv_algo``): it selects the algorithm, is validated where it is read and is part of the graph stamp on its own.
 W4_THRESHOLDS = {}
+_THRESHOLD_KEYS = ("min_k", "min_k_addend", "min_wgs", "min_wgrad_work", "min_k_32")
 
 
 def reload_thresholds():
@@ -151,13 +156,36 @@ def reload_thresholds():
     its MFMA groups -- 16 x 20 s: 1.18-1.41 x at every block shape, 8 x 20 s: 0.8-0.9 x at the 3.3 M stage transitions, 1.0-1.3 x
     from 6.5 M on: profiles/r05_w4w_small_shapes.txt; 2^24 with the first version of the kernel);
     ADYOLO_W4_MIN_K_32 (32): smallest contraction for the F(4x4) form with 32-channel OUTPUT blocks (stage 1's 32 -> 32 layers
-    and the 64 -> 32 data-gradient: 1.04-1.14 x the F(2x2) kernel per launch, profiles/r05_w4p_nb1_ab.txt)."""
-    W4_THRESHOLDS.update(min_k=int(os.environ.get("ADYOLO_W4_MIN_K", "64")),
-                         min_k_addend=int(os.environ.get("ADYOLO_W4_MIN_K_ADDEND", "32")),
-                         min_wgs=int(os.environ.get("ADYOLO_W4_MIN_WGS", "200")),
-                         min_wgrad_work=int(os.environ.get("ADYOLO_W4W_MIN_WORK", "6000000")),
-                         min_k_32=int(os.environ.get("ADYOLO_W4_MIN_K_32", "32")))
-    return dict(W4_THRESHOLDS)
+    and the 64 -> 32 data-gradient: 1.04-1.14 x the F(2x2) kernel per launch, profiles/r05_w4p_nb1_ab.txt).
+    On / off switches in the same table: ADYOLO_W4_PERSIST (persistent F(4x4) kernel; 0 = the one-patch form), ADYOLO_W4_NARROW
+    (patches one / two tiles wide on maps up to 8 bins wide), ADYOLO_WINO1D (1-D Winograd along time on one-bin-wide maps),
+    ADYOLO_WGRAD_ALGO (weight-gradient algorithm when it differs from ADYOLO_CONV_ALGO).
+    Returns the numeric thresholds (``switch_table()``: everything)."""
+    env = os.environ.get
+    W4_THRESHOLDS.update(min_k=int(env("ADYOLO_W4_MIN_K", "64")),
+                         min_k_addend=int(env("ADYOLO_W4_MIN_K_ADDEND", "32")),
+                         min_wgs=int(env("ADYOLO_W4_MIN_WGS", "200")),
+                         min_wgrad_work=int(env("ADYOLO_W4W_MIN_WORK", "6000000")),
+                         min_k_32=int(env("ADYOLO_W4_MIN_K_32", "32")),
+                         persist=env("ADYOLO_W4_PERSIST", "1") != "0",
+                         narrow=env("ADYOLO_W4_NARROW", "1") != "0",
+                         wino1d=env("ADYOLO_WINO1D", "1") != "0",
+                         wgrad_algo=(env("ADYOLO_WGRAD_ALGO") or "").lower() or None)
+    if _lib.loaded():                                  # (not loaded yet: the library reads the environment at its first launch)
+        _lib.load().adyolo_reload_switches()
+    return {k: W4_THRESHOLDS[k] for k in _THRESHOLD_KEYS}
+
+
+def switch_table():
+    """Every cached dispatch switch + the algorithm: what a recorded graph's kernel choice depends on besides its input shape
+    (``graph.ForwardGraphs._stamp`` / ``StepGraphs`` key on it) and what bench.py echoes in ``dispatch``."""
+    t = dict(W4_THRESHOLDS)
+    t["conv_algo"] = conv_algo()
+    return t
+
+
+def switch_stamp():
+    return tuple(sorted((k, str(v)) for k, v in switch_table().items()))
 
 
 reload_thresholds()
@@ -175,7 +203,7 @@ def w4_narrow_ok(cin, cout):
     wide (``adyolo_wino4_fwd``, plain launches, 64-channel output blocks in both directions) -- the ResNet-Conformer's middle
     stages: 2.9 x the implicit GEMM at 32 x 800 x 4 x 128 (tools/wino4/narrow_check.py)."""
     return (conv_algo() == "winograd4" and cin % 64 == 0 and cout % 64 == 0 and _w4_eligible(cin, cout) and _w4_eligible(cout, cin)
-            and os.environ.get("ADYOLO_W4_NARROW", "1") != "0")
+            and W4_THRESHOLDS["narrow"] and W4_THRESHOLDS["persist"])
 
 
 def _w4_eligible(k_gemm, n_gemm, allow32=False):
@@ -240,7 +268,7 @@ class DualPack:
         F(2x2) kernel was the faster one there below 128 channels (ADYOLO_W4_MIN_K_ADDEND, now 32: no effect by default).  persistent_ok: the launch's
         operand combination has a persistent form (``W4P_EPIS``, no bias, masks as bits) -- with 32-channel output blocks
         (cout % 64 != 0) there is no other F(4x4) kernel."""
-        if cout % 64 and not (persistent_ok and os.environ.get("ADYOLO_W4_PERSIST", "1") != "0"):
+        if cout % 64 and not (persistent_ok and W4_THRESHOLDS["persist"]):
             return self.f2
         wgs = _lib.load().adyolo_wino4_tiles(n, h, w) * ((cout + 63) // 64)
         if wgs < W4_THRESHOLDS["min_wgs"]:
@@ -365,7 +393,7 @@ def wgrad_form(cin, cout, algo=None, shape=None):
     enough (ADYOLO_W4W_MIN_WORK; one workgroup per CU: small launches stay on the two-per-CU kernel); else
     the F(2x2,3x3) domain (16 per 36) when both channel counts are multiples of 32; else the direct implicit GEMM.  The ONE
     place that decides it -- ``conv3x3_wgrad`` and bench.py both ask here."""
-    algo = algo or os.environ.get("ADYOLO_WGRAD_ALGO") or conv_algo()
+    algo = algo or W4_THRESHOLDS["wgrad_algo"] or conv_algo()
     if algo == "winograd4" and shape is not None and cin % 32 == 0 and cout % 32 == 0:
         n, h, w = shape
         if (w % 16 == 0 or w in (4, 8)) and h % 4 == 0 and n * w // 16 * (h // 4) * cin * cout >= W4_THRESHOLDS["min_wgrad_work"] and \
@@ -876,7 +904,7 @@ def conv_out_hw(h, w, kh, kw, sh, sw, ph, pw):
 def wino1d_ok(n, h, cin, cout):
     """The 3 x 1 convolution along H (x [N][H][1][Cin]) takes the 1-D Winograd form: whole output tiles, GEMM-friendly channel
     counts and enough rows to fill the chip with the six position GEMMs (``ADYOLO_WINO1D=0`` switches it off)."""
-    return (os.environ.get("ADYOLO_WINO1D", "1") != "0" and h % 4 == 0 and cin % 64 == 0 and cout % 64 == 0
+    return (W4_THRESHOLDS["wino1d"] and h % 4 == 0 and cin % 64 == 0 and cout % 64 == 0
             and n * (h // 4) >= 2048)
 
 

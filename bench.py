@@ -364,7 +364,8 @@ def _run_extra_config(name, cfg, torch, modes):
             kt.wrap(_ops, "conv3x3", "Winograd 3x3 forward / dgrad [issued FLOPs]",
                     lambda x, wpk, cout, **kw: fl(2.0 * x.shape[0] * x.shape[1] * x.shape[2] * cout * 9 * x.shape[3] * (_issued_share(_picked(_ops, x, wpk, cout, kw.get("addend") is not None)))))
             kt.wrap(_ops, "conv3x3_wgrad", "Winograd 3x3 weight-gradient [issued FLOPs]",
-                    lambda x, dy, cin_real, **kw: fl(2.0 * x.shape[0] * x.shape[1] * x.shape[2] * dy.shape[3] * 9 * x.shape[3] * 16.0 / 36.0))
+                    lambda x, dy, cin_real, **kw: fl(2.0 * x.shape[0] * x.shape[1] * x.shape[2] * dy.shape[3] * 9 * x.shape[3]
+                                                     * _ops.wgrad_form(x.shape[3], dy.shape[3], kw.get("algo"), (x.shape[0], x.shape[1], x.shape[2]))[1]))
             torch.manual_seed(100)
             model = WrapperModel((1, 7, T, 64), (), prm).to(device)
             tr = TrainStep(model, WrapperCriterion(prm), fx, prm, graph=False)
@@ -689,7 +690,7 @@ def main():
             by_name[name]["launches_per_step"] += cnt
             key = "%d->%d ops%d" % (cin, cout, epi)
             by_name[name]["by_shape"][key] = by_name[name]["by_shape"].get(key, 0) + cnt
-        dispatch = {"conv3x3": by_name, "thresholds": dict(ops.W4_THRESHOLDS),
+        dispatch = {"conv3x3": by_name, "thresholds": ops.switch_table(),
                     "env": {k: os.environ.get(k) for k in ("ADYOLO_LIB", "ADYOLO_CONV_ALGO", "ADYOLO_W4_PERSIST", "ADYOLO_W4_MIN_K",
                                                            "ADYOLO_W4_MIN_K_ADDEND", "ADYOLO_W4_MIN_WGS",
                                                            "ADYOLO_WGRAD_ALGO", "ADYOLO_GEMM_TILE")},

@@ -145,6 +145,10 @@ int adyolo_wino4_fwd(const float *x, const float *u, const float *bias, const fl
  *      one-patch-per-workgroup kernel otherwise or with ADYOLO_W4_PERSIST=0; same results within fp32 rounding.
  *      adyolo_wino4_last_form(): which one the last call launched (1 one-patch, 2 persistent, 0 none yet) -- for reporting. */
 int adyolo_wino4_last_form(void);
+/*      adyolo_reload_switches(): the library reads ADYOLO_W4_PERSIST / ADYOLO_W4_NARROW from the environment ONCE (at the first
+ *      adyolo_wino4_fwd) and keeps them; this re-reads them (ops.reload_thresholds() calls it: one switch table for the host
+ *      code and the library).  Returns the table as bits: 1 persistent kernel on, 2 narrow patches on. */
+int adyolo_reload_switches(void);
 /* K2w4w (round 5, csrc/wino4w.hip): the weight gradient in the Winograd F(4x4,3x3) domain,
  *      dw = G^T [ sum over 4x4 output tiles (B^T d B) (.) (A e A^T) ] G  (36 multiplies per 16 outputs and channel pair: 9/36 of the
  *      direct form's matrix FLOPs, 1.78x fewer MFMAs than adyolo_wino_wgrad; interpolation points of K2w4; error against a float64

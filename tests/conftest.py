@@ -20,18 +20,26 @@ def golden_dir():
 
 
 @pytest.fixture(autouse=True)
-def _w4_thresholds_follow_the_environment(monkeypatch):
-    """``ops`` caches the ADYOLO_W4_* dispatch thresholds at import (``ops.reload_thresholds``): tests move them with
-    ``monkeypatch.setenv``, so re-read them whenever such a variable is set and once more when the test's environment is
-    restored."""
-    real_setenv = monkeypatch.setenv
+def _switch_table_follows_the_environment(monkeypatch):
+    """``ops`` caches the dispatch switches at import (``ops.reload_thresholds``: the ADYOLO_W4_* / ADYOLO_W4W_* thresholds,
+    ADYOLO_W4_PERSIST / _NARROW, ADYOLO_WINO1D, ADYOLO_WGRAD_ALGO): tests move them with ``monkeypatch.setenv`` / ``delenv``, so
+    re-read the table whenever such a variable is set or deleted and once more when the test's environment is restored.  (Code
+    that writes ``os.environ`` directly calls ``ops.reload_thresholds()`` itself: README "Switches".)"""
+    real_setenv, real_delenv = monkeypatch.setenv, monkeypatch.delenv
+
+    def reload(name):
+        if name.startswith("ADYOLO_") and "adyolo_amd" in sys.modules:
+            from adyolo_amd import ops
+            ops.reload_thresholds()
 
     def setenv(name, value, *a, **kw):
         real_setenv(name, value, *a, **kw)
-        if name.startswith("ADYOLO_W4") and "adyolo_amd" in sys.modules:       # (ADYOLO_W4_* and ADYOLO_W4W_*)
-            from adyolo_amd import ops
-            ops.reload_thresholds()
-    monkeypatch.setenv = setenv
+        reload(name)
+
+    def delenv(name, *a, **kw):
+        real_delenv(name, *a, **kw)
+        reload(name)
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
     yield
     monkeypatch.undo()
     if "adyolo_amd" in sys.modules:

@@ -340,6 +340,72 @@ def test_runtime_error_inside_a_capture_falls_back_to_eager(ops, monkeypatch):
     assert losses[True] == losses[False], losses
 
 
+def test_failure_inside_backward_of_a_capture(ops, monkeypatch):
+    """Round 5 ADVICE: (a) an error CAUSED by recording that strikes in the middle of backward (gradient sink open, BatchNorm
+    counters pending) still ends in a clean eager fallback with the eager trainer's losses; (b) an error that has nothing to do
+    with recording (a bug, out of memory) is NOT swallowed into a permanent eager fallback: it propagates, the shape is not
+    marked eager-only, the stream is not left capturing, and the trainer records and replays normally afterwards -- with the
+    losses of a trainer that never failed (a recording runs nothing, so the failed attempt must not have advanced any state)."""
+    import warnings
+    from adyolo_amd import ops as _ops, functional as Fn
+    from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
+    from adyolo_amd.features import FeatureExtractor
+    from adyolo_amd.datasets import synthetic_audio, synthetic_targets
+    from adyolo_amd.train import TrainStep
+    n = 24000 * 2
+    audio = synthetic_audio(2, n, seed=13).to("cuda:0")
+    target = synthetic_targets(2, n // 2400, 12, seed=13).to("cuda:0")
+    real_wgrad = _ops.conv3x3_wgrad
+
+    def make(graph):
+        torch.manual_seed(100)
+        prm = _params()
+        model = WrapperModel((1, 7, n // 600, 64), (), prm).to("cuda:0")
+        return TrainStep(model, WrapperCriterion(prm), FeatureExtractor(None, "cuda:0"), prm, graph=graph)
+    ref = make(False)
+    want = [float(ref.step(audio, target)) for _ in range(4)]
+
+    # (a) capture-related, raised by the 5th weight-gradient launch of the recorded backward
+    calls = {"n": 0}
+
+    def wgrad_refusing_capture(*a, **kw):
+        if torch.cuda.is_current_stream_capturing():
+            calls["n"] += 1
+            if calls["n"] == 5:
+                raise RuntimeError("HIP error: operation not permitted when stream is capturing (injected)")
+        return real_wgrad(*a, **kw)
+    tr = make(True)
+    monkeypatch.setattr(_ops, "conv3x3_wgrad", wgrad_refusing_capture)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        got = [float(tr.step(audio, target)) for _ in range(4)]
+    assert got == want, (got, want)
+    assert not torch.cuda.is_current_stream_capturing() and Fn.SINK.views is None and not Fn._COUNTER_SCOPE
+    assert tr.graphs.captures == 0 and len(tr.graphs.eager_only) == 1
+    assert sum("not hipGraph-capturable" in str(w.message) for w in caught) == 1
+
+    # (b) NOT capture-related: propagates; afterwards the trainer captures and replays as if nothing had happened
+    calls["n"] = 0
+
+    def wgrad_with_a_bug(*a, **kw):
+        if torch.cuda.is_current_stream_capturing():
+            calls["n"] += 1
+            if calls["n"] == 5:
+                raise RuntimeError("injected bug: shapes do not match")
+        return real_wgrad(*a, **kw)
+    tr = make(True)
+    monkeypatch.setattr(_ops, "conv3x3_wgrad", wgrad_with_a_bug)
+    got = [float(tr.step(audio, target))]                        # warm-up step, eager
+    with pytest.raises(RuntimeError, match="injected bug"):
+        tr.step(audio, target)
+    assert not torch.cuda.is_current_stream_capturing() and Fn.SINK.views is None and not Fn._COUNTER_SCOPE
+    assert not tr.graphs.eager_only and tr.graphs.captures == 0
+    monkeypatch.setattr(_ops, "conv3x3_wgrad", real_wgrad)
+    got += [float(tr.step(audio, target)) for _ in range(3)]
+    assert tr.graphs.captures == 1 and tr.graphs.replays == 3
+    assert got == want, (got, want)
+
+
 def test_recorded_graphs_are_bounded_lru(ops, monkeypatch):
     """``StepGraphs`` / ``ForwardGraphs`` keep at most ``graph.MAX_GRAPHS`` recorded graphs (each owns a private pool with its
     shape's activations): the least recently used one is evicted, an evicted shape is simply recorded again, and the outputs

@@ -400,8 +400,24 @@ def test_dispatch_thresholds_and_parameter_epoch(monkeypatch):
     assert ops._w4_eligible(64, 64) and not ops._w4_eligible(32, 64) and not ops._w4_eligible(64, 32) and not ops._w4_eligible(1024, 64)
     monkeypatch.setenv("ADYOLO_W4_MIN_K", "32")                     # (the fixture reloads)
     assert ops.W4_THRESHOLDS["min_k"] == 32 and ops._w4_eligible(32, 64)
-    monkeypatch.delenv("ADYOLO_W4_MIN_K")
-    assert ops.reload_thresholds()["min_k"] == 64
+    monkeypatch.delenv("ADYOLO_W4_MIN_K")                            # (the fixture reloads on delenv too)
+    assert ops.W4_THRESHOLDS["min_k"] == 64 and ops.reload_thresholds()["min_k"] == 64
+    # the on / off switches live in the same table, and the table is what recorded graphs are keyed on
+    for k in ("ADYOLO_W4_PERSIST", "ADYOLO_W4_NARROW", "ADYOLO_WINO1D"):
+        monkeypatch.delenv(k, raising=False)
+    t0 = ops.switch_table()
+    assert t0["persist"] and t0["narrow"] and t0["wino1d"] and t0["wgrad_algo"] is None and t0["conv_algo"] == ops.conv_algo()
+    s0 = ops.switch_stamp()
+    monkeypatch.setenv("ADYOLO_W4_PERSIST", "0")
+    assert not ops.W4_THRESHOLDS["persist"] and ops.switch_stamp() != s0 and not ops.w4_narrow_ok(64, 64)
+    import os as _os
+    _os.environ["ADYOLO_WINO1D"] = "0"                               # a direct write is NOT seen until reload_thresholds()
+    assert ops.W4_THRESHOLDS["wino1d"] and ops.wino1d_ok(32, 800, 64, 64)
+    ops.reload_thresholds()
+    assert not ops.W4_THRESHOLDS["wino1d"] and not ops.wino1d_ok(32, 800, 64, 64)
+    del _os.environ["ADYOLO_WINO1D"]
+    monkeypatch.delenv("ADYOLO_W4_PERSIST")
+    assert ops.switch_stamp() == s0
     assert not hasattr(ops, "math_mode")
     monkeypatch.delenv("ADYOLO_WGRAD_ALGO", raising=False)
     monkeypatch.delenv("ADYOLO_CONV_ALGO", raising=False)

@@ -51,8 +51,10 @@ for (n, h, w, cin, cout) in [(32, 800, 4, 128, 128), (32, 800, 8, 64, 64)]:
     wpk, _ = ops.pack_w3x3(wt, cin, want_dgrad=False, algo="winograd4")
     tn = t(lambda: ops.conv3x3(x, wpk, cout))
     os.environ["ADYOLO_W4_NARROW"] = "0"
+    ops.reload_thresholds()
     tw = t(lambda: ops.conv3x3(x, wpk, cout))
     del os.environ["ADYOLO_W4_NARROW"]
+    ops.reload_thresholds()
     wk = ops.pack_wk(wt)
     tg = t(lambda: ops.conv_gemm(0, x, wk, n, h, w, cin, cout, 3, 3, 1, 1, 1, 1))
     fl = 2.0 * n * h * w * cin * cout * 9

@@ -49,6 +49,7 @@ def combos(n, h, w, cin, cout, seed=0):
 
 def run(x, wpk, cout, kw, persist):
     os.environ["ADYOLO_W4_PERSIST"] = "1" if persist else "0"
+    ops.reload_thresholds()
     out = ops.conv3x3(x, wpk, cout, **kw)
     torch.cuda.synchronize()
     return out if isinstance(out, tuple) else (out, None)
@@ -99,6 +100,7 @@ def bench(batch, iters, stages, only=None):
             for rep in range(2):
                 for persist in (False, True):
                     os.environ["ADYOLO_W4_PERSIST"] = "1" if persist else "0"
+                    ops.reload_thresholds()
                     wp = wpk if (persist or cout % 64 == 0) else wp2        # (32 output channels: F(2x2) is the alternative)
                     fn = lambda: ops.conv3x3(x, wp, cout, **kw)                                        # noqa: E731
                     fn()
