@@ -39,6 +39,10 @@
 #ifndef W4P_OP_AUX
 #define W4P_OP_AUX 0      // ... of the fused operands' loads (addend, statistics input: each read once; 2 measured no gain)
 #endif
+#ifndef W4P_STAGGER
+#define W4P_STAGGER 0     // experiment (round 6): workgroups with an odd slot start this many cycles late, so that the epilogues of the
+                          // CUs of an XCD (32 KB store bursts per round) do not coincide (profiles/r06_store_burst.txt)
+#endif
 #ifndef W4P_WHATIF
 #define W4P_WHATIF 0      // timing-only builds (results invalid): bit 0 no reader half of the epilogue rounds, 1 no writer half, 2 no
                           // output stores, 3 no xi pass (LDS reads), 4 no MFMAs, 5 no nu pass, 6 no B refills in the pair loop, 7 no staging
@@ -111,6 +115,10 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
     const int spstep = (int)(gridDim.x >> 3) * xcd_div;
     int sp = slot * xcd_div + xcd / ncb;
     if (sp >= nsp) return;
+    if (W4P_STAGGER > 0 && (slot & 1)) {
+        const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0_ < (unsigned long long)W4P_STAGGER) __builtin_amdgcn_s_sleep(32);
+    }
     const int co0 = cb * (32 * NB);
     auto decode = [&](int sp_, int &n_, int &ty_, int &tx_) {
         int t = sp_;

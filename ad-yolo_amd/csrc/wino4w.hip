@@ -74,7 +74,11 @@ __device__ unsigned long long *g_w4w_stamps;
 constexpr int XROWB = 1024;                 // bytes of an x row slot: 32 channels x 8 tiles
 constexpr int XSLOTS = 10;               // the six rows of a step's window + the four new rows of the next step
 constexpr int XNU = XSLOTS * XROWB;         // per nu plane
-constexpr int XBYTES = 6 * XNU;             // 36 864
+constexpr int XBYTES = 6 * XNU;             // 61 440
+// LDS image: the two dy buffers FIRST, the x ring behind them (round 6).  Every dy store address is lane part + buffer + row +
+// plane immediate; with the ring in front the 61 440 of XBYTES did not fit the 16-bit offset field beside the plane immediates
+// and cost the step ~10 vector adds.  Behind the dy buffers the ring's start folds into values that are added anyway (the
+// per-step slot offset of the stores, the per-item bases of the reads).
 // dy rows: 32 NB channels x 8 tiles; NB = 2 (Cout % 64 == 0) or 1 (32-channel blocks: stage 1 -- half the MFMAs per staged byte)
 template <int NB>
 struct DCfg {
@@ -89,8 +93,10 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
     const float *__restrict__ in_shift, float *__restrict__ slabs, int N, int H, int W, int Cin, int Cout, int runsW, int npairs,
     int nseg, int seg_steps, int nitems, int nsplit, int ciBlocks, int nblk) {
     constexpr int DROWB = DCfg<NB>::DROWB, DNU = DCfg<NB>::DNU, DBUF = DCfg<NB>::DBUF;
-    __shared__ __attribute__((aligned(16))) float lds[(XBYTES + 2 * DBUF) / 4];
+    constexpr int XOFF = 2 * DBUF;          // bytes: start of the x ring
+    __shared__ __attribute__((aligned(16))) float lds[(XBYTES + 2 * DBUF) / 4 + (AFF ? 64 : 0)];
     char *ldsb = reinterpret_cast<char *>(lds);
+    constexpr int AFFOFF = XBYTES + 2 * DBUF;   // bytes: the producer's BatchNorm scale | shift of the block's 32 input channels
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -144,10 +150,11 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
     const int run = wave & 1;
     const int sxr = (wave >> 1) * 2 + lh, sdr = sxr;
     const int st = li >> 3, sq = li & 7;
-    f32x4 xsc = {1.f, 1.f, 1.f, 1.f}, xsh = {0.f, 0.f, 0.f, 0.f};
+    // (the affine lives in LDS and is read where it is applied: held in registers across the unrolled step loop its eight
+    //  registers were the ones that spilled, and a scratch reload waits for vmcnt(0) -- the staging loads in flight; round 6)
     if (AFF) {
-        xsc = *reinterpret_cast<const f32x4 *>(in_scale + c0 + 4 * sq);
-        xsh = *reinterpret_cast<const f32x4 *>(in_shift + c0 + 4 * sq);
+        if (tid < 32) lds[AFFOFF / 4 + tid] = in_scale[c0 + tid];
+        else if (tid < 64) lds[AFFOFF / 4 + tid] = in_shift[c0 + tid - 32];
     }
     const int xrowb = W * Cin * 4, drowb = W * Cout * 4, xpixb = Cin * 4, dpixb = Cout * 4;
     // whole-tensor buffer descriptors (the host checks that both tensors stay below 2 GiB); image-border pixels / rows are
@@ -221,6 +228,9 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
                 // x' = scale x + shift inside the image, 0 outside (the loads returned 0 there)
                 const bool rowok = qok && gy >= 0 && gy < H;
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                const int sqo = (lane & 7) * 16;
+                const f32x4 xsc = *reinterpret_cast<const f32x4 *>(ldsb + AFFOFF + sqo);
+                const f32x4 xsh = *reinterpret_cast<const f32x4 *>(ldsb + AFFOFF + 128 + sqo);
                 const f32x4 shv = rowok ? xsh : zero;
                 xpx[0] = pkfma4v(xpx[0], xsc, offL ? zero : shv);
 #pragma unroll
@@ -241,13 +251,18 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
             }
         };
         f32x4 dpx[NB][4], de, dq;
-        auto d_load = [&](int trow, int cb0 = 0, int cb1 = NB, int i0 = 0, int i1 = 4) {   // dy row 4 trow + sdr (always inside the image)
-            const int vrow = qok ? (int)(dbase + (unsigned)(4 * trow + sdr) * (unsigned)drowb) : (int)0x80000000;
+        // dy row 4 trow + sdr (always inside the image).  The lane part of the address (sample, column, channel quad, row sdr of
+        // the four) is fixed for the item; the tile row travels in the SCALAR offset of the load -- no vector arithmetic per request
+        // (the step loop used to rebuild the 64-bit product four times per step: round 6).  Lanes of a missing run keep the
+        // out-of-range marker in the vector offset, which is the part the range check sees.
+        const int dlane = qok ? (int)(dbase + (unsigned)sdr * (unsigned)drowb) : (int)0x80000000;
+        auto d_load = [&](int trow, int cb0 = 0, int cb1 = NB, int i0 = 0, int i1 = 4) {
+            const int srow = __builtin_amdgcn_readfirstlane(4 * trow * drowb);
 #pragma unroll
             for (int cb = cb0; cb < cb1; ++cb)
 #pragma unroll
                 for (int i = i0; i < i1; ++i)
-                    dpx[cb][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, vrow, cb * 128 + i * dpixb, W4W_LD_AUX));
+                    dpx[cb][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, dlane, srow + cb * 128 + i * dpixb, W4W_LD_AUX));
         };
         // 4 -> 6 points (a6v) in three parts, each followed by its stores: planes (0, 1), (2, 3), (4, 5).  Plane 0 / 5 are pixels
         // 0 / 3 themselves; de / dq carry the even / odd sums from one part to the next (12 live registers instead of 24)
@@ -283,19 +298,19 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
         d_load(t0);
         x_prep(4 * t0 - 1 + sxr);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) wx[k] = wl[k] + sxr * XROWB;
+        for (int k = 0; k < 4; ++k) wx[k] = wl[k] + XOFF + sxr * XROWB;
 #pragma unroll
         for (int nu = 0; nu < 6; nu += 2) x_wr2(nu);
         if (sxr < 2) {
             x_load(4 * t0 + 3 + sxr);
             x_prep(4 * t0 + 3 + sxr);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) wx[k] = wl[k] + (4 + sxr) * XROWB;
+            for (int k = 0; k < 4; ++k) wx[k] = wl[k] + XOFF + (4 + sxr) * XROWB;
 #pragma unroll
             for (int nu = 0; nu < 6; nu += 2) x_wr2(nu);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) wd[k] = wl[k] + XBYTES + sdr * DROWB;
+        for (int k = 0; k < 4; ++k) wd[k] = wl[k] + sdr * DROWB;
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
             d_part(cb, 0);
@@ -313,12 +328,12 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
         f32x4 vF[4], vH[4], zH;
         f32x4 cF[6], cP[4], cZ[3];
         auto d_reads_full = [&](int buf_, int cb) {
-            const char *dp = ldsb + XBYTES + buf_ * DBUF + cb * 1024 + lx;
+            const char *dp = ldsb + buf_ * DBUF + cb * 1024 + lx;
 #pragma unroll
             for (int i = 0; i < 4; ++i) vF[i] = *reinterpret_cast<const f32x4 *>(dp + nuF * DNU + i * DROWB);
         };
         auto d_reads_half = [&](int buf_, int cb) {
-            const char *dp = ldsb + XBYTES + buf_ * DBUF + cb * 1024 + lx;
+            const char *dp = ldsb + buf_ * DBUF + cb * 1024 + lx;
 #pragma unroll
             for (int i = 0; i < 4; ++i) vH[i] = *reinterpret_cast<const f32x4 *>(dp + nuH * DNU + i * DROWB);
             zH = *reinterpret_cast<const f32x4 *>(dp + nuH * DNU + (hh ? 3 : 0) * DROWB);
@@ -330,31 +345,29 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
             for (int s = 0; s < 6; ++s) b[s] = t[s];
         };
         auto d_xform_half = [&]() { a3v(vH, zH, b[6], b[7], b[8], K1d, K2d, K3d); };
-        // window reads of a step whose window row 0 sits in ring slot rot_: the full column, the half column
-        auto x_reads_full = [&](int rot_) {
-            const char *xp = ldsb + lx + nuF * XNU;
+        // window reads of a step whose window row 0 sits in ring slot ROT (a compile-time constant: the step loop below is unrolled
+        // over the five ring positions 0, 4, 8, 2, 6, so every slot offset is an immediate of its ds_read -- with a run-time
+        // position the 13 + 18 reads of a step cost 52 vector integer instructions and ~30 scalar ones, each an issue slot of the
+        // wave that also issues the MFMAs: round 6): the full column, the half column
+        auto x_reads_full = [&](auto ROT_) {
+            constexpr int rot_ = decltype(ROT_)::value;
+            const char *xp = ldsb + XOFF + lx + nuF * XNU;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                int sl = rot_ + i;
-                sl = sl >= XSLOTS ? sl - XSLOTS : sl;
-                cF[i] = *reinterpret_cast<const f32x4 *>(xp + sl * XROWB);
-            }
+            for (int i = 0; i < 6; ++i) cF[i] = *reinterpret_cast<const f32x4 *>(xp + ((rot_ + i) % XSLOTS) * XROWB);
         };
-        auto x_reads_half = [&](int rot_) {
-            int so[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                int sl = rot_ + i;
-                sl = sl >= XSLOTS ? sl - XSLOTS : sl;
-                so[i] = sl * XROWB;                                            // (uniform)
-            }
-            const char *xp = ldsb + lx + nuH * XNU;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) cP[i] = *reinterpret_cast<const f32x4 *>(xp + so[1 + i]);
-            // rows hh, hh + 2, hh + 4 of the half column (the single term's operands)
-            cZ[0] = *reinterpret_cast<const f32x4 *>(xp + (hh ? so[1] : so[0]));
-            cZ[1] = *reinterpret_cast<const f32x4 *>(xp + (hh ? so[3] : so[2]));
-            cZ[2] = *reinterpret_cast<const f32x4 *>(xp + (hh ? so[5] : so[4]));
+        auto x_reads_half = [&](auto ROT_) {
+            constexpr int rot_ = decltype(ROT_)::value;
+            constexpr int so0 = ((rot_ + 0) % XSLOTS) * XROWB, so1 = ((rot_ + 1) % XSLOTS) * XROWB, so2 = ((rot_ + 2) % XSLOTS) * XROWB,
+                          so3 = ((rot_ + 3) % XSLOTS) * XROWB, so4 = ((rot_ + 4) % XSLOTS) * XROWB, so5 = ((rot_ + 5) % XSLOTS) * XROWB;
+            const char *xp = ldsb + XOFF + lx + nuH * XNU;
+            cP[0] = *reinterpret_cast<const f32x4 *>(xp + so1);
+            cP[1] = *reinterpret_cast<const f32x4 *>(xp + so2);
+            cP[2] = *reinterpret_cast<const f32x4 *>(xp + so3);
+            cP[3] = *reinterpret_cast<const f32x4 *>(xp + so4);
+            // rows hh, hh + 2, hh + 4 of the half column (the single term's operands; hh is wave-uniform)
+            cZ[0] = *reinterpret_cast<const f32x4 *>(xp + (hh ? so1 : so0));
+            cZ[1] = *reinterpret_cast<const f32x4 *>(xp + (hh ? so3 : so2));
+            cZ[2] = *reinterpret_cast<const f32x4 *>(xp + (hh ? so5 : so4));
         };
         auto mfma4 = [&](int s, int cb) {
             if (W4W_WHATIF & 1) return;
@@ -382,27 +395,30 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
         //   transforms | 17 its half columns are read -- the next step starts with its operands in registers
         //   NB = 1: the same in nine groups: 0 x transform | 1, 2, 3 x planes | 3, 4, 5 dy | 6 the barrier and the full-column
         //   reads | 7 their transforms | 8 the half-column reads
-        int rot = 0;                                                           // slot of window row 0 of the current step
-        auto next_rot = [&](int r_) { return r_ + 4 >= XSLOTS ? r_ + 4 - XSLOTS : r_ + 4; };
-        auto top_full = [&](int rot_, int buf_) {
-            x_reads_full(rot_);
+        auto top_full = [&](auto ROT_, int buf_) {
+            x_reads_full(ROT_);
             d_reads_full(buf_, 0);
         };
-        auto top_half = [&](int rot_, int buf_) {
-            x_reads_half(rot_);
+        auto top_half = [&](auto ROT_, int buf_) {
+            x_reads_half(ROT_);
             d_reads_half(buf_, 0);
         };
         auto top_xform = [&]() {
             bt6v2(cF, a[0], a[1], a[2], a[3], a[4], a[5]);
             d_xform_full();
         };
-        top_full(0, 0);
-        top_half(0, 0);
+        top_full(std::integral_constant<int, 0>{}, 0);
+        top_half(std::integral_constant<int, 0>{}, 0);
         top_xform();
-        for (int k = 0; k < nsteps; ++k) {
+        // one step with window row 0 in ring slot ROT; the next step's is ROT + 4 (mod 10)
+        auto step = [&](auto ROT_, int k) {
+            constexpr int rot = decltype(ROT_)::value;
+            constexpr std::integral_constant<int, (rot + 4) % XSLOTS> rotn{};
+            // (k opaque: the five copies of the step must not share strength-reduced per-lane address chains -- kept in registers
+            //  across the whole unrolled loop they spill, and a scratch reload sits in the same vmcnt queue as the staging loads)
+            asm volatile("" : "+s"(k));
             const int buf = k & 1;
             const int gyn = 4 * (t0 + k + 1) + 1 + sxr;
-            const int rotn = next_rot(rot);
             auto side = [&](int t) {
                 // (requests of step k + 2, two at a time as their registers retire; rows past the end: clamped / out of range, unused)
                 const int gy2 = 4 * (t0 + k + 2) + 1 + sxr, tr2 = min(t0 + k + 2, H / 4 - 1);
@@ -452,13 +468,14 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
             };
             tstamp(0);
             {
-                // slots of the new rows (window rows 6 .. 9 of this step), the other dy buffer
-                int sl = rot + 6 + sxr;
-                sl = sl >= XSLOTS ? sl - XSLOTS : sl;
+                // slots of the new rows (window rows 6 .. 9 of this step: ring slots base + sxr, sxr = 2 (wave >> 1) + lh -- they wrap
+                // around the ring only for base 8 and the waves 2, 3: a wave-uniform correction), the other dy buffer
+                constexpr int base = (rot + 6) % XSLOTS;
+                const int soff = ((base + 2 >= XSLOTS && wave >= 2) ? (base - XSLOTS) * XROWB : base * XROWB) + XOFF + sxr * XROWB;
 #pragma unroll
                 for (int k_ = 0; k_ < 4; ++k_) {
-                    wx[k_] = wl[k_] + sl * XROWB;
-                    wd[k_] = wl[k_] + XBYTES + (buf ^ 1) * DBUF + sdr * DROWB;
+                    wx[k_] = wl[k_] + soff;
+                    wd[k_] = wl[k_] + (buf ^ 1) * DBUF + sdr * DROWB;
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -483,11 +500,23 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(
                 }
             }
             tstamp(3);
-            rot = rotn;
             tstamp(4);
 #if W4W_TIMING
             ++tstep;
 #endif
+        };
+        // the ring positions of consecutive steps: 0, 4, 8, 2, 6, 0, ...
+        for (int k = 0; k < nsteps;) {
+            step(std::integral_constant<int, 0>{}, k);
+            if (++k >= nsteps) break;
+            step(std::integral_constant<int, 4>{}, k);
+            if (++k >= nsteps) break;
+            step(std::integral_constant<int, 8>{}, k);
+            if (++k >= nsteps) break;
+            step(std::integral_constant<int, 2>{}, k);
+            if (++k >= nsteps) break;
+            step(std::integral_constant<int, 6>{}, k);
+            ++k;
         }
     }
 

@@ -79,7 +79,7 @@ def _align_relu_masks(model, captured, g, bits=None):
 
 # tensors allowed above 5 x the reference's own float32 deviation in the UN-ALIGNED gradient comparison of the seed-100 step, with
 # the factor measured for them (see the comment at the comparison): {algorithm: {parameter name: factor}}
-UNALIGNED_WHITELIST = {"winograd4": {}}
+UNALIGNED_WHITELIST = {"winograd4": {"encoder.layer1.2.se.fc.0.weight": 5.5}}       # measured 5.13 x (gpurun_out/r06/pytest1.txt)
 
 
 @pytest.mark.parametrize("algo", ["direct", "winograd", "winograd4"])
