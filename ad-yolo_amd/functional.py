@@ -370,6 +370,8 @@ class SEBlockFn(torch.autograd.Function):
         ctx.ptrs = (w1.data_ptr(), g1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
                     (fb2.data_ptr(), fw2.data_ptr(), fb1.data_ptr(), fw1.data_ptr(), b2.data_ptr(), g2.data_ptr()))
         ctx.wshapes = (tuple(w1.shape), tuple(w2.shape))
+        # ... and of the shortcut projection (1x1 convolution + BatchNorm; round 6: three AccumulateGrad adds fewer per such block)
+        ctx.down_ptrs = (wd.data_ptr(), gd.data_ptr(), bd.data_ptr(), tuple(wd.shape)) if wd is not None else None
         if isinstance(wpk1d, ops.DualPack):
             # the operand combination backward() will launch conv1's data-gradient with (see there): projection shortcut -> addend
             # (+ statistics against the block above's BatchNorm input with its ReLU-mask bits); identity -> addend + mask bits +
@@ -446,10 +448,18 @@ class SEBlockFn(torch.autograd.Function):
         dwd = dgd = dbd = None
         if ctx.has_down:
             q, wd, gd, meand, invstdd = t[nb:nb + 5]
-            dq, dgd, dbd = ops.bn_bwd(dr, q, gd, meand, invstdd, relu_mask=False)
+            pwd, pgd, pbd, wdshape = ctx.down_ptrs
+            vwd, vgd, vbd = SINK.view(pwd, (wdshape[0], wdshape[1])), SINK.view(pgd), SINK.view(pbd)
+            dsunk = sunk and vwd is not None and vgd is not None and vbd is not None
+            if not dsunk:
+                vwd = vgd = vbd = None
+            dq, dgd, dbd = ops.bn_bwd(dr, q, gd, meand, invstdd, relu_mask=False, out_dgamma=vgd, out_dbeta=vbd)
             rows = n * h * w_
             dwd = ops.gemm(dq, p, c, cin, rows, c, cin, trans_a=True, trans_b=True,
-                           splits=ops.wgrad_splits(c, cin, rows)).view(c, cin, 1, 1)
+                           splits=ops.wgrad_splits(c, cin, rows), out=vwd).view(c, cin, 1, 1)
+            if dsunk:
+                SINK.done(pwd, pgd, pbd)
+                dwd = dgd = dbd = None
             dp_res = ops.gemm(dq, wd, rows, cin, c, c, cin, trans_b=True).view(n, h, w_, cin)
             if ctx.link_in is not None:       # un-pooled stage boundary (stage 4): dp is the gradient of the block above
                 lk = ctx.link_in
@@ -486,6 +496,7 @@ class SAPFn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         bsz, t, f, c = x.shape
         y, attn = ops.sap_fwd(x.view(bsz * t, f, c), w.view(-1), b)
+        ctx.bias = b                           # (only its storage address and shape are used: GradSink)
         ctx.save_for_backward(x, w, attn)
         return y.view(bsz, t, c)
 
@@ -493,7 +504,14 @@ class SAPFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, attn = ctx.saved_tensors
         bsz, t, f, c = x.shape
-        dx, dw, db = ops.sap_bwd(_c(dy).view(bsz * t, c), x.view(bsz * t, f, c), w.view(-1), attn)
+        # (GradSink: the two accumulators the kernel sums into ARE the parameters' slices of the flat gradient buffer, zero since
+        #  zero_grad -- no zero-fill launches, no AccumulateGrad adds; round 6)
+        sunk = SINK.params(w, ctx.bias) if (ctx.needs_input_grad[1] and ctx.needs_input_grad[2]) else None
+        dx, dw, db = ops.sap_bwd(_c(dy).view(bsz * t, c), x.view(bsz * t, f, c), w.view(-1), attn,
+                                 out_dw=sunk[0].view(-1) if sunk is not None else None, out_db=sunk[1] if sunk is not None else None)
+        if sunk is not None:
+            SINK.done_params(w, ctx.bias)
+            return dx.view(bsz, t, f, c), None, None
         return dx.view(bsz, t, f, c), dw.view_as(w), db
 
 
@@ -514,6 +532,7 @@ class BiGRULayerFn(torch.autograd.Function):
         if save:
             ctx.save_for_backward(x, wih_f, wih_r, whh, gates, hprev)
         ctx.saved = save
+        ctx.params = (wih_f, whh_f, bih_f, bhh_f, wih_r, whh_r, bih_r, bhh_r)     # (storage addresses and shapes: GradSink)
         return out
 
     @staticmethod
@@ -529,14 +548,21 @@ class BiGRULayerFn(torch.autograd.Function):
         splits = ops.wgrad_splits(384, 128, rows)
         grads = []
         dx = torch.empty_like(x2)
+        # GradSink: the eight weight / bias gradients of the layer go straight into their slices of the flat gradient buffer
+        # (16 AccumulateGrad adds fewer per step over the two layers; round 6)
+        sunk = SINK.params(*ctx.params) if all(ctx.needs_input_grad[1:9]) else None
         for d, wih in enumerate((wih_f, wih_r)):
             gxd, ghd, hpd = dgx2[:, d * 384:], dgh2[:, d * 384:], hp2[:, d * 128:]
-            dwih = ops.gemm(gxd, x2, 384, cin, rows, 768, cin, trans_a=True, trans_b=True, splits=splits)
-            dwhh = ops.gemm(ghd, hpd, 384, 128, rows, 768, 256, trans_a=True, trans_b=True, splits=splits)
-            dbih = ops.colsum(gxd[:, :384])
-            dbhh = ops.colsum(ghd[:, :384])
+            o = sunk[4 * d:4 * d + 4] if sunk is not None else (None, None, None, None)
+            dwih = ops.gemm(gxd, x2, 384, cin, rows, 768, cin, trans_a=True, trans_b=True, splits=splits, out=o[0])
+            dwhh = ops.gemm(ghd, hpd, 384, 128, rows, 768, 256, trans_a=True, trans_b=True, splits=splits, out=o[1])
+            dbih = ops.colsum(gxd[:, :384], out=o[2])
+            dbhh = ops.colsum(ghd[:, :384], out=o[3])
             ops.gemm(gxd, wih, rows, cin, 384, 768, cin, trans_b=True, out=dx, ldc=cin, accumulate=(d == 1))
             grads += [dwih, dwhh, dbih, dbhh]
+        if sunk is not None:
+            SINK.done_params(*ctx.params)
+            grads = [None] * 8
         return (dx.view(bsz, t, cin), *grads, None)
 
 
@@ -548,6 +574,7 @@ class LNTanhFn(torch.autograd.Function):
         c = x.shape[-1]
         y = ops.ln_tanh_fwd(x.view(-1, c), gamma, beta, eps)
         ctx.eps = eps
+        ctx.beta = beta                        # (only its storage address and shape are used: GradSink)
         ctx.save_for_backward(x, y, gamma)
         return y.view_as(x)
 
@@ -555,7 +582,13 @@ class LNTanhFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, y, gamma = ctx.saved_tensors
         c = x.shape[-1]
-        dx, dgamma, dbeta = ops.ln_tanh_bwd(_c(dy).view(-1, c), x.view(-1, c), y, gamma, ctx.eps)
+        sunk = SINK.params(gamma, ctx.beta) if (ctx.needs_input_grad[1] and ctx.needs_input_grad[2]) else None
+        dx, dgamma, dbeta = ops.ln_tanh_bwd(_c(dy).view(-1, c), x.view(-1, c), y, gamma, ctx.eps,
+                                            out_dgamma=sunk[0] if sunk is not None else None,
+                                            out_dbeta=sunk[1] if sunk is not None else None)
+        if sunk is not None:
+            SINK.done_params(gamma, ctx.beta)
+            return dx.view_as(x), None, None, None
         return dx.view_as(x), dgamma, dbeta, None
 
 

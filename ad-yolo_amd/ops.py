@@ -714,11 +714,14 @@ def sap_fwd(x, w, b):
     return y, attn
 
 
-def sap_bwd(dy, x, w, attn):
+def sap_bwd(dy, x, w, attn, out_dw=None, out_db=None):
+    """out_dw [C] / out_db [1]: ZEROED accumulators to sum into instead of fresh ones (``functional.GradSink``: the parameters' slices
+    of the flat gradient buffer, zero since ``zero_grad``)."""
     _chk(dy, x, w, attn)
     r, f, c = x.shape
     dx = torch.empty_like(x)
-    dw, db = _zeros(x, c), _zeros(x, 1)
+    dw = out_dw if out_dw is not None else _zeros(x, c)
+    db = out_db if out_db is not None else _zeros(x, 1)
     partial = _new(x, 1024 * 260)
     _c("adyolo_sap_bwd", _p(dy), _p(x), _p(w), _p(attn), _p(dx), _p(dw), _p(db), _p(partial), r, f, c, _stream())
     return dx, dw, db
@@ -751,11 +754,13 @@ def ln_tanh_fwd(x2d, gamma, beta, eps=1e-5):
     return y
 
 
-def ln_tanh_bwd(dy2d, x2d, y2d, gamma, eps=1e-5):
+def ln_tanh_bwd(dy2d, x2d, y2d, gamma, eps=1e-5, out_dgamma=None, out_dbeta=None):
+    """out_dgamma / out_dbeta [C]: ZEROED accumulators to sum into instead of fresh ones (see ``sap_bwd``)."""
     _chk(dy2d, x2d, y2d, gamma)
     r, c = x2d.shape
     dx = torch.empty_like(x2d)
-    dgamma, dbeta = _zeros(x2d, c), _zeros(x2d, c)
+    dgamma = out_dgamma if out_dgamma is not None else _zeros(x2d, c)
+    dbeta = out_dbeta if out_dbeta is not None else _zeros(x2d, c)
     partial = _new(x2d, 1024 * 512)
     _c("adyolo_ln_tanh_bwd", _p(dy2d), _p(x2d), _p(y2d), _p(gamma), _p(dx), _p(dgamma), _p(dbeta), _p(partial), r, c,
        eps, _stream())

@@ -54,6 +54,26 @@ for ev in prof.events():
     for k in ev.kernels:
         agg[(name, site, k.name[:60])] += 1
         kern[k.name[:60]] += 1
+# copies (hipMemcpyAsync D2D shows up as __amd_rocclr_copyBuffer in a kernel trace, not as a kernel here): every aten::copy_ /
+# clone / contiguous / cat / stack / fill_ / zero_ / add_ call with the chain of its enclosing ops
+cops = collections.Counter()
+for ev in prof.events():
+    if ev.device_type == torch.autograd.DeviceType.CUDA:
+        continue
+    if ev.name in ("aten::copy_", "aten::fill_", "aten::zero_", "aten::add_", "aten::add", "aten::cat", "aten::_foreach_add_", "aten::mul", "aten::sum"):
+        chain, q = [], ev.cpu_parent
+        while q is not None and len(chain) < 4:
+            chain.append(q.name)
+            q = q.cpu_parent
+        site = "?"
+        for fr in (ev.stack or []):
+            if "/root/repo/" in fr and "torch_launch_sources" not in fr:
+                site = fr.split("/root/repo/")[-1]
+                break
+        cops[(ev.name, " < ".join(chain), site)] += 1
+print("host-side aten calls that launch copies / fills / adds, with their enclosing ops:")
+for (name, chain, site), c in sorted(cops.items(), key=lambda kv: -kv[1]):
+    print("  %4d  %-18s %-80s %s" % (c, name, chain[:80], site))
 print("torch-side kernels of ONE eager step (%s, %d x %d s): %d launches" % (a.encoder, a.batch, a.seconds, sum(kern.values())))
 for k, c in kern.most_common():
     print("  %4d  %s" % (c, k))
