@@ -27,7 +27,19 @@ for st, (h, w, c) in SHAPES.items():
 
     def bn_apply():
         _c("adyolo_bn_bwd_apply", _p(dy), _p(x), _p(g), _p(m), _p(iv), _p(sdy), _p(sdyx), _p(dx), NULL, NULL, NULL, NULL, rows, c, 1, 1.0, _stream())
-    for name, fn in (("bn_bwd_apply", bn_apply),):
+    cc, rr = torch.randn(n, h, w, c, device="cuda:0"), torch.randn(n, h, w, c, device="cuda:0")
+    sc, sh = torch.rand(c, device="cuda:0") + 0.5, torch.randn(c, device="cuda:0")
+    sv = torch.rand(n, c, device="cuda:0")
+    eo = torch.empty_like(cc)
+    from adyolo_amd import _lib
+    words = _lib.load().adyolo_relu_mask_words(n, h * w, c)
+    bits = torch.empty(words, dtype=torch.int64, device="cuda:0")
+
+    def se_fwd():
+        _c("adyolo_se_tail_fwd", _p(cc), _p(rr), _p(sc), _p(sh), _p(sv), NULL, NULL, _p(eo), _p(bits), n, h * w, c, _stream())
+    def se_fwd_nobits():
+        _c("adyolo_se_tail_fwd", _p(cc), _p(rr), _p(sc), _p(sh), _p(sv), NULL, NULL, _p(eo), NULL, n, h * w, c, _stream())
+    for name, fn in (("bn_bwd_apply", bn_apply), ("se_tail_fwd", se_fwd), ("se_tail_fwd/nobits", se_fwd_nobits)):
         fn()
         torch.cuda.synchronize()
         ts = []
