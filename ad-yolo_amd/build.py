@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libadyolo_hip.so")
-SOURCES = ["conv.hip", "wino.hip", "wino4.hip", "wino4w.hip", "wino4p_e0.hip", "wino4p_e1.hip", "wino4p_e2.hip", "wino4p_e9.hip", "wino4p_e27.hip", "wino4p_e31.hip", "gemm.hip", "norm.hip", "seq.hip", "loss.hip", "losses.hip", "features.hip", "features_mic.hip", "conformer.hip", "wino1d.hip", "attention.hip", "aug.hip", "optim.hip"]
+SOURCES = ["conv.hip", "wino.hip", "wino4.hip", "wino4w.hip", "wino4p_e0.hip", "wino4p_e1.hip", "wino4p_e2.hip", "wino4p_e9.hip", "wino4p_e15.hip", "wino4p_e27.hip", "wino4p_e31.hip", "gemm.hip", "norm.hip", "seq.hip", "loss.hip", "losses.hip", "features.hip", "features_mic.hip", "conformer.hip", "wino1d.hip", "attention.hip", "aug.hip", "optim.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # per-file additions.  wino4.hip: the depth of its B-fragment register ring (9, 12 or 18; 9 = 2304 matrix cycles ahead; 12 measured the same)
 # wino.hip: no SLP vectoriser -- it pairs the float4 transform arithmetic into v_pk_fma_f32 across DIFFERENT ds_read results and gathers

@@ -108,4 +108,45 @@ __device__ __forceinline__ double block_colsum32(const float *__restrict__ parti
     return s;
 }
 
+// The same for TWO arrays at once (the sum and the sum of squares / the two BatchNorm-backward sums: persample_reduce_kernel):
+// both arrays' loads are in flight together and the workgroup meets at two barriers instead of four.  Each total is summed in
+// exactly the order block_colsum32 uses (bit-identical results).  `red` = 512 doubles of LDS.
+__device__ __forceinline__ void block_colsum32x2(const float *__restrict__ pa, const float *__restrict__ pb, int nparts, size_t ld,
+                                                 int c0, int C, double *red, double &ra, double &rb) {
+    const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+    const int c = c0 + cx;
+    double s = 0.0, t = 0.0;
+    if (c < C) {
+        double s1 = 0.0, s2 = 0.0, s3 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+        int p = py;
+        for (; p + 24 < nparts; p += 32) {
+            const float a0 = pa[(size_t)p * ld + c], a1 = pa[(size_t)(p + 8) * ld + c];
+            const float a2 = pa[(size_t)(p + 16) * ld + c], a3 = pa[(size_t)(p + 24) * ld + c];
+            const float b0 = pb[(size_t)p * ld + c], b1 = pb[(size_t)(p + 8) * ld + c];
+            const float b2 = pb[(size_t)(p + 16) * ld + c], b3 = pb[(size_t)(p + 24) * ld + c];
+            s += (double)a0; s1 += (double)a1; s2 += (double)a2; s3 += (double)a3;
+            t += (double)b0; t1 += (double)b1; t2 += (double)b2; t3 += (double)b3;
+        }
+        for (; p < nparts; p += 8) {
+            s += (double)pa[(size_t)p * ld + c];
+            t += (double)pb[(size_t)p * ld + c];
+        }
+        s = (s + s1) + (s2 + s3);
+        t = (t + t1) + (t2 + t3);
+    }
+    red[threadIdx.x] = s;
+    red[256 + threadIdx.x] = t;
+    __syncthreads();
+    if (py == 0) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            s += red[k * 32 + cx];
+            t += red[256 + k * 32 + cx];
+        }
+    }
+    __syncthreads();
+    ra = s;
+    rb = t;
+}
+
 }  // namespace adyolo

@@ -740,7 +740,7 @@ extern "C" int adyolo_wino4_fwd(const float *x, const float *u, const float *bia
     // ones the SE-ResNet block launches); everything else, and ADYOLO_W4_PERSIST=0, takes the one-patch-per-workgroup kernel below.
     const int epi = (stats ? 1 : 0) | (addend ? 2 : 0) | (addend_mask ? 4 : 0) | (stat_aux ? 8 : 0) | (stat_mask ? 16 : 0);
     const bool bits_ok = (!addend_mask || (mask_bits & 1)) && (!stat_mask || (mask_bits & 2));
-    if (xcd_div > 0 && bits_ok && !bias && (sw & 1) && (epi == 0 || epi == 1 || epi == 2 || epi == 9 || epi == 27 || epi == 31)) {
+    if (xcd_div > 0 && bits_ok && !bias && (sw & 1) && (epi == 0 || epi == 1 || epi == 2 || epi == 9 || epi == 15 || epi == 27 || epi == 31)) {
         static int ncus = 0;
         if (ncus == 0) {
             int dev = 0, v = 0;
@@ -759,6 +759,7 @@ extern "C" int adyolo_wino4_fwd(const float *x, const float *u, const float *bia
             case 1: w4::launch_wino4p<1>(a); break;
             case 2: w4::launch_wino4p<2>(a); break;
             case 9: w4::launch_wino4p<9>(a); break;
+            case 15: w4::launch_wino4p<15>(a); break;
             case 27: w4::launch_wino4p<27>(a); break;
             default: w4::launch_wino4p<31>(a); break;
         }

@@ -17,7 +17,7 @@ struct W4Launch {                                         // everything adyolo_w
 // kernel does not survive run-time operand combinations (conditionally loaded operand arrays were merged through scratch
 // memory).  Instantiated: the combinations the SE-ResNet block launches (functional.py) -- 0 plain, 1 forward convolutions,
 // 9 data-gradient of conv2, 2 / 27 / 31 data-gradient of conv1 (projection shortcut after a pooled / un-pooled stage boundary,
-// identity shortcut); every other combination, and
+// identity shortcut), 15 the same for the first block (statistics against the stem's BatchNorm input: no mask); every other combination, and
 // masks given as float tensors, take the one-patch kernel (wino4.hip)
 template <int EPI>
 void launch_wino4p(const W4Launch &a);

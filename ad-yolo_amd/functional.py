@@ -375,7 +375,8 @@ class SEBlockFn(torch.autograd.Function):
         if isinstance(wpk1d, ops.DualPack):
             # the operand combination backward() will launch conv1's data-gradient with (see there): projection shortcut -> addend
             # (+ statistics against the block above's BatchNorm input with its ReLU-mask bits); identity -> addend + mask bits +
-            # statistics / mask bits of the block above; the other combinations (the very first block's, the unfused ones) have no
+            # statistics / mask bits of the block above; the very first block -> addend + mask bits + statistics against the stem's
+            # BatchNorm input (combination 15, persistent since round 6); the other combinations (the unfused ones) have no
             # persistent F(4x4) form
             lk = ctx.link_in
             if wd is not None:
@@ -383,7 +384,9 @@ class SEBlockFn(torch.autograd.Function):
             elif lk is not None:
                 p_ok = ebits is not None and lk.ebits is not None
             else:
-                p_ok = not FUSE_DR
+                stem15 = FUSE_DR and ebits is not None and ctx.stem_holder is not None and \
+                    getattr(ctx.stem_holder, "stem_bn", None) is not None
+                p_ok = (not FUSE_DR) or stem15
             wpk1d = wpk1d.pick(n, h, w_, cin, True, p_ok)
         tensors = [p, src, scale1, cc, e, g1, mean1, invstd1, g2, b2, mean2, invstd2, ssum2, pooled, hid, s, fw1, fw2,
                    wpk1d, wpk2d, shift1]

@@ -148,7 +148,8 @@ _THRESHOLD_KEYS = ("min_k", "min_k_addend", "min_wgs", "min_wgrad_work", "min_k_
 
 
 def reload_thresholds():
-    """ADYOLO_W4_MIN_K (64): smallest contraction that gets the F(4x4) form packed; ADYOLO_W4_MIN_K_ADDEND (32; 128 until the
+    """ADYOLO_W4_MIN_K (32; 64 until round 6 -- with the persistent kernel the 32 -> 64 stage transition runs 0.56 -> 0.42 ms on
+    F(4x4)): smallest contraction that gets the F(4x4) form packed; ADYOLO_W4_MIN_K_ADDEND (32; 128 until the
     persistent kernel of round 5): the same for launches that add a tensor in their epilogue; ADYOLO_W4_MIN_WGS (200): below
     that many 64-channel x patch work items a launch stays on the F(2x2) kernel (two workgroups per CU); ADYOLO_W4W_MIN_WORK
     (6 M): smallest (tile rows of 16-column runs) x Cin x Cout = N W/16 H/4 Cin Cout for the F(4x4)-domain weight gradient
@@ -162,7 +163,7 @@ def reload_thresholds():
     ADYOLO_WGRAD_ALGO (weight-gradient algorithm when it differs from ADYOLO_CONV_ALGO).
     Returns the numeric thresholds (``switch_table()``: everything)."""
     env = os.environ.get
-    W4_THRESHOLDS.update(min_k=int(env("ADYOLO_W4_MIN_K", "64")),
+    W4_THRESHOLDS.update(min_k=int(env("ADYOLO_W4_MIN_K", "32")),
                          min_k_addend=int(env("ADYOLO_W4_MIN_K_ADDEND", "32")),
                          min_wgs=int(env("ADYOLO_W4_MIN_WGS", "200")),
                          min_wgrad_work=int(env("ADYOLO_W4W_MIN_WORK", "6000000")),
@@ -195,7 +196,7 @@ reload_thresholds()
 DISPATCH_LOG = None
 
 
-W4P_EPIS = (0, 1, 2, 9, 27, 31)            # operand combinations the persistent F(4x4) kernel is built for (csrc/wino4p_launch.hpp)
+W4P_EPIS = (0, 1, 2, 9, 15, 27, 31)            # operand combinations the persistent F(4x4) kernel is built for (csrc/wino4p_launch.hpp)
 
 
 def w4_narrow_ok(cin, cout):

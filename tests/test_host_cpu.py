@@ -396,12 +396,12 @@ def test_dispatch_thresholds_and_parameter_epoch(monkeypatch):
     from adyolo_amd import ops
     for k in ("ADYOLO_W4_MIN_K", "ADYOLO_W4_MIN_K_ADDEND", "ADYOLO_W4_MIN_WGS"):
         monkeypatch.delenv(k, raising=False)
-    assert ops.reload_thresholds() == {"min_k": 64, "min_k_addend": 32, "min_wgs": 200, "min_wgrad_work": 6000000, "min_k_32": 32}
-    assert ops._w4_eligible(64, 64) and not ops._w4_eligible(32, 64) and not ops._w4_eligible(64, 32) and not ops._w4_eligible(1024, 64)
-    monkeypatch.setenv("ADYOLO_W4_MIN_K", "32")                     # (the fixture reloads)
-    assert ops.W4_THRESHOLDS["min_k"] == 32 and ops._w4_eligible(32, 64)
+    assert ops.reload_thresholds() == {"min_k": 32, "min_k_addend": 32, "min_wgs": 200, "min_wgrad_work": 6000000, "min_k_32": 32}
+    assert ops._w4_eligible(64, 64) and ops._w4_eligible(32, 64) and not ops._w4_eligible(64, 32) and not ops._w4_eligible(1024, 64)
+    monkeypatch.setenv("ADYOLO_W4_MIN_K", "64")                     # (the fixture reloads)
+    assert ops.W4_THRESHOLDS["min_k"] == 64 and not ops._w4_eligible(32, 64)
     monkeypatch.delenv("ADYOLO_W4_MIN_K")                            # (the fixture reloads on delenv too)
-    assert ops.W4_THRESHOLDS["min_k"] == 64 and ops.reload_thresholds()["min_k"] == 64
+    assert ops.W4_THRESHOLDS["min_k"] == 32 and ops.reload_thresholds()["min_k"] == 32
     # the on / off switches live in the same table, and the table is what recorded graphs are keyed on
     for k in ("ADYOLO_W4_PERSIST", "ADYOLO_W4_NARROW", "ADYOLO_WINO1D"):
         monkeypatch.delenv(k, raising=False)

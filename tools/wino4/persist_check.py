@@ -40,6 +40,8 @@ def combos(n, h, w, cin, cout, seed=0):
         "fwd conv2: affine, stats (1)": dict(in_affine=aff, want_stats=True),
         "dgrad conv2: stats vs bn aux (9)": dict(want_stats=True, stat_bn=(aux, mean, invstd)),
         "dgrad conv1, projection after a pooled boundary: addend (2)": dict(addend=dy),
+        "dgrad conv1 of the first block: addend + bits, stats vs the stem's aux (15)": dict(addend=dy, addend_mask=bits1, want_stats=True,
+                                                                                           stat_bn=(aux, mean, invstd)),
         "dgrad conv1, projection: addend, stats vs aux, stat bits (27)": dict(addend=dy, want_stats=True, stat_bn=(aux, mean, invstd),
                                                                               stat_mask=bits2),
         "dgrad conv1, identity: addend + bits, stats vs aux, stat bits (31)": dict(addend=dy, addend_mask=bits1, want_stats=True,
