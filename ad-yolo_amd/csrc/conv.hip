@@ -382,6 +382,10 @@ __global__ __launch_bounds__(256, 4) void stem_fwd_kernel(const float *__restric
                                                           float *__restrict__ stats, int H, int W, int tilesW, int tilesH,
                                                           int relu) {
     __shared__ float red[4 * 32 * 2];
+    // output tiles of the waves (32 pixels x 32 channels each, rows padded to 36 floats): the MFMA result has a lane own one
+    // CHANNEL of 16 pixels, so the direct epilogue was 16 dword stores per lane and row (256 B per wave-instruction) for a
+    // 1.26 GB output; through LDS a lane stores four 16-byte pieces (1 KB per wave-instruction, whole 128-byte pixels; round 6)
+    __shared__ __attribute__((aligned(16))) float otile[4][32 * 36];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     int bid = blockIdx.x;
@@ -418,18 +422,26 @@ __global__ __launch_bounds__(256, 4) void stem_fwd_kernel(const float *__restric
             acc = mfma32(a[tap].z, bw[tap].z, acc);
             acc = mfma32(a[tap].w, bw[tap].w, acc);
         }
-        if (gy < H) {
-            float *yrow = y + (((size_t)n * H + gy) * W) * 32 + li;
+        if (gy < H) {                                   // (wave-uniform)
+            float *ot = otile[wave];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int gx = tx0 + mfma_row(r, lane);
-                if (gx < W) {
-                    float v = acc[r] + bv;
-                    if (relu) v = fmaxf(v, 0.f);
-                    yrow[(size_t)gx * 32] = v;
+                const int px = mfma_row(r, lane);
+                float v = acc[r] + bv;
+                if (relu) v = fmaxf(v, 0.f);
+                ot[px * 36 + li] = v;
+                if (tx0 + px < W) {
                     ssum += v;
                     ssq += v * v;
                 }
+            }
+            // (the tile is private to the wave: its LDS writes are ordered before its reads by the wait the compiler inserts)
+            float *yrow = y + (((size_t)n * H + gy) * W + tx0) * 32;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int px = k * 8 + (lane >> 3), c4 = lane & 7;
+                const f32x4 v4 = *reinterpret_cast<const f32x4 *>(&ot[px * 36 + c4 * 4]);
+                if (tx0 + px < W) __builtin_nontemporal_store(v4, reinterpret_cast<f32x4 *>(yrow + (size_t)px * 32 + c4 * 4));
             }
         }
     }

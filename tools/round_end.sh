@@ -1,6 +1,6 @@
 # usage (GPU box): bash tools/round_end.sh <tag>   -> the GPU suite, the round's profiles and the full bench line under gpurun_out/
 R=$GRAFT_REPO_ROOT
-tag=${1:-r05}
+tag=${1:-r06}
 cd $R
 timeout 1500 python3 -m pytest tests -m gpu -x -q > gpurun_out/${tag}_pytest_gpu.log 2>&1
 tail -3 gpurun_out/${tag}_pytest_gpu.log
