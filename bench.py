@@ -25,6 +25,7 @@ two extra, separately instrumented steps AFTER the timed region, so their events
 (8 x 20 s clips, 3 warm-ups, median of 5 steps; N = 1, rank 0 only).
 """
 import argparse
+import ctypes
 import json
 import os
 import socket
@@ -97,22 +98,86 @@ def self_launch(n_gpus, argv):
 
 
 # ---------------------------------------------------------------------------------------------- HIP-event timers
-class KernelTimer:
-    """HIP-event timing of selected op families on the launch stream, only while `active`."""
+class TimingEvent:
+    """A HIP event made for TIMING: ``hipEventDisableSystemFence`` (the runtime accepts one of its three release flags per event).  ``torch.cuda.Event`` is a default
+    event: when it is recorded the runtime performs a system-scope release -- the L2 is written back and invalidated -- which costs
+    the command processor microseconds per record and leaves the next kernel a cold cache (hip_runtime_api.h: "On some AMD GPU
+    devices this can improve the accuracy of timing measurements by avoiding the cost of cache writeback and invalidation, and the
+    performance impact of those actions on the execution of following work").  Same API underneath (hipEventRecord on the stream
+    the kernels are launched on, hipEventElapsedTime), created through the HIP runtime PyTorch has already loaded."""
+    _hip = None
+    FLAGS = 0x20000000
+
+    @classmethod
+    def runtime(cls):
+        if cls._hip is None:
+            path = None
+            with open("/proc/self/maps") as f:                       # the ONE runtime of this process (PyTorch ships its own copy)
+                for ln in f:
+                    if "libamdhip64" in ln:
+                        path = ln.split()[-1]
+                        break
+            if path is None:
+                raise RuntimeError("no HIP runtime is mapped (import torch and touch the GPU first)")
+            hip = ctypes.CDLL(path)
+            hip.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+            hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+            hip.hipEventSynchronize.argtypes = [ctypes.c_void_p]
+            hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+            cls._hip = hip
+        return cls._hip
 
     def __init__(self, torch):
         self.torch = torch
+        self.h = ctypes.c_void_p()
+        rc = self.runtime().hipEventCreateWithFlags(ctypes.byref(self.h), self.FLAGS)
+        if rc != 0:
+            raise RuntimeError("hipEventCreateWithFlags failed (%d)" % rc)
+
+    def record(self):
+        rc = self._hip.hipEventRecord(self.h, ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise RuntimeError("hipEventRecord failed (%d)" % rc)
+
+    def elapsed_time(self, other):
+        self._hip.hipEventSynchronize(other.h)
+        ms = ctypes.c_float()
+        rc = self._hip.hipEventElapsedTime(ctypes.byref(ms), self.h, other.h)
+        if rc != 0:
+            raise RuntimeError("hipEventElapsedTime failed (%d)" % rc)
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self._hip.hipEventDestroy(self.h)
+        except Exception:                                               # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+def make_event(torch, kind="timing"):
+    """kind 'timing': TimingEvent (no system-scope fence); 'torch': torch.cuda.Event(enable_timing=True) -- the A/B switch
+    ``--event-kind`` of the bench"""
+    return TimingEvent(torch) if kind == "timing" else torch.cuda.Event(enable_timing=True)
+
+
+class KernelTimer:
+    """HIP-event timing of selected op families on the launch stream, only while `active`."""
+
+    def __init__(self, torch, kind="timing"):
+        self.torch = torch
+        self.kind = kind
         self.active = False
         self.records = {}          # family -> list of (start, end, work)
 
     def wrap(self, module, name, family, work_fn, gate=None):
         orig = getattr(module, name)
-        ev = self.torch.cuda.Event
 
         def timed(*a, **kw):
             if not (self.active if gate is None else gate()):
                 return orig(*a, **kw)
-            s, e = ev(enable_timing=True), ev(enable_timing=True)
+            s, e = make_event(self.torch, self.kind), make_event(self.torch, self.kind)
             s.record()
             out = orig(*a, **kw)
             e.record()
@@ -445,6 +510,9 @@ def main():
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
                     help="skip the host-fed variant of the step (int16 clips through AudioStager), reported as `pipeline`")
     ap.add_argument("--graph", action="store_true", help="replay the headline step from a hipGraph too (no per-kernel events)")
+    ap.add_argument("--event-kind", default="timing", choices=["timing", "torch"],
+                    help="timing: HIP events created with hipEventDisableSystemFence (no L2 write-back / invalidate "
+                         "per record); torch: torch.cuda.Event (default flags: a system-scope release per record)")
     ap.add_argument("--events", default="dominant", choices=["dominant", "all"],
                     help="HIP events inside the TIMED steps: around every 3x3 forward / data-gradient launch (the family of the dominant kernel: "
                          "`roofline`) or also around the weight gradients and K1 (`all`: +~100 launches x 2 events x ~6.5 us of GPU idle per step)")
@@ -524,7 +592,7 @@ def main():
         torch.cuda.empty_cache()
     trainer = TrainStep(model, criterion, fx, prm, graph=args.graph)
 
-    timer = KernelTimer(torch)
+    timer = KernelTimer(torch, args.event_kind)
     # work = (algorithmic FLOPs of the 3x3 convolution, matrix FLOPs actually issued: 16/36 of that in Winograd form)
 
     from adyolo_amd import _lib as _alib
@@ -556,7 +624,7 @@ def main():
     def timed_features(a, channels_last8=True):
         if not (timer.active if ev_all else stage["on"]):
             return feat_call(a, channels_last8)
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s, e = make_event(torch, args.event_kind), make_event(torch, args.event_kind)
         s.record()
         out = feat_call(a, channels_last8)
         e.record()
@@ -714,7 +782,7 @@ def main():
         fwd_ms = []
         for i in range(5):
             timer.active = i >= 2
-            s_e, e_e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_e, e_e = make_event(torch, args.event_kind), make_event(torch, args.event_kind)
             s_e.record()
             out = model(feat, channels_last8=True)
             e_e.record()
