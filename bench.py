@@ -156,10 +156,22 @@ class TimingEvent:
             pass
 
 
+EVENT_KIND_USED = {"kind": None, "fallback": None}
+
+
 def make_event(torch, kind="timing"):
     """kind 'timing': TimingEvent (no system-scope fence); 'torch': torch.cuda.Event(enable_timing=True) -- the A/B switch
-    ``--event-kind`` of the bench"""
-    return TimingEvent(torch) if kind == "timing" else torch.cuda.Event(enable_timing=True)
+    ``--event-kind`` of the bench.  Should the runtime refuse the flagged event (another ROCm release), every later call takes
+    torch.cuda.Event and the line says so (``event_kind``)."""
+    if kind == "timing" and EVENT_KIND_USED["fallback"] is None:
+        try:
+            ev = TimingEvent(torch)
+            EVENT_KIND_USED["kind"] = "hipEventDisableSystemFence"
+            return ev
+        except Exception as exc:                                        # noqa: BLE001
+            EVENT_KIND_USED["fallback"] = "%s: %s" % (type(exc).__name__, exc)
+    EVENT_KIND_USED["kind"] = "torch.cuda.Event"
+    return torch.cuda.Event(enable_timing=True)
 
 
 class KernelTimer:
@@ -914,6 +926,9 @@ def main():
             },
             "final_loss": round(loss_val, 6),
             "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
+            # how the per-launch durations of `roofline` / `stages` were taken (HIP events on the launch stream; --events / --event-kind)
+            "timing": {"events_in_timed_steps": args.events, "event_kind": EVENT_KIND_USED["kind"],
+                       "event_fallback": EVENT_KIND_USED["fallback"]},
         }
         line["stages"].update(stages)
         if encoder_fwd is not None:
