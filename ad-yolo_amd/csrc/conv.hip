@@ -432,7 +432,9 @@ __global__ __launch_bounds__(256, 4) void stem_fwd_kernel(const float *__restric
                 ot[px * 36 + li] = v;
                 if (tx0 + px < W) {
                     ssum += v;
-                    ssq += v * v;
+                    float sq = v * v;            // (a product and a sum, not an fma -- the empty asm keeps the compiler from contracting
+                    asm volatile("" : "+v"(sq));  //  them: the statistics of every round of this kernel agree bit for bit)
+                    ssq += sq;
                 }
             }
             // (the tile is private to the wave: its LDS writes are ordered before its reads by the wait the compiler inserts)
