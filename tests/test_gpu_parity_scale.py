@@ -545,6 +545,32 @@ def test_dispatch_table_at_the_bench_shape(ops):
     assert {epi for (name, _, _, epi), _ in log.items() if name == "wino4p_fwd_kernel"} == {1, 2, 9, 15, 27, 31}
 
 
+def test_bench_timing_events_measure_what_torch_events_measure(ops):
+    """``bench.TimingEvent`` (HIP events created with hipEventDisableSystemFence through the runtime PyTorch has loaded; round 6)
+    around the same launches as ``torch.cuda.Event``: the two clocks agree (a 3x3 convolution of ~1 ms: within 10 %), the events
+    are recorded on the current stream, and ``make_event`` reports which kind it handed out."""
+    import bench
+    x = torch.randn(16, 600, 16, 128, device="cuda:0")
+    wt = torch.randn(128, 128, 3, 3, device="cuda:0") * 0.05
+    wpk, _ = ops.pack_w3x3(wt, 128, want_dgrad=False)
+    for _ in range(3):
+        ops.conv3x3(x, wpk, 128)
+    torch.cuda.synchronize()
+    a0, a1 = bench.make_event(torch, "timing"), bench.make_event(torch, "timing")
+    assert bench.EVENT_KIND_USED["fallback"] is None and bench.EVENT_KIND_USED["kind"] == "hipEventDisableSystemFence"
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    a0.record()
+    for _ in range(8):
+        ops.conv3x3(x, wpk, 128)
+    a1.record()
+    t1.record()
+    torch.cuda.synchronize()
+    ms_a, ms_t = a0.elapsed_time(a1), t0.elapsed_time(t1)
+    assert ms_a > 0.2 and abs(ms_a - ms_t) <= 0.1 * ms_t, (ms_a, ms_t)
+    assert isinstance(bench.make_event(torch, "torch"), torch.cuda.Event)
+
+
 # ------------------------------------------------------------------------------ data-parallel path on one GPU (RCCL, 1 rank)
 _DP_CHILD = r"""
 import hashlib, json, os, sys
