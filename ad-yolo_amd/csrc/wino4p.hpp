@@ -549,15 +549,30 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- writer: raw accumulators (rows rh * 8 .. + 7 of the 32 x 32 tile) of the wave's nine positions, straight from
-            // the AccVGPRs; the registers are zeroed for the next patch while the stores drain
+            // the AccVGPRs; the registers are zeroed for the next patch while the stores drain.  Two registers per instruction
+            // (ds_write2st64_b32: words 64 apart -- the exchange rows -- with both data operands AccVGPRs): 3 source dwords = 6 cycles
+            // of the LDS store path for 512 bytes where a ds_write_b32 takes 4 for 256 -- 928 against 1 212 cycles per round in
+            // tools/micro/write2_acc.hip (profiles/r06_addtid_probe.txt).  hipcc merges such pairs for architectural registers but
+            // not for AccVGPRs, hence the assembly; the wait below is the one the compiler would have placed before the barrier.
+            // (The ninth tile of a 64-channel workgroup lives in architectural registers: mfma32x4_vgpr.)
             if (!(W4P_WHATIF & 2)) {
+                const unsigned xwb = (unsigned)(size_t)xwr;
 #pragma unroll
                 for (int s = 0; s < 9; ++s)
 #pragma unroll
-                    for (int rr = 0; rr < 8; ++rr) {
-                        xwr[(s * 8 + rr) * 64] = acc[s][nt][rh * 8 + rr];
+                    for (int rr = 0; rr < 8; rr += 2) {
+                        if (s < 8 || NB == 1)
+                            asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%c3 offset1:%c4"
+                                         :: "v"(xwb), "a"(acc[s][nt][rh * 8 + rr]), "a"(acc[s][nt][rh * 8 + rr + 1]), "i"(s * 8 + rr),
+                                            "i"(s * 8 + rr + 1) : "memory");
+                        else
+                            asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%c3 offset1:%c4"
+                                         :: "v"(xwb), "v"(acc[s][nt][rh * 8 + rr]), "v"(acc[s][nt][rh * 8 + rr + 1]), "i"(s * 8 + rr),
+                                            "i"(s * 8 + rr + 1) : "memory");
                         acc[s][nt][rh * 8 + rr] = 0.f;
+                        acc[s][nt][rh * 8 + rr + 1] = 0.f;
                     }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             tstamp(2 + rnd);
             __syncthreads();
