@@ -43,6 +43,11 @@
 #define W4P_STAGGER 0     // experiment (round 6): workgroups with an odd slot start this many cycles late, so that the epilogues of the
                           // CUs of an XCD (32 KB store bursts per round) do not coincide (profiles/r06_store_burst.txt)
 #endif
+#ifndef W4P_KILLDUP
+#define W4P_KILLDUP 1     // 1 (2: and its B fragments past the end -- measured no better, profiles/r06_w4p_killdup_ab.txt): the last pair's requests for pair 1 of the NEXT patch (issued for the schedule's sake, never used, issued again
+                          // from the epilogue) fetch nothing; 0: they are real loads (until round 6: "by then they are L2 hits" -- at stage 1
+                          // they were not: profiles/r06_w4p_fetch_excess.txt)
+#endif
 #ifndef W4P_WHATIF
 #define W4P_WHATIF 0      // timing-only builds (results invalid): bit 0 no reader half of the epilogue rounds, 1 no writer half, 2 no
                           // output stores, 3 no xi pass (LDS reads), 4 no MFMAs, 5 no nu pass, 6 no B refills in the pair loop, 7 no staging
@@ -201,9 +206,11 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
         for (int j = 0; j < 6; ++j)
             off[j] = (rowok && (unsigned)(gx0 + j) < (unsigned)Wv) ? base + j * pixb : (int)0x80000000;
     };
-    auto st_load = [&](f32x4 (&p)[6], int round, int pr, bool on) {
+    // (dead: a request whose data nobody will use -- see pair_body -- is made against an EMPTY buffer: every lane is out of range,
+    //  nothing is fetched, and the load stays in place for the compiler's vmcnt bookkeeping)
+    auto st_load = [&](f32x4 (&p)[6], int round, int pr, bool on, bool dead = false) {
         const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(round == 2 ? xbL : xbF), 0,
-                                                                              (int)nrec, 0x00020000);
+                                                                              (W4P_KILLDUP && dead) ? 0 : (int)nrec, 0x00020000);
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int vo = round == 0 ? offF[j] : round == 1 ? offF[j] + RS * rowb : (on ? offL[j] : (int)0x80000000);
@@ -243,14 +250,16 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
 
     const int nkg = Cin / 8, npairs = Cin / 16;           // (npairs is even: Cin % 32 == 0)
     const size_t ustride_pos = (size_t)(Cout / 32) * nkg * 256;
-    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(u), 0, (int)(36 * ustride_pos * 4), 0x00020000);
+    const int urec = (int)(36 * ustride_pos * 4);
     const int ulane = lane * 16;
     const int uwave = (int)((((size_t)(wave * 9) * (Cout / 32) + (size_t)cb * NB) * nkg * 256) * 4);
     // B fragment of use u of a pair (18 NB uses: u = (9 half + s) NB + nt) -- fragment (s, nt) of group 2 pr + half
-    auto bload = [&](int uu, int kg) {
+    // (dead: as in st_load -- the last pair's requests past the end of the patch are repeated by the epilogue)
+    auto bload = [&](int uu, int kg, bool dead = false) {
         const int s = uu / NB, nt = uu % NB;
         const int so = uwave + (int)((s * ustride_pos + ((size_t)nt * nkg + kg) * 256) * 4);
+        const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(u), 0,
+                                                                              (W4P_KILLDUP > 1 && dead) ? 0 : urec, 0x00020000);
         const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, ulane, so, 0));
         return make_float4(v[0], v[1], v[2], v[3]);
     };
@@ -333,8 +342,10 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
     // One pair of the pipeline (the 36 steps of wino4_fwd_kernel).  The same code runs for every pair of a patch, the last one
     // included: there the image being staged is pair 0 of the next patch, and the requests for ITS pair 1, the first A fragments
     // and the B fragments past the end are issued as always but never used -- the epilogue issues them again when their
-    // registers are free (by then they are L2 hits).  No run-time condition around a load or an LDS read (the compiler's
-    // vmcnt / lgkmcnt bookkeeping stays exact), and nothing of them is live across the epilogue.
+    // registers are free.  (Round 6: the unused pair-1 requests go to an empty buffer -- W4P_KILLDUP -- because the epilogue's
+    // repeat was NOT an L2 hit at stages 1 and 2, where an XCD's L2 holds only a few microseconds of the kernel's traffic.)
+    // No run-time condition around a load or an LDS read (the compiler's vmcnt / lgkmcnt bookkeeping stays exact), and nothing
+    // of them is live across the epilogue.
     auto pair_body = [&](int pr) {
         float *Cn = lds + ((pr + 1) & 1) * (2 * CBUF);
         const int prn = pr + 1 < npairs ? pr + 1 : 0;                          // pair being staged
@@ -397,7 +408,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                     if (live && !(W4P_WHATIF & 64)) {
                         const int v = use + BR;
                         const int kgv = 2 * pr + v / UH;
-                        bq[slot_] = bload(v % UH, kgv < nkg ? kgv : kgv - nkg);  // (wraps: the next patch uses the same U)
+                        bq[slot_] = bload(v % UH, kgv < nkg ? kgv : kgv - nkg, kgv >= nkg);  // (wraps: the next patch uses the same U)
                     }
                     if (step == 24) {
                         __syncthreads();                                       // the next pair's image is complete
@@ -408,8 +419,8 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                     if (step == 28) a_reads_full(0);                           // (bases: the next pair's already)
                     if (step == 32) a_reads_half(0);
                     if (!(W4P_WHATIF & 128)) {
-                        if (step == 25) st_load(pvA, 0, prn2, true);
-                        if (step == 16) st_load(pvB, 1, prn2, true);
+                        if (step == 25) st_load(pvA, 0, prn2, true, pr == npairs - 1);
+                        if (step == 16) st_load(pvB, 1, prn2, true, pr == npairs - 1);
                         if (step == 8) st_load(pvA, 2, prn, lwave);
                     }
                     __builtin_amdgcn_sched_barrier(0);
