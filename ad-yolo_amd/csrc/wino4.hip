@@ -145,15 +145,17 @@ __global__ __launch_bounds__(256, 1) void wino4_fwd_kernel(
             const int sq4 = (round == 2 ? lane : tid) & 3;
             const float4 isc = *reinterpret_cast<const float4 *>(&aff[pr * 16 + sq4 * 4]);
             const float4 ish = *reinterpret_cast<const float4 *>(&aff[WMAXC + pr * 16 + sq4 * 4]);
+            // (under an EXEC mask made by the range comparison instead of a compare and four selects per pixel: wino4_common.hpp)
+            int vo[6];
+            f32x4 q[6];
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                const int vo = round == 0 ? offF[j] : round == 1 ? offF[j] + RS * rowb : offL[j];
-                const bool ok = (unsigned)vo < nrec;
-                p[j].x = fmaf(p[j].x, isc.x, ok ? ish.x : 0.f);
-                p[j].y = fmaf(p[j].y, isc.y, ok ? ish.y : 0.f);
-                p[j].z = fmaf(p[j].z, isc.z, ok ? ish.z : 0.f);
-                p[j].w = fmaf(p[j].w, isc.w, ok ? ish.w : 0.f);
+                vo[j] = round == 0 ? offF[j] : round == 1 ? offF[j] + RS * rowb : offL[j];
+                q[j] = f32x4{p[j].x, p[j].y, p[j].z, p[j].w};
             }
+            aff6_inrange(q, f32x4{isc.x, isc.y, isc.z, isc.w}, f32x4{ish.x, ish.y, ish.z, ish.w}, vo, nrec);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) p[j] = make_float4(q[j][0], q[j][1], q[j][2], q[j][3]);
         }
         bt6(p, p);
     };

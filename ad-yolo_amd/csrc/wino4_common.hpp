@@ -68,6 +68,46 @@ __device__ __forceinline__ f32x4 pkfma4v(f32x4 a, f32x4 b, f32x4 c) {
     asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(a.hi), "v"(b.hi), "v"(c.hi));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
+// p[j] = p[j] * sc + sh on the lanes whose byte offset vo[j] lies inside the buffer (vo[j] < nrec, unsigned); the other lanes keep
+// p[j], which is the 0 an out-of-range buffer load returned.  The comparison writes EXEC (v_cmpx) and the two packed FMAs run under
+// it: one vector instruction per pixel on top of the FMAs instead of a compare and four selects of the shift (round 6).  Every
+// lane of the wave must be active at the call (the staging code is).
+__device__ __forceinline__ void aff6_inrange(f32x4 (&p)[6], f32x4 sc, f32x4 sh, const int (&vo)[6], unsigned nrec) {
+    f32x2 l0 = p[0].lo, h0 = p[0].hi, l1 = p[1].lo, h1 = p[1].hi, l2 = p[2].lo, h2 = p[2].hi;
+    f32x2 l3 = p[3].lo, h3 = p[3].hi, l4 = p[4].lo, h4 = p[4].hi, l5 = p[5].lo, h5 = p[5].hi;
+    unsigned long long sv;
+#define ADYOLO_AFF1(L, H, O)                                                                                                      \
+    "v_cmpx_gt_u32_e32 vcc, %[n], %[" O "]\n\tv_pk_fma_f32 %[" L "], %[" L "], %[scl], %[shl]\n\t"                                   \
+    "v_pk_fma_f32 %[" H "], %[" H "], %[sch], %[shh]\n\ts_mov_b64 exec, %[sv]\n\t"
+    asm volatile("s_mov_b64 %[sv], exec\n\t" ADYOLO_AFF1("l0", "h0", "o0") ADYOLO_AFF1("l1", "h1", "o1") ADYOLO_AFF1("l2", "h2", "o2")
+                     ADYOLO_AFF1("l3", "h3", "o3") ADYOLO_AFF1("l4", "h4", "o4") ADYOLO_AFF1("l5", "h5", "o5")
+                 : [l0] "+v"(l0), [h0] "+v"(h0), [l1] "+v"(l1), [h1] "+v"(h1), [l2] "+v"(l2), [h2] "+v"(h2), [l3] "+v"(l3),
+                   [h3] "+v"(h3), [l4] "+v"(l4), [h4] "+v"(h4), [l5] "+v"(l5), [h5] "+v"(h5), [sv] "=&s"(sv)
+                 : [scl] "v"(sc.lo), [sch] "v"(sc.hi), [shl] "v"(sh.lo), [shh] "v"(sh.hi), [n] "s"(nrec), [o0] "v"(vo[0]),
+                   [o1] "v"(vo[1]), [o2] "v"(vo[2]), [o3] "v"(vo[3]), [o4] "v"(vo[4]), [o5] "v"(vo[5])
+                 : "vcc");
+#undef ADYOLO_AFF1
+    p[0] = __builtin_shufflevector(l0, h0, 0, 1, 2, 3);
+    p[1] = __builtin_shufflevector(l1, h1, 0, 1, 2, 3);
+    p[2] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3);
+    p[3] = __builtin_shufflevector(l3, h3, 0, 1, 2, 3);
+    p[4] = __builtin_shufflevector(l4, h4, 0, 1, 2, 3);
+    p[5] = __builtin_shufflevector(l5, h5, 0, 1, 2, 3);
+}
+// sum += v, sq = v * w + sq on the lanes with off >= 0 (an output pixel inside the image; out-of-image pixels carry the sign bit in
+// their store offset), under an EXEC mask made by the comparison: no selects of v (round 6).  Every lane active at the call.
+__device__ __forceinline__ void stat_acc_inimage(f32x4 &sum, f32x4 &sq, f32x4 v, f32x4 w, int off) {
+    f32x2 sl = sum.lo, sh = sum.hi, ql = sq.lo, qh = sq.hi;
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\tv_cmpx_le_i32_e32 vcc, 0, %[o]\n\tv_pk_add_f32 %[sl], %[sl], %[vl]\n\t"
+                 "v_pk_add_f32 %[sh], %[sh], %[vh]\n\tv_pk_fma_f32 %[ql], %[vl], %[wl], %[ql]\n\t"
+                 "v_pk_fma_f32 %[qh], %[vh], %[wh], %[qh]\n\ts_mov_b64 exec, %[sv]"
+                 : [sl] "+v"(sl), [sh] "+v"(sh), [ql] "+v"(ql), [qh] "+v"(qh), [sv] "=&s"(sv)
+                 : [vl] "v"(v.lo), [vh] "v"(v.hi), [wl] "v"(w.lo), [wh] "v"(w.hi), [o] "v"(off)
+                 : "vcc");
+    sum = __builtin_shufflevector(sl, sh, 0, 1, 2, 3);
+    sq = __builtin_shufflevector(ql, qh, 0, 1, 2, 3);
+}
 // the same, in place, on ext-vector pixels (wino4p.hpp)
 __device__ __forceinline__ void bt6v(f32x4 (&c)[6]) {
     auto fm = [](float k, f32x4 a, f32x4 b) { return pkfma4(k, a, b); };

@@ -43,6 +43,15 @@
 #define W4P_STAGGER 0     // experiment (round 6): workgroups with an odd slot start this many cycles late, so that the epilogues of the
                           // CUs of an XCD (32 KB store bursts per round) do not coincide (profiles/r06_store_burst.txt)
 #endif
+#ifndef W4P_AFF_EXEC
+#define W4P_AFF_EXEC 1    // 1: the producer's BatchNorm affine is applied under an EXEC mask made by the range comparison (aff6_inrange),
+                          // 0: compare + four selects of the shift per pixel (until round 6)
+#endif
+#ifndef W4P_STAT_EXEC
+#define W4P_STAT_EXEC 1   // 1: the epilogue's BatchNorm-statistics sums skip out-of-image pixels through EXEC (stat_acc_inimage)
+                          // except with both kinds of mask bits (operand set 31: measured 0.3-1.3 % slower there, set 27 4-5 % faster,
+                          // the others 0-1.5 % faster: profiles/r06_w4p_exec_masks.txt), 0: four selects per pixel (until round 6)
+#endif
 #ifndef W4P_KILLDUP
 #define W4P_KILLDUP 1     // 1 (2: and its B fragments past the end -- measured no better, profiles/r06_w4p_killdup_ab.txt): the last pair's requests for pair 1 of the NEXT patch (issued for the schedule's sake, never used, issued again
                           // from the epilogue) fetch nothing; 0: they are real loads (until round 6: "by then they are L2 hits" -- at stage 1
@@ -225,12 +234,18 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
             const int sq4 = (round == 2 ? lane : tid) & 3;
             const f32x4 isc = *reinterpret_cast<const f32x4 *>(&aff[pr * 16 + sq4 * 4]);
             const f32x4 ish = *reinterpret_cast<const f32x4 *>(&aff[WMAXC + pr * 16 + sq4 * 4]);
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            int vo[6];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int vo = round == 0 ? offF[j] : round == 1 ? offF[j] + RS * rowb : offL[j];
-                const bool ok = (unsigned)vo < nrec;
-                p[j] = pkfma4v(p[j], isc, ok ? ish : zero);
+            for (int j = 0; j < 6; ++j) vo[j] = round == 0 ? offF[j] : round == 1 ? offF[j] + RS * rowb : offL[j];
+            if (W4P_AFF_EXEC) {
+                aff6_inrange(p, isc, ish, vo, nrec);
+            } else {
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const bool ok = (unsigned)vo[j] < nrec;
+                    p[j] = pkfma4v(p[j], isc, ok ? ish : zero);
+                }
             }
         }
         bt6v(p);
@@ -695,7 +710,16 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                         }
                         if (!(W4P_WHATIF & 4) || (e == 0 && b == 0))
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yrs, off[e][b], 0, W4P_ST_AUX);
-                        if (ST) {
+                        if (ST && W4P_STAT_EXEC && !(SMK && MK)) {
+                            // masked-out components count 0; so do out-of-image pixels: the sums are taken under an EXEC mask
+                            if (SMK) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) v[k] = andf(v[k], (unsigned)__builtin_amdgcn_sbfe((int)smk, bit0 + k, 1u));
+                            }
+                            f32x4 w_ = v;
+                            if (AUX) w_ = fm(-1.f, smean, ax[e][b]) * sinv;
+                            stat_acc_inimage(ssum[nt], ssq[nt], v, w_, off[e][b]);
+                        } else if (ST) {
                             // out-of-image pixels and masked-out components count 0
                             const unsigned kin = ~(unsigned)(off[e][b] >> 31);
 #pragma unroll
