@@ -47,6 +47,12 @@
 #define W4P_AFF_EXEC 1    // 1: the producer's BatchNorm affine is applied under an EXEC mask made by the range comparison (aff6_inrange),
                           // 0: compare + four selects of the shift per pixel (until round 6)
 #endif
+#ifndef W4P_BRES
+#define W4P_BRES 1        // 1: 32 -> 32 layers take the resident-U form of the kernel (BRES below), 0: the B ring as everywhere else
+#endif
+#ifndef W4P_BRES_ACC
+#define W4P_BRES_ACC 3    // channel groups (of the four) of the resident U kept in AccVGPRs
+#endif
 #ifndef W4P_STAT_EXEC
 #define W4P_STAT_EXEC 1   // 1: the epilogue's BatchNorm-statistics sums skip out-of-image pixels through EXEC (stat_acc_inimage)
                           // except with both kinds of mask bits (operand set 31: measured 0.3-1.3 % slower there, set 27 4-5 % faster,
@@ -100,7 +106,17 @@ struct KargLayout<void (*)(A...)> {
 
 // NB: 32-channel output blocks per workgroup -- 2 (Cout % 64 == 0) or 1 (32-channel layers: half the MFMAs per A fragment and per
 // staged pixel, two epilogue rounds; no one-patch counterpart)
-template <int TC, bool AFF, int EPI, int NB>
+// (the pair index as a compile-time value where the pair body is called with one: BRES)
+template <typename T>
+struct PairConst { static constexpr int value = 0; };
+template <int V>
+struct PairConst<std::integral_constant<int, V>> { static constexpr int value = V; };
+
+// BRES (32 -> 32 layers: NB = 1, Cin = 32, two pairs per patch): the wave's whole share of U -- 9 positions x 4 groups of 8 channels,
+// 144 registers, the half of the accumulator file an NB = 1 kernel leaves unused -- is loaded ONCE per workgroup and stays resident:
+// no B fragment loads in the pair loop (a buffer load costs the issuing wave ~19 cycles next to the fp32 MFMA, 72 of them per patch),
+// and the two pairs are two copies of the body (pair index, image-buffer parity and register indices are compile-time constants)
+template <int TC, bool AFF, int EPI, int NB, bool BRES = false>
 __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
     const float *__restrict__ x, const float *__restrict__ u, const float *__restrict__ bias,
     const float *__restrict__ addend, const float *__restrict__ addend_mask, const float *__restrict__ in_scale,
@@ -263,7 +279,8 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
         st_write(p, round, Cn);
     };
 
-    const int nkg = Cin / 8, npairs = Cin / 16;           // (npairs is even: Cin % 32 == 0)
+    static_assert(!BRES || NB == 1, "resident U: 32-channel output blocks only");
+    const int nkg = BRES ? 4 : Cin / 8, npairs = BRES ? 2 : Cin / 16;     // (npairs is even: Cin % 32 == 0)
     const size_t ustride_pos = (size_t)(Cout / 32) * nkg * 256;
     const int urec = (int)(36 * ustride_pos * 4);
     const int ulane = lane * 16;
@@ -281,8 +298,19 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
     constexpr int BR = W4_BRING;
     constexpr int UH = 9 * NB;                            // uses per 8-channel group
     float4 bq[BR];
+    f32x4 bres[BRES ? 9 : 1][4];                          // [position of the wave][group of 8 input channels]
+    if (BRES) {
 #pragma unroll
-    for (int uu = 0; uu < BR; ++uu) bq[uu] = bload(uu % UH, (uu / UH) % nkg);
+        for (int s = 0; s < 9; ++s)
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                const float4 t = bload(s, kg);
+                bres[s][kg] = f32x4{t.x, t.y, t.z, t.w};
+            }
+    } else {
+#pragma unroll
+        for (int uu = 0; uu < BR; ++uu) bq[uu] = bload(uu % UH, (uu / UH) % nkg);
+    }
 
     int n, ty0, tx0;
     decode(sp, n, ty0, tx0);
@@ -361,7 +389,8 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
     // repeat was NOT an L2 hit at stages 1 and 2, where an XCD's L2 holds only a few microseconds of the kernel's traffic.)
     // No run-time condition around a load or an LDS read (the compiler's vmcnt / lgkmcnt bookkeeping stays exact), and nothing
     // of them is live across the epilogue.
-    auto pair_body = [&](int pr) {
+    auto pair_body = [&](auto PR_) {
+        const int pr = PR_;                                                    // (BRES: an integral constant)
         float *Cn = lds + ((pr + 1) & 1) * (2 * CBUF);
         const int prn = pr + 1 < npairs ? pr + 1 : 0;                          // pair being staged
         const int prn2 = pr + 2 < npairs ? pr + 2 : pr + 2 - npairs;           // pair being requested
@@ -407,6 +436,18 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                     } else if (W4P_WHATIF & 16) {
                         asm volatile("" : "+v"(a[s]));
                         asm volatile("" : "+v"(bq[slot_].x), "+v"(bq[slot_].y), "+v"(bq[slot_].z), "+v"(bq[slot_].w));
+                    } else if (BRES) {
+                        // (three of the four channel groups live in AccVGPRs -- 144 accumulators + 108 = 252 of the 256 -- and are MFMA
+                        //  operands there; left to itself the allocator parks ~70 of them in AccVGPRs too, but copies each back)
+                        const int kg_ = (2 * PairConst<decltype(PR_)>::value + half) & 3;        // (a constant once the loops are unrolled)
+                        f32x4 &b_ = bres[s][kg_];
+                        if (kg_ < W4P_BRES_ACC) asm volatile("" : "+a"(b_)); else asm volatile("" : "+v"(b_));
+                        asm volatile("" : "+v"(a[s]));
+                        acc[s][0] = mfma32(a[s][0], b_[0], acc[s][0]);
+                        acc[s][0] = mfma32(a[s][1], b_[1], acc[s][0]);
+                        acc[s][0] = mfma32(a[s][2], b_[2], acc[s][0]);
+                        acc[s][0] = mfma32(a[s][3], b_[3], acc[s][0]);
+                        asm volatile("" : "+a"(acc[s][0]));
                     } else if (s < 8 || NB == 1) {
                         const int an = live ? nt : 0;
                         asm volatile("" : "+v"(a[s]));
@@ -420,7 +461,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     // ---- loads of the step
-                    if (live && !(W4P_WHATIF & 64)) {
+                    if (live && !BRES && !(W4P_WHATIF & 64)) {
                         const int v = use + BR;
                         const int kgv = 2 * pr + v / UH;
                         bq[slot_] = bload(v % UH, kgv < nkg ? kgv : kgv - nkg, kgv >= nkg);  // (wraps: the next patch uses the same U)
@@ -470,7 +511,12 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
             Wn = W;
         }
         tstamp(0);
-        for (int pr = 0; pr < npairs; ++pr) pair_body(pr);
+        if constexpr (BRES) {
+            pair_body(std::integral_constant<int, 0>{});
+            pair_body(std::integral_constant<int, 1>{});
+        } else {
+            for (int pr = 0; pr < npairs; ++pr) pair_body(pr);
+        }
         tstamp(1);
         __syncthreads();                                  // every wave is done with image buffers 2, 3
 
@@ -739,8 +785,10 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
             if (W4P_TIMING && rnd == 2 * NB - 1) tstamp(14);
             if (rnd == 2 * NB - 1) {
                 // ... and its first B fragments (L2 hits: the last pair requested them once already)
+                if (!BRES) {
 #pragma unroll
-                for (int uu = 0; uu < BR; ++uu) bq[uu] = bload(uu % UH, (uu / UH) % nkg);
+                    for (int uu = 0; uu < BR; ++uu) bq[uu] = bload(uu % UH, (uu / UH) % nkg);
+                }
             }
             tstamp(6 + rnd);
             __syncthreads();                              // the exchange region is free again
@@ -805,8 +853,8 @@ static_assert(KL::offset(9) == KA_STAT_AUX && KL::offset(10) == KA_STAT_MEAN && 
 
 template <int EPI>
 void launch_wino4p(const W4Launch &a) {
-#define ADYOLO_WINO4P_FWD(TC_, AFF_, NB_)                                                                                  \
-    hipLaunchKernelGGL((wino4p_fwd_kernel<TC_, AFF_, EPI, NB_>), dim3((unsigned)a.grid), dim3(256), 0, a.st, a.x, a.u, a.bias, \
+#define ADYOLO_WINO4P_FWD(TC_, AFF_, NB_, ...)                                                                             \
+    hipLaunchKernelGGL((wino4p_fwd_kernel<TC_, AFF_, EPI, NB_, ##__VA_ARGS__>), dim3((unsigned)a.grid), dim3(256), 0, a.st, a.x, a.u, a.bias, \
                        a.addend, a.addend_mask, a.in_scale, a.in_shift, a.y, a.stats, a.stat_aux, a.stat_mean,             \
                        a.stat_invstd, a.stat_mask, a.H, a.W, a.Cin, a.Cout, a.patchesW, a.patchesH, a.nsp, a.ncb,          \
                        a.xcd_div, a.relu, a.mask_bits)
@@ -826,6 +874,18 @@ void launch_wino4p(const W4Launch &a) {
     if (a.nb == 2) {
         ADYOLO_WINO4P_NB(2)
     } else {
+        // 32 -> 32 layers: the resident-U form where the epilogue leaves it the registers (operand sets 15 / 27 / 31 do not: 20-46
+        // spilled registers and 6-14 % slower, profiles/r06_w4p_bres_ab.txt)
+        if constexpr (W4P_BRES && (EPI == 0 || EPI == 1 || EPI == 2 || EPI == 9)) {
+            if (a.Cin == 32) {
+                if (a.tc == 8) {
+                    if (a.in_scale) ADYOLO_WINO4P_FWD(8, true, 1, true); else ADYOLO_WINO4P_FWD(8, false, 1, true);
+                } else {
+                    if (a.in_scale) ADYOLO_WINO4P_FWD(4, true, 1, true); else ADYOLO_WINO4P_FWD(4, false, 1, true);
+                }
+                return;
+            }
+        }
         ADYOLO_WINO4P_NB(1)
     }
 #undef ADYOLO_WINO4P_NB
