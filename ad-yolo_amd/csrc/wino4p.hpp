@@ -289,9 +289,10 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
     // (dead: as in st_load -- the last pair's requests past the end of the patch are repeated by the epilogue)
     auto bload = [&](int uu, int kg, bool dead = false) {
         const int s = uu / NB, nt = uu % NB;
-        const int so = uwave + (int)((s * ustride_pos + ((size_t)nt * nkg + kg) * 256) * 4);
-        const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(u), 0,
-                                                                              (W4P_KILLDUP > 1 && dead) ? 0 : urec, 0x00020000);
+        // (the wave's base is part of the resource's address, not of every load's scalar offset: one s_add per load fewer)
+        const int so = (int)((s * ustride_pos + ((size_t)nt * nkg + kg) * 256) * 4);
+        const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(reinterpret_cast<const char *>(u) + uwave), 0, (W4P_KILLDUP > 1 && dead) ? 0 : urec - uwave, 0x00020000);
         const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, ulane, so, 0));
         return make_float4(v[0], v[1], v[2], v[3]);
     };
