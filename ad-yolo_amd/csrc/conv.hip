@@ -466,67 +466,124 @@ __global__ __launch_bounds__(256, 4) void stem_fwd_kernel(const float *__restric
 // Weight gradient of the 8-channel stem convolution (Cin = 8 padded from 7, Cout = 32; reference resnet.py:142).  As a GEMM
 // it is D[co][n = tap*8 + ci] = sum over pixels dy[pix][co] * x[pix + tap][ci]: M = 32 output channels is exactly one MFMA
 // tile, N = 72 is three (the last a quarter full) and the contraction runs over pixels, so both operands ARE in MFMA layout
-// in memory: lane (co, pixel parity) reads dy[pixel][co] (128 contiguous bytes per pixel across the 32 lanes) and lane
-// (n, pixel parity) reads x[pixel + tap][ci] (32 contiguous bytes per tap) straight from global memory -- no LDS staging,
-// no transposition.  A wave walks image rows, SW_U pixel pairs (4 x SW_U dword loads) in flight ahead of 3 x SW_U MFMAs; the
-// generic kernel above pads Cin to 32 (4x the matrix work) and took 1.69 ms at B = 64 x 60 s for a 1.57 GB read.
-constexpr int SW_U = 8;
+// in memory: lane (co, pixel parity) needs dy[pixel][co] and lane (n, pixel parity) needs x[pixel + tap][ci] -- no
+// transposition.  Until round 6 the lanes read exactly that from global memory, four dword loads per three MFMAs, and the
+// kernel was bound by the address path of those gathers (0.91 ms at B = 64 x 60 s for a 1.57 GB read; 0.38 ms of MFMAs).  Now a
+// workgroup stages four image rows x 64 pixels of dy and the six x rows around them (one halo column each side, out-of-image
+// pixels as zeros) in LDS with 16-byte loads -- ~12 per thread and chunk, requested one chunk ahead -- and the lanes take their
+// operands from there with ds_read_b32 at immediate offsets: no predicate and no address arithmetic in the loop.  Rows, pixel
+// pairs and accumulation order are the old kernel's: the result is bit-identical.
+constexpr int SW_U = 8;                                   // pixel pairs read ahead of their MFMAs
+constexpr int SW_T = 64;                                  // pixel columns per chunk
+constexpr int SW_XS = (SW_T + 4) * 8;                     // floats per staged x row: 66 pixels (a halo column each side) + 2 of padding --
+                                                          // 544 = 32 mod 64, which keeps the three tap rows of a B read in different banks
 __global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                                                             float *__restrict__ slabs, int H, int W, int rows_total) {
-    __shared__ float red[4 * 32 * 72];
+    // dy [4 rows][64 pixels][32] | x [6 rows + a row of zeros][68 pixels][8]; the final reduction reuses the space
+    __shared__ __attribute__((aligned(16))) float lds[4 * SW_T * 32 + 7 * SW_XS];
+    static_assert(4 * SW_T * 32 + 7 * SW_XS >= 4 * 32 * 72, "the reduction buffer must fit");
+    float *dyL = lds, *xL = lds + 4 * SW_T * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    int ky[3], kx[3], ci[3];
-    bool tv[3];
+    int ky[3], boff[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-        const int n = t * 32 + li, tap = n >> 3;
-        tv[t] = tap < 9;
+        const int n = t * 32 + li, tap = n < 72 ? n >> 3 : 8;        // (columns 72 .. 95 are never stored: any address will do)
         ky[t] = tap / 3 - 1;
-        kx[t] = tap % 3 - 1;
-        ci[t] = n & 7;
+        boff[t] = (lh + 1 + (tap % 3 - 1)) * 8 + (n & 7);            // floats inside a staged x row, pixel pair 0
     }
     f32x16 acc[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int i = tid; i < SW_XS; i += 256) xL[6 * SW_XS + i] = 0.f;
 
-    // rows are dealt to the workgroups in contiguous runs (neighbouring rows share their x taps in L2), one row per wave
+    // rows are dealt to the workgroups in contiguous runs, one row of a four-row chunk per wave
     const int per = (rows_total + gridDim.x - 1) / gridDim.x;
     const int r0 = blockIdx.x * per, r1 = min(rows_total, r0 + per);
-    for (int row = r0 + wave; row < r1; row += 4) {
-        const int y = row % H;
-        const float *dyrow = dy + (size_t)row * W * 32 + li;
-        const float *xrow[3];
-        bool rowok[3];
+    const int ncol = (W + SW_T - 1) / SW_T;
+    const int nchunk = r0 < r1 ? ((r1 - r0 + 3) / 4) * ncol : 0;
+    f32x4 pd[8], px_[4];
+    // chunk -> registers: 16-byte buffer loads against per-chunk resources (offsets stay small whatever the tensor's size);
+    // a pixel outside the image, the workgroup's rows or the tensor gets the out-of-range offset and reads as zeros
+    auto request = [&](int chunk) {
+        const int cr = r0 + (chunk / ncol) * 4, c0 = (chunk % ncol) * SW_T;
+        const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dy) + (size_t)cr * W * 32, 0,
+                                                                              0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x) + ((ptrdiff_t)cr - 1) * W * 8, 0,
+                                                                              0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int yy = y + ky[t];
-            rowok[t] = tv[t] && yy >= 0 && yy < H;
-            xrow[t] = x + ((size_t)(row + (rowok[t] ? ky[t] : 0)) * W) * 8 + ci[t];
+        for (int i = 0; i < 8; ++i) {
+            const int f = tid + 256 * i;
+            const int j = f >> 9, col = c0 + ((f & 511) >> 3);
+            const bool ok = cr + j < r1 && col < W;
+            pd[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  drs, ok ? ((j * W + col) * 32 + (f & 7) * 4) * 4 : (int)0x80000000, 0, 0));
         }
-        for (int xp = 0; xp < W; xp += 2 * SW_U) {
-            float a[SW_U], b[3][SW_U];
 #pragma unroll
-            for (int u = 0; u < SW_U; ++u) {
-                const int px = xp + 2 * u + lh;
-                const bool pok = px < W;
-                a[u] = pok ? dyrow[(size_t)px * 32] : 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i;
+            const int j = f / 132, rem = f - j * 132;
+            const int row = cr - 1 + j, col = c0 - 1 + (rem >> 1);
+            const bool ok = f < 6 * 132 && row >= 0 && row < rows_total && col >= 0 && col < W;
+            px_[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   xrs, ok ? ((j * W + col) * 8 + (rem & 1) * 4) * 4 : (int)0x80000000, 0, 0));
+        }
+    };
+    auto deposit = [&]() {                                // registers -> LDS
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const int xx = px + kx[t];
-                    const bool ok = pok && rowok[t] && xx >= 0 && xx < W;
-                    b[t][u] = ok ? xrow[t][(size_t)xx * 8] : 0.f;
-                }
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4 *>(&dyL[(tid + 256 * i) * 4]) = pd[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i;
+            const int j = f / 132;
+            if (f < 6 * 132) *reinterpret_cast<f32x4 *>(&xL[j * SW_XS + (f - j * 132) * 4]) = px_[i];
+        }
+    };
+    if (nchunk > 0) request(0);
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        deposit();
+        __syncthreads();
+        if (chunk + 1 < nchunk) request(chunk + 1);
+        const int row = r0 + (chunk / ncol) * 4 + wave;
+        if (row < r1) {
+            const int y = row % H;
+            const float *ap = dyL + (wave * SW_T + lh) * 32 + li;
+            const float *bp[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int yy = y + ky[t];
+                bp[t] = xL + ((yy >= 0 && yy < H) ? wave + 1 + ky[t] : 6) * SW_XS + boff[t];
             }
+            // the reads of group g + 1 are issued in front of the MFMAs of group g (two register sets; pinned, or the scheduler
+            // sinks every read to just above its use and exposes the LDS latency 32 times per chunk)
+            constexpr int NG = SW_T / (2 * SW_U);
+            float a[2][SW_U], b[2][3][SW_U];
+            auto reads = [&](int g) {
 #pragma unroll
-            for (int u = 0; u < SW_U; ++u)
+                for (int u = 0; u < SW_U; ++u) {
+                    a[g & 1][u] = ap[(g * SW_U + u) * 64];
 #pragma unroll
-                for (int t = 0; t < 3; ++t) acc[t] = mfma32(a[u], b[t][u], acc[t]);
+                    for (int t = 0; t < 3; ++t) b[g & 1][t][u] = bp[t][(g * SW_U + u) * 16];
+                }
+            };
+            reads(0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 1 < NG) reads(g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < SW_U; ++u)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) acc[t] = mfma32(a[g & 1][u], b[g & 1][t][u], acc[t]);
+            }
         }
+        __syncthreads();
     }
     // the four waves' partial sums are added in wave order; one slab [32][9][8] per workgroup
+    float *red = lds;
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
