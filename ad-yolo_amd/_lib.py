@@ -58,6 +58,8 @@ SIGNATURES = {
     "adyolo_se_fc_fwd": (I, [P] * 10 + [I, I, I, I, P]),
     "adyolo_relu_mask_words": (L, [I, I, I]),
     "adyolo_se_tail_fwd": (I, [P] * 9 + [I, I, I, P]),
+    "adyolo_se_tail_fwd_pool_ok": (I, [I, I, I]),
+    "adyolo_se_tail_fwd_pool": (I, [P] * 9 + [I, I, I, I, P]),
     "adyolo_se_tail_bwd_reduce": (I, [P] * 9 + [I, I, I, P]),
     "adyolo_se_tail_bwd_tiles": (I, [P, P, P, I, I, I, P]),
     "adyolo_se_fc_bwd_words": (L, [I, I]),

@@ -411,6 +411,86 @@ __global__ __launch_bounds__(256) void se_tail_fwd_kernel(
     }
 }
 
+// The same tail at a POOLED stage boundary (the next block starts with AvgPool2d(2, 2), reference resnet.py:147-150 /
+// SEBasicBlock's `pool`): e itself is only ever read by that pooling (the backward passes read its ReLU-mask bits), so this
+// form writes avgpool2(e) [N][H/2][W/2][C] and the bits of e, and e never goes to HBM -- one tensor write and one tensor read
+// fewer per boundary.  A thread owns one float4 of an even image row AND the one below it; its horizontal neighbour is c4n lanes
+// away (__shfl_xor; 2 c4n divides 64 and a row has a multiple of 64 float4s, so a wave covers whole pixel pairs of one row
+// and 64-aligned mask words of both rows); the even-pixel lanes store 0.25 * (((a + b) + c) + d), avgpool2_fwd_kernel's order.
+__global__ __launch_bounds__(256) void se_tail_fwd_pool_kernel(
+    const float *__restrict__ c, const float *__restrict__ r, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ s, const float *__restrict__ r_scale,
+    const float *__restrict__ r_shift, float *__restrict__ pooled, unsigned long long *__restrict__ mask, int H, int W,
+    int c4n, int c4shift) {
+    const int n = blockIdx.y;
+    const int W4 = W * c4n, items = (H >> 1) * W4;
+    const size_t base = (size_t)n * H * W4;
+    const float4 *c4 = reinterpret_cast<const float4 *>(c) + base, *r4 = reinterpret_cast<const float4 *>(r) + base;
+    float4 *o4 = reinterpret_cast<float4 *>(pooled) + (base >> 2);
+    const int cx = (int)threadIdx.x & (c4n - 1);
+    const float4 sc = reinterpret_cast<const float4 *>(scale)[cx], sh = reinterpret_cast<const float4 *>(shift)[cx];
+    const float4 sv = reinterpret_cast<const float4 *>(s)[(size_t)n * c4n + cx];
+    float4 rs = make_float4(1.f, 1.f, 1.f, 1.f), rt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r_scale) {
+        rs = reinterpret_cast<const float4 *>(r_scale)[cx];
+        rt = reinterpret_cast<const float4 *>(r_shift)[cx];
+    }
+    auto tail = [&](float4 cv, float4 rv) {
+        if (r_scale) rv = make_float4(fmaf(rv.x, rs.x, rt.x), fmaf(rv.y, rs.y, rt.y), fmaf(rv.z, rs.z, rt.z), fmaf(rv.w, rs.w, rt.w));
+        float4 o;
+        o.x = fmaxf((cv.x * sc.x + sh.x) * sv.x + rv.x, 0.f);
+        o.y = fmaxf((cv.y * sc.y + sh.y) * sv.y + rv.y, 0.f);
+        o.z = fmaxf((cv.z * sc.z + sh.z) * sv.z + rv.z, 0.f);
+        o.w = fmaxf((cv.w * sc.w + sh.w) * sv.w + rv.w, 0.f);
+        return o;
+    };
+    auto bits = [&](const float4 &o, size_t i) {          // (the whole wave is here: items and every row are multiples of 64)
+        const unsigned long long bx = __ballot(o.x > 0.f), by = __ballot(o.y > 0.f);
+        const unsigned long long bz = __ballot(o.z > 0.f), bw = __ballot(o.w > 0.f);
+        const int lane = threadIdx.x & 63;
+        if (lane < 4) mask[((base + i) >> 6) * 4 + lane] = lane == 0 ? bx : (lane == 1 ? by : (lane == 2 ? bz : bw));
+    };
+    auto across = [&](const float4 &v) {
+        return make_float4(__shfl_xor(v.x, c4n, 64), __shfl_xor(v.y, c4n, 64), __shfl_xor(v.z, c4n, 64), __shfl_xor(v.w, c4n, 64));
+    };
+    constexpr int U = 2;
+    const int step = (int)gridDim.x * 256 * U;
+    for (int j0 = (int)blockIdx.x * 256 * U + (int)threadIdx.x; j0 < items; j0 += step) {
+        float4 cv[U][2], rv[U][2];
+        int src[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * 256;
+            if (j < items) {
+                const int yp = j / W4;
+                src[u] = j + yp * W4;                     // = (2 yp) W4 + (j - yp W4)
+                cv[u][0] = ew_ld(&c4[src[u]]);
+                rv[u][0] = ew_ld(&r4[src[u]]);
+                cv[u][1] = ew_ld(&c4[src[u] + W4]);
+                rv[u][1] = ew_ld(&r4[src[u] + W4]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * 256;
+            if (j < items) {
+                const float4 a = tail(cv[u][0], rv[u][0]), cc = tail(cv[u][1], rv[u][1]);
+                if (mask) {
+                    bits(a, (size_t)src[u]);
+                    bits(cc, (size_t)src[u] + W4);
+                }
+                const float4 b = across(a), d = across(cc);
+                const int yp = j / W4, ce = j - yp * W4, px = ce >> c4shift;
+                if (!(px & 1)) {
+                    const float4 o = make_float4(0.25f * (a.x + b.x + cc.x + d.x), 0.25f * (a.y + b.y + cc.y + d.y),
+                                                 0.25f * (a.z + b.z + cc.z + d.z), 0.25f * (a.w + b.w + cc.w + d.w));
+                    o4[((size_t)yp * (W >> 1) + (px >> 1)) * c4n + cx] = o;
+                }
+            }
+        }
+    }
+}
+
 // One workgroup per sample: dpool[n][:] and this sample's contribution to every parameter gradient / batch sum,
 // written to part[n][P] with P = 2*C*Cr + Cr + 3*C laid out [db2 C | dw2 C*Cr | db1 Cr | dw1 Cr*C | sdd C | sddx C] -- the
 // order in which these six gradients (se.fc.2.bias, se.fc.2.weight, se.fc.0.bias, se.fc.0.weight, bn2.bias, bn2.weight) lie in
@@ -789,6 +869,31 @@ extern "C" int adyolo_se_tail_fwd(const float *c, const float *r, const float *s
         hipLaunchKernelGGL(se_tail_fwd_kernel<false>, dim3(gx, N), dim3(256), 0, as_stream(stream), c, r, scale, shift, s,
                            r_scale, r_shift, e, reinterpret_cast<unsigned long long *>(mask), hw4, C / 4);
     return check_launch("se_tail_fwd");
+}
+
+// 1 when adyolo_se_tail_fwd_pool takes the shape (C/4 a power of two <= 32, even H and W, a row of W*C/4 float4 a multiple of 64)
+extern "C" int adyolo_se_tail_fwd_pool_ok(int H, int W, int C) {
+    if (C % 4 || H <= 0 || W <= 0) return 0;
+    const int c4n = C / 4;
+    return chan_ok(C) && (c4n & (c4n - 1)) == 0 && c4n <= 32 && H % 2 == 0 && W % 2 == 0 && ((long)W * c4n) % 64 == 0 &&
+           (long)H * W * c4n < (1L << 30);
+}
+
+extern "C" int adyolo_se_tail_fwd_pool(const float *c, const float *r, const float *scale, const float *shift, const float *s,
+                                       const float *r_scale, const float *r_shift, float *pooled, uint64_t *mask, int N, int H,
+                                       int W, int C, void *stream) {
+    ADYOLO_REQUIRE(c && r && scale && shift && s && pooled && N > 0 && (!r_scale) == (!r_shift), ADYOLO_EINVAL,
+                   "se_tail_fwd_pool: bad arguments");
+    ADYOLO_REQUIRE(adyolo_se_tail_fwd_pool_ok(H, W, C), ADYOLO_ENOSUP, "se_tail_fwd_pool: unsupported shape H=%d W=%d C=%d", H, W, C);
+    const int c4n = C / 4;
+    int c4shift = 0;
+    while ((1 << c4shift) < c4n) ++c4shift;
+    const long items = (long)(H / 2) * W * c4n;
+    int gx = ew_grid(cdiv(items, 2L));
+    if ((long)gx * N > 16384) gx = (int)(16384 / N > 0 ? 16384 / N : 1);
+    hipLaunchKernelGGL(se_tail_fwd_pool_kernel, dim3(gx, N), dim3(256), 0, as_stream(stream), c, r, scale, shift, s, r_scale,
+                       r_shift, pooled, reinterpret_cast<unsigned long long *>(mask), H, W, c4n, c4shift);
+    return check_launch("se_tail_fwd_pool");
 }
 
 extern "C" int adyolo_se_tail_bwd_reduce(const float *de, const float *e, const uint64_t *mask, const float *c,

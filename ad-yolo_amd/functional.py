@@ -33,6 +33,8 @@ FUSE_MASKBITS = os.environ.get("ADYOLO_FUSE_MASKBITS", "1") != "0"
 # The stem's BatchNorm output is never written: the stem hands relu(conv(x)) and (scale, shift) to the first block, which
 # applies the affine while conv1 / its weight-gradient stage the tensor and while the SE tail reads the identity shortcut.
 FUSE_STEM_AFFINE = os.environ.get("ADYOLO_FUSE_STEM_AFFINE", "1") != "0"
+# the tail of the last block in front of a pooled stage boundary writes avgpool2(e) + the mask bits of e, never e (round 6)
+FUSE_POOL = os.environ.get("ADYOLO_FUSE_POOL", "1") != "0"
 
 
 class BlockLink:
@@ -42,6 +44,7 @@ class BlockLink:
     def __init__(self):
         self.cc = self.mean2 = self.invstd2 = self.tiles = self.ebits = None
         self.affine = self.stem_bn = None        # (stem hand-over: see StemFn / FUSE_STEM_AFFINE)
+        self.prepooled = False                   # A wrote avgpool2(e) instead of e (FUSE_POOL): B must not pool again
 
 
 def _c(t):
@@ -289,9 +292,11 @@ class SEBlockFn(torch.autograd.Function):
         p_aff = bns[5] if len(bns) > 5 else None      # (scale, shift): the input is seen through this per-channel affine
         ctx.stem_holder = bns[6] if len(bns) > 6 else None    # BlockLink of the stem: its BatchNorm backward sums come from our dgrad
         packs = bns[7] if len(bns) > 7 else None              # (u_fwd1, u_dgrad1, u_fwd2, u_dgrad2) from ops.WinoPackSet, or None
+        pool_next = bool(bns[8]) if len(bns) > 8 else False   # the NEXT block starts with AvgPool2d(2, 2): see FUSE_POOL below
+        prepooled = pool and link_in is not None and link_in.prepooled   # ... and the block BELOW handed us avgpool2(its output)
         if p_aff is not None and (pool or wd is not None):
             raise NotImplementedError("p_affine is only supported for identity-shortcut blocks without pooling")
-        p = ops.avgpool2(x) if pool else x
+        p = ops.avgpool2(x) if (pool and not prepooled) else x
         n, h, w_, cin = p.shape
         c = w1.shape[0]
         if packs is not None:
@@ -350,7 +355,14 @@ class SEBlockFn(torch.autograd.Function):
             r, raff = q, (scaled, shiftd)            # the downsample BatchNorm is applied while the tail reads q
         else:
             r, raff = p, p_aff
-        if training and FUSE_MASKBITS:
+        # FUSE_POOL: in front of a pooled stage boundary the tail writes avgpool2(e) and the ReLU-mask bits of e; e itself -- read
+        # only by that pooling in the forward pass, through its bits in the backward pass -- never goes to HBM (round 6)
+        pool_out = FUSE_POOL and pool_next and link_out is not None and ops.se_tail_pool_ok(h, w_, c) and \
+            (FUSE_MASKBITS or not training)
+        if pool_out:
+            e, ebits = ops.se_tail_fwd(cc, r, scale2, shift2, s, want_mask=training, r_affine=raff, pool_hw=(h, w_))
+            link_out.prepooled = True
+        elif training and FUSE_MASKBITS:
             e, ebits = ops.se_tail_fwd(cc, r, scale2, shift2, s, want_mask=True, r_affine=raff)
         else:
             e, ebits = ops.se_tail_fwd(cc, r, scale2, shift2, s, r_affine=raff), None
@@ -360,7 +372,8 @@ class SEBlockFn(torch.autograd.Function):
         if ctx.link_out is not None:
             link_out.cc, link_out.mean2, link_out.invstd2, link_out.tiles = cc, mean2, invstd2, None
             link_out.ebits = ebits
-        ctx.training, ctx.pool, ctx.has_down = training, pool, wd is not None
+        ctx.training, ctx.pool, ctx.has_down = training, pool and not prepooled, wd is not None
+        ctx.pool_out = (h, w_) if pool_out else None
         ctx.in_hw = (x.shape[1], x.shape[2])
         ctx.fused_affine = aff is not None
         ctx.a_unfused = None if aff is not None else a      # (A/B switch only; keeps `a` alive for BN1's backward)
@@ -388,7 +401,7 @@ class SEBlockFn(torch.autograd.Function):
                     getattr(ctx.stem_holder, "stem_bn", None) is not None
                 p_ok = (not FUSE_DR) or stem15
             wpk1d = wpk1d.pick(n, h, w_, cin, True, p_ok)
-        tensors = [p, src, scale1, cc, e, g1, mean1, invstd1, g2, b2, mean2, invstd2, ssum2, pooled, hid, s, fw1, fw2,
+        tensors = [p, src, scale1, cc, None if pool_out else e, g1, mean1, invstd1, g2, b2, mean2, invstd2, ssum2, pooled, hid, s, fw1, fw2,
                    wpk1d, wpk2d, shift1]
         names = ["p", "a", "scale1", "cc", "e", "g1", "mean1", "invstd1", "g2", "b2", "mean2", "invstd2", "ssum2", "pooled",
                  "hid", "s", "fw1", "fw2", "wpk1d", "wpk2d", "shift1"]
@@ -412,6 +425,8 @@ class SEBlockFn(torch.autograd.Function):
         n, h, w_, cin = p.shape
         c = cc.shape[-1]
         de = _c(de)
+        if ctx.pool_out is not None:              # our output was avgpool2(e): the gradient of e itself
+            de = ops.avgpool2_bwd(de, ctx.pool_out[0], ctx.pool_out[1])
         tiles = None
         if ctx.link_out is not None and ctx.link_out.tiles is not None:
             tiles, ctx.link_out.tiles = ctx.link_out.tiles, None      # left by the block above (its dgrad produced `de`)

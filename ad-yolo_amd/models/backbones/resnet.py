@@ -82,14 +82,16 @@ class SEBasicBlock(nn.Module):
         else:
             self.downsample = None
 
-    def forward(self, x, link_in=None, link_out=None, in_affine=None, stem_holder=None, packs=None):
+    def forward(self, x, link_in=None, link_out=None, in_affine=None, stem_holder=None, packs=None, pool_next=False):
         """link_in / link_out: ``functional.BlockLink`` shared with the block below / above (see FUSE_SEBWD);
         in_affine = (scale, shift): x is seen through this per-channel affine (the stem's un-materialised BatchNorm);
-        packs = the Winograd-packed filters of conv1 / conv2 from the encoder's ``ops.WinoPackSet`` (one launch for all)."""
+        packs = the Winograd-packed filters of conv1 / conv2 from the encoder's ``ops.WinoPackSet`` (one launch for all);
+        pool_next: the block that consumes our output starts with AvgPool2d(2, 2) -- we may hand it the pooled tensor
+        (``functional.FUSE_POOL``; ``link_out.prepooled`` tells it)."""
         fc0, fc2 = self.se.fc["0"], self.se.fc["2"]
         args = [x, self.training, self.pool,
                 (self.bn1, self.bn2, self.downsample["1"] if self.downsample is not None else None, link_in, link_out,
-                 in_affine, stem_holder, packs),
+                 in_affine, stem_holder, packs, pool_next),
                 self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight, self.bn2.weight, self.bn2.bias,
                 fc0.weight, fc0.bias, fc2.weight, fc2.bias]
         if self.downsample is not None:
@@ -205,7 +207,8 @@ class SEResnet34(nn.Module):
             nxt = Fn.BlockLink()
             pk = (packs.get(2 * bi) + packs.get(2 * bi + 1)) if packs is not None else None
             y = blk(y, link_in=link, link_out=nxt, in_affine=stem_affine,
-                    stem_holder=holder if stem_affine is not None else None, packs=pk)
+                    stem_holder=holder if stem_affine is not None else None, packs=pk,
+                    pool_next=bi + 1 < len(blocks) and bool(blocks[bi + 1].pool))
             stem_affine = None
             link = nxt
         y = Fn.SAPFn.apply(y, self.attention.W.weight, self.attention.W.bias)

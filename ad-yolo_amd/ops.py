@@ -628,19 +628,34 @@ def se_fc_fwd(ssum, scale, shift, w1, b1, w2, b2, hw):
     return pooled, hid, s
 
 
-def se_tail_fwd(c_t, r_t, scale, shift, s, want_mask=False, r_affine=None):
+def se_tail_pool_ok(h, w, ch):
+    """True when ``se_tail_fwd(..., pool_hw=(h, w))`` takes the shape (adyolo_se_tail_fwd_pool_ok)."""
+    return bool(_lib.load().adyolo_se_tail_fwd_pool_ok(int(h), int(w), int(ch)))
+
+
+def se_tail_fwd(c_t, r_t, scale, shift, s, want_mask=False, r_affine=None, pool_hw=None):
     """e = relu((c*scale+shift)*s + r), r seen through r_affine = (scale, shift) per channel when given.  want_mask: also return the ReLU mask (e > 0) as bits (int64 words, 1/32 of the
-    bytes of e) for ``se_tail_bwd(..., mask=)``; None when the shape does not support it (HW*C/4 % 64 != 0)."""
+    bytes of e) for ``se_tail_bwd(..., mask=)``; None when the shape does not support it (HW*C/4 % 64 != 0).
+    pool_hw = (H, W): return avgpool2(e) [N][H/2][W/2][C] INSTEAD of e (the block in front of a pooled stage boundary; e is
+    never written), always as a pair (pooled, mask or None); the caller checks ``se_tail_pool_ok`` first."""
     _chk(c_t, r_t, scale, shift, s)
     n, ch = c_t.shape[0], c_t.shape[-1]
     hw = c_t.numel() // (n * ch)
-    e = torch.empty_like(c_t)
     mask = None
     if want_mask:
         words = _lib.load().adyolo_relu_mask_words(n, hw, ch)
         if words > 0:
             mask = torch.empty(words, dtype=torch.int64, device=c_t.device)
     rs, rt = r_affine if r_affine is not None else (None, None)
+    if pool_hw is not None:
+        h, w = pool_hw
+        if want_mask and mask is None:
+            raise _lib.AdyoloHipError("se_tail_fwd(pool_hw=): the shape has no mask bits")
+        pooled = _new(c_t, n, h // 2, w // 2, ch)
+        _c("adyolo_se_tail_fwd_pool", _p(c_t), _p(r_t), _p(scale), _p(shift), _p(s), _p(rs), _p(rt), _p(pooled), _p(mask), n, h, w,
+           ch, _stream())
+        return pooled, mask
+    e = torch.empty_like(c_t)
     _c("adyolo_se_tail_fwd", _p(c_t), _p(r_t), _p(scale), _p(shift), _p(s), _p(rs), _p(rt), _p(e), _p(mask), n, hw, ch,
        _stream())
     return (e, mask) if want_mask else e

@@ -269,6 +269,15 @@ long adyolo_relu_mask_words(int N, int HW, int C);
 int adyolo_se_tail_fwd(const float *c, const float *r, const float *scale, const float *shift,
                        const float *s, const float *r_scale /*or NULL*/, const float *r_shift /*or NULL*/, float *e,
                        uint64_t *mask /*or NULL*/, int N, int HW, int C, void *stream);
+/* The tail of the LAST block in front of a pooled stage boundary (the next SEBasicBlock starts with nn.AvgPool2d(2, 2):
+ * resnet.py:29,40 / _make_layer :158-164): pooled [N][H/2][W/2][C] = avgpool2(e) and the ReLU-mask bits of e; e itself is not
+ * written (only the pooling reads it in the forward pass, the backward passes read the bits).  adyolo_se_tail_fwd_pool_ok: 1
+ * when the shape is taken (C/4 a power of two <= 32, H and W even, W*C/4 a multiple of 64), else use adyolo_se_tail_fwd +
+ * adyolo_avgpool2_fwd.  Same values as those two calls, bit for bit. */
+int adyolo_se_tail_fwd_pool_ok(int H, int W, int C);
+int adyolo_se_tail_fwd_pool(const float *c, const float *r, const float *scale, const float *shift, const float *s,
+                            const float *r_scale /*or NULL*/, const float *r_shift /*or NULL*/, float *pooled,
+                            uint64_t *mask /*or NULL*/, int N, int H, int W, int C, void *stream);
 int adyolo_se_tail_bwd_reduce(const float *de, const float *e, const uint64_t *mask /*or NULL*/, const float *c,
                               const float *mean, const float *invstd, float *sg, float *sgx, float *partial, int N,
                               int HW, int C, void *stream);

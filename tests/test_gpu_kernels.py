@@ -311,6 +311,34 @@ def test_batchnorm_train_fwd_bwd(ops, n, h, w, c):
     assert_close(nchw(dxm), x.grad * (x.detach() > 0), 5e-5, "bn dx with relu mask")
 
 
+@pytest.mark.parametrize("n,h,w,c,r_affine,want_mask", [
+    (2, 8, 64, 32, False, True), (3, 6, 32, 64, True, True), (1, 4, 16, 128, False, False), (2, 64, 16, 32, True, True),
+])
+def test_se_tail_fwd_pooled_equals_tail_then_avgpool(ops, n, h, w, c, r_affine, want_mask):
+    """The tail in front of a pooled stage boundary (reference resnet.py:29,40: the next block's AvgPool2d(2, 2)) writes
+    avgpool2(e) and the ReLU-mask bits of e in one pass: both bit-identical to se_tail_fwd followed by avgpool2."""
+    import torch
+    torch.manual_seed(5)
+    cc, r = dev(torch.randn(n, h, w, c)), dev(torch.randn(n, h, w, c))
+    scale, shift = dev(torch.rand(c) + 0.5), dev(torch.randn(c))
+    s = dev(torch.rand(n, c))
+    raff = (dev(torch.rand(c) + 0.5), dev(torch.randn(c))) if r_affine else None
+    assert ops.se_tail_pool_ok(h, w, c)
+    if want_mask:
+        e, bits = ops.se_tail_fwd(cc, r, scale, shift, s, want_mask=True, r_affine=raff)
+    else:
+        e, bits = ops.se_tail_fwd(cc, r, scale, shift, s, r_affine=raff), None
+    ref = ops.avgpool2(e)
+    got, gbits = ops.se_tail_fwd(cc, r, scale, shift, s, want_mask=want_mask, r_affine=raff, pool_hw=(h, w))
+    assert got.shape == ref.shape and torch.equal(got, ref)
+    if want_mask:
+        assert bits is not None and torch.equal(gbits, bits)
+    else:
+        assert gbits is None
+    # shapes the fused form does not take are reported, not mangled
+    assert not ops.se_tail_pool_ok(7, 64, 32) and not ops.se_tail_pool_ok(8, 6, 32) and not ops.se_tail_pool_ok(8, 64, 256)
+
+
 def test_avgpool(ops):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 32, 12, 16, generator=g, requires_grad=True)

@@ -46,6 +46,17 @@ def _rel(got, ref):
 
 
 # ------------------------------------------------------------------------------ the reference's training shape, default init
+class _ShapeOnly:
+    """Stand-in for a ReLU output that was never written (the tail in front of a pooled stage boundary stores avgpool2(e) and
+    the mask bits of e, functional.FUSE_POOL): its mask lives in the bits alone."""
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+    def numel(self):
+        return int(np.prod(self.shape))
+
+
 def _align_relu_masks(model, captured, g, bits=None):
     """Give the fragile ReLU elements (golden: float64 pre-activation within 1e-4 x absmax of zero) the float64 mask.
     The build derives every ReLU mask in backward from a saved ReLU OUTPUT (`a > 0`, `e > 0`) -- or, for the SE tail, from
@@ -58,12 +69,14 @@ def _align_relu_masks(model, captured, g, bits=None):
         pos = torch.from_numpy(np.unpackbits(g["fragile_pos_" + site])[:idx.numel()].astype(bool))
         n, h, w, c = t.shape                                   # ours: channels-last; golden indices: flat NCHW
         ww, hh, cc, nn_ = idx % w, (idx // w) % h, (idx // (w * h)) % c, idx // (w * h * c)
-        flat = (((nn_ * h + hh) * w + ww) * c + cc).to(t.device)
-        pos = pos.to(t.device)
-        v = t.data.view(-1)
-        cur = v[flat]
-        flips += int(((cur > 0) != pos).sum())
-        v[flat] = torch.where(pos, torch.where(cur > 0, cur, torch.full_like(cur, 1e-30)), torch.zeros_like(cur))
+        flat = ((nn_ * h + hh) * w + ww) * c + cc
+        if not isinstance(t, _ShapeOnly):
+            flat = flat.to(t.device)
+            pos = pos.to(t.device)
+            v = t.data.view(-1)
+            cur = v[flat]
+            flips += int(((cur > 0) != pos).sum())
+            v[flat] = torch.where(pos, torch.where(cur > 0, cur, torch.full_like(cur, 1e-30)), torch.zeros_like(cur))
         if bits is not None and site in bits:                  # float4 i = flat >> 2 owns bit (i & 63) of word (i >> 6) * 4 + k
             words = bits[site].cpu().numpy().view(np.uint64)
             f = flat.cpu().numpy().astype(np.uint64)
@@ -71,6 +84,8 @@ def _align_relu_masks(model, captured, g, bits=None):
             w = ((i4 >> np.uint64(6)) * np.uint64(4) + k).astype(np.int64)
             one = np.uint64(1) << (i4 & np.uint64(63))
             p = pos.cpu().numpy()
+            if isinstance(t, _ShapeOnly):                      # no values: the bits ARE the mask
+                flips += int((((words[w] & one) != 0) != p).sum())
             np.bitwise_or.at(words, w[p], one[p])
             np.bitwise_and.at(words, w[~p], ~one[~p])
             bits[site].data.copy_(torch.from_numpy(words.view(np.int64)))      # .data: no version bump on a saved tensor
@@ -122,8 +137,12 @@ def test_seed100_training_step_matches_reference(ops, monkeypatch, algo):
     def grab(site_a, site_e, is_first):
         def hook(mod, inp, out):
             sv = Fn.saved(out.grad_fn)                         # SEBlockFn's saved tensors by name
-            assert sv["e"].data_ptr() == out.data_ptr()
-            captured[site_a], captured[site_e] = sv["a"], out  # a = relu(conv1(x)), e = the block output
+            if sv["e"] is None:                                # the block output is avgpool2(e) (functional.FUSE_POOL): bits only
+                assert "ebits" in sv and out.shape[1] * 2 == sv["cc"].shape[1]
+                captured[site_a], captured[site_e] = sv["a"], _ShapeOnly(sv["cc"].shape)
+            else:
+                assert sv["e"].data_ptr() == out.data_ptr()
+                captured[site_a], captured[site_e] = sv["a"], out  # a = relu(conv1(x)), e = the block output
             if "ebits" in sv:
                 bits[site_e] = sv["ebits"]                     # (e > 0) as bits, read by the SE-tail backward
             if is_first:
