@@ -65,6 +65,8 @@ SIGNATURES = {
     "adyolo_se_fc_bwd_words": (L, [I, I]),
     "adyolo_se_fc_bwd": (I, [P] * 16 + [I, I, I, I, P]),
     "adyolo_se_tail_bwd_apply": (I, [P] * 13 + [I, I, I, F, P]),
+    "adyolo_se_tail_bwd_reduce_pooled": (I, [P] * 8 + [I, I, I, I, P]),
+    "adyolo_se_tail_bwd_apply_pooled": (I, [P] * 13 + [I, I, I, I, F, P]),
     "adyolo_avgpool2_fwd": (I, [P, P, I, I, I, I, P]),
     "adyolo_avgpool2_bwd": (I, [P, P, I, I, I, I, P]),
     "adyolo_add": (I, [P, P, P, L, P]),

@@ -91,10 +91,18 @@ struct BnBwdF {          // (dy, dy * xhat)
     }
 };
 struct SeBwdF {          // g = de * (e > 0): (g, g * xhat(c)); the mask comes from `mask` bits when given, else from e
-    const float *de, *e, *c, *mean, *invstd; const unsigned long long *mask; int HW, C;
+    // Wp > 0: `de` is the gradient of avgpool2(e), [N][H/2][Wp/2][C] with Wp the width of e: de = 0.25 * that, spread 2 x 2
+    const float *de, *e, *c, *mean, *invstd; const unsigned long long *mask; int HW, C, Wp;
     __device__ void operator()(int n, int r, int cx, float4 &a, float4 &b) const {
         const size_t o = ((size_t)n * HW + r) * C + cx * 4;
-        const float4 d = ew_ld(reinterpret_cast<const float4 *>(de + o));
+        float4 d;
+        if (Wp > 0) {
+            const int y = r / Wp, x = r - y * Wp;
+            const float4 g4 = *reinterpret_cast<const float4 *>(de + (((size_t)n * (HW / Wp >> 1) + (y >> 1)) * (Wp >> 1) + (x >> 1)) * C + cx * 4);
+            d = make_float4(0.25f * g4.x, 0.25f * g4.y, 0.25f * g4.z, 0.25f * g4.w);
+        } else {
+            d = ew_ld(reinterpret_cast<const float4 *>(de + o));
+        }
         const float4 cv = ew_ld(reinterpret_cast<const float4 *>(c + o));
         const float4 m = *reinterpret_cast<const float4 *>(mean + cx * 4);
         const float4 is = *reinterpret_cast<const float4 *>(invstd + cx * 4);
@@ -553,16 +561,22 @@ __global__ __launch_bounds__(256) void se_fc_bwd_sample_kernel(
     }
 }
 
-template <bool INV>
+// POOLED (INV only): `de` is the gradient of avgpool2(e) -- [N][H/2][W/2][C], the block's output at a pooled stage boundary was
+// the pooled tensor (se_tail_fwd_pool_kernel) -- and the gradient of e itself, 0.25 x that spread over 2 x 2 pixels, is formed
+// here; it is also WRITTEN to de_out when given (the identity shortcut's share, the addend of conv1's data gradient): no
+// avgpool2_bwd launch, and neither pass of this backward reads a full-size de
+template <bool INV, bool POOLED = false>
 __global__ __launch_bounds__(256) void se_tail_bwd_apply_kernel(
     const float *__restrict__ de, const float *__restrict__ e, const float *__restrict__ c,
     const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ invstd,
     const float *__restrict__ s, const float *__restrict__ dpool, const float *__restrict__ sdd,
     const float *__restrict__ sddx, float *__restrict__ dc, float *__restrict__ dr,
-    const unsigned long long *__restrict__ mask, long hw4, int c4n, float invHW, float invR) {
+    const unsigned long long *__restrict__ mask, long hw4, int c4n, float invHW, float invR, int W = 0, int c4shift = 0,
+    float *__restrict__ de_out = nullptr) {
     const int n = blockIdx.y;
     const size_t base = (size_t)n * hw4;
-    const float4 *de4 = reinterpret_cast<const float4 *>(de) + base, *c4 = reinterpret_cast<const float4 *>(c) + base;
+    const float4 *de4 = reinterpret_cast<const float4 *>(de) + (POOLED ? (base >> 2) : base), *c4 = reinterpret_cast<const float4 *>(c) + base;
+    float4 *deo4 = (POOLED && de_out) ? reinterpret_cast<float4 *>(de_out) + base : nullptr;
     const float4 *e4 = e ? reinterpret_cast<const float4 *>(e) + base : nullptr;
     float4 *dc4 = reinterpret_cast<float4 *>(dc) + base, *dr4 = dr ? reinterpret_cast<float4 *>(dr) + base : nullptr;
     float4 ga, m, is, sv, dp, a, b;
@@ -598,7 +612,13 @@ __global__ __launch_bounds__(256) void se_tail_bwd_apply_kernel(
             for (int u = 0; u < EW_U; ++u) {
                 const long i = i0 + u * 256;
                 if (i < hw4) {
-                    d[u] = ew_ld(&de4[i]);
+                    if (POOLED) {
+                        const int pix = (int)(i >> c4shift), y = pix / W, x = pix - y * W;
+                        const float4 g4 = de4[(((size_t)(y >> 1) * (W >> 1) + (x >> 1)) << c4shift) + (i & (c4n - 1))];
+                        d[u] = make_float4(0.25f * g4.x, 0.25f * g4.y, 0.25f * g4.z, 0.25f * g4.w);
+                    } else {
+                        d[u] = ew_ld(&de4[i]);
+                    }
                     cv[u] = ew_ld(&c4[i]);
                     if (mask) {
                         mask_bits4(mask, base + i, px[u], py[u], pz[u], pw[u]);
@@ -611,7 +631,10 @@ __global__ __launch_bounds__(256) void se_tail_bwd_apply_kernel(
 #pragma unroll
             for (int u = 0; u < EW_U; ++u) {
                 const long i = i0 + u * 256;
-                if (i < hw4) one(i, d[u], cv[u], px[u], py[u], pz[u], pw[u]);
+                if (i < hw4) {
+                    one(i, d[u], cv[u], px[u], py[u], pz[u], pw[u]);
+                    if (POOLED && deo4) ew_st(&deo4[i], d[u]);
+                }
             }
         }
     } else {
@@ -904,12 +927,31 @@ extern "C" int adyolo_se_tail_bwd_reduce(const float *de, const float *e, const 
     ADYOLO_REQUIRE(chan_ok(C) && N <= 1024, ADYOLO_ENOSUP, "se_tail_bwd_reduce: unsupported C=%d or N=%d", C, N);
     hipStream_t st = as_stream(stream);
     const int G = pick_G(N, HW);
-    SeBwdF f{de, e, c, mean, invstd, reinterpret_cast<const unsigned long long *>(mask), HW, C};
+    SeBwdF f{de, e, c, mean, invstd, reinterpret_cast<const unsigned long long *>(mask), HW, C, 0};
     hipLaunchKernelGGL((reduce2_partial_kernel<SeBwdF>), dim3(G, N), dim3(256), 0, st, f, partial, HW, C, G);
     int rc = check_launch("se_tail_bwd_reduce_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(persample_reduce_kernel, dim3(cdiv(C, 32), N), dim3(256), 0, st, partial, sg, sgx, N, G, C);
     return check_launch("se_tail_bwd_reduce_final");
+}
+
+// ... with the gradient of avgpool2(e) in place of de (see se_tail_bwd_apply_kernel<INV, POOLED>)
+extern "C" int adyolo_se_tail_bwd_reduce_pooled(const float *dpooled, const uint64_t *mask, const float *c, const float *mean,
+                                                const float *invstd, float *sg, float *sgx, float *partial, int N, int H, int W,
+                                                int C, void *stream) {
+    ADYOLO_REQUIRE(dpooled && mask && c && mean && invstd && sg && sgx && partial && N > 0 && H > 0 && W > 0, ADYOLO_EINVAL,
+                   "se_tail_bwd_reduce_pooled: bad arguments");
+    ADYOLO_REQUIRE(chan_ok(C) && N <= 1024 && adyolo_se_tail_fwd_pool_ok(H, W, C), ADYOLO_ENOSUP,
+                   "se_tail_bwd_reduce_pooled: unsupported shape H=%d W=%d C=%d N=%d", H, W, C, N);
+    hipStream_t st = as_stream(stream);
+    const int HW = H * W;
+    const int G = pick_G(N, HW);
+    SeBwdF f{dpooled, nullptr, c, mean, invstd, reinterpret_cast<const unsigned long long *>(mask), HW, C, W};
+    hipLaunchKernelGGL((reduce2_partial_kernel<SeBwdF>), dim3(G, N), dim3(256), 0, st, f, partial, HW, C, G);
+    int rc = check_launch("se_tail_bwd_reduce_pooled_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(persample_reduce_kernel, dim3(cdiv(C, 32), N), dim3(256), 0, st, partial, sg, sgx, N, G, C);
+    return check_launch("se_tail_bwd_reduce_pooled_final");
 }
 
 // the same two per-sample sums from the per-patch sums a convolution epilogue already produced (stat_mask = e,
@@ -961,6 +1003,28 @@ extern "C" int adyolo_se_tail_bwd_apply(const float *de, const float *e, const u
                            mean, invstd, s, dpool, sdd, sddx, dc, dr, reinterpret_cast<const unsigned long long *>(mask),
                            hw4, C / 4, 1.0f / (float)HW, inv_r);
     return check_launch("se_tail_bwd_apply");
+}
+
+extern "C" int adyolo_se_tail_bwd_apply_pooled(const float *dpooled, const uint64_t *mask, const float *c, const float *gamma,
+                                               const float *mean, const float *invstd, const float *s, const float *dpool,
+                                               const float *sdd, const float *sddx, float *dc, float *dr, float *de_out, int N,
+                                               int H, int W, int C, float count_scale, void *stream) {
+    ADYOLO_REQUIRE(dpooled && mask && c && gamma && mean && invstd && s && dpool && sdd && sddx && dc && N > 0 && H > 0 && W > 0 &&
+                       count_scale >= 1.f,
+                   ADYOLO_EINVAL, "se_tail_bwd_apply_pooled: bad arguments");
+    ADYOLO_REQUIRE(adyolo_se_tail_fwd_pool_ok(H, W, C), ADYOLO_ENOSUP, "se_tail_bwd_apply_pooled: unsupported shape H=%d W=%d C=%d",
+                   H, W, C);
+    const int HW = H * W, c4n = C / 4;
+    int c4shift = 0;
+    while ((1 << c4shift) < c4n) ++c4shift;
+    const float inv_r = (float)(1.0 / ((double)N * (double)HW * (double)count_scale));
+    const long hw4 = (long)HW * c4n;
+    int gx = ew_grid(cdiv(hw4, (long)EW_U));
+    if ((long)gx * N > 16384) gx = (int)(16384 / N > 0 ? 16384 / N : 1);
+    hipLaunchKernelGGL((se_tail_bwd_apply_kernel<true, true>), dim3(gx, N), dim3(256), 0, as_stream(stream), dpooled,
+                       (const float *)nullptr, c, gamma, mean, invstd, s, dpool, sdd, sddx, dc, dr,
+                       reinterpret_cast<const unsigned long long *>(mask), hw4, c4n, 1.0f / (float)HW, inv_r, W, c4shift, de_out);
+    return check_launch("se_tail_bwd_apply_pooled");
 }
 
 extern "C" int adyolo_avgpool2_fwd(const float *x, float *y, int N, int H, int W, int C, void *stream) {

@@ -35,6 +35,7 @@ FUSE_MASKBITS = os.environ.get("ADYOLO_FUSE_MASKBITS", "1") != "0"
 FUSE_STEM_AFFINE = os.environ.get("ADYOLO_FUSE_STEM_AFFINE", "1") != "0"
 # the tail of the last block in front of a pooled stage boundary writes avgpool2(e) + the mask bits of e, never e (round 6)
 FUSE_POOL = os.environ.get("ADYOLO_FUSE_POOL", "1") != "0"
+FUSE_POOL_BWD = os.environ.get("ADYOLO_FUSE_POOL_BWD", "1") != "0"      # ... and its backward never reads a full-size de
 
 
 class BlockLink:
@@ -425,7 +426,13 @@ class SEBlockFn(torch.autograd.Function):
         n, h, w_, cin = p.shape
         c = cc.shape[-1]
         de = _c(de)
-        if ctx.pool_out is not None:              # our output was avgpool2(e): the gradient of e itself
+        ebits_early = t[21] if ctx.has_bits else None
+        pooled_hw = None
+        if ctx.pool_out is not None and ebits_early is not None and FUSE_POOL_BWD:
+            # our output was avgpool2(e): both passes of the tail's backward spread the pooled gradient on the fly, and the
+            # apply pass writes the gradient of e itself where the identity shortcut needs it (conv1's data-gradient addend)
+            pooled_hw = ctx.pool_out
+        elif ctx.pool_out is not None:
             de = ops.avgpool2_bwd(de, ctx.pool_out[0], ctx.pool_out[1])
         tiles = None
         if ctx.link_out is not None and ctx.link_out.tiles is not None:
@@ -441,10 +448,16 @@ class SEBlockFn(torch.autograd.Function):
         sunk = vse is not None and vw1 is not None and vw2 is not None and vg1 is not None and vb1 is not None
         if not sunk:
             vse = vw1 = vw2 = vg1 = vb1 = None
+        de_full = None
+        if pooled_hw is not None and not ctx.has_down and FUSE_DR:
+            de_full = torch.empty(n, pooled_hw[0], pooled_hw[1], c, dtype=torch.float32, device=de.device)
         dc, dr, dg2, db2, dfw1, dfb1, dfw2, dfb2 = ops.se_tail_bwd(de, e, cc, g2, b2, mean2, invstd2, ssum2, pooled,
                                                                    hid, s, fw1, fw2,
                                                                    want_dr=ctx.has_down or not FUSE_DR, tile_stats=tiles,
-                                                                   mask=ebits, packed_out=vse)
+                                                                   mask=ebits, packed_out=vse, pooled_hw=pooled_hw,
+                                                                   de_out=de_full)
+        if pooled_hw is not None:
+            de = de_full                          # (None when nothing below reads it)
         if ctx.fused_affine:
             a = src
             dw2 = ops.conv3x3_wgrad(a, dc, c, in_affine=(scale1, shift1), out=vw2)

@@ -662,13 +662,18 @@ def se_tail_fwd(c_t, r_t, scale, shift, s, want_mask=False, r_affine=None, pool_
 
 
 def se_tail_bwd(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1, w2, want_dr=True, tile_stats=None,
-                mask=None, packed_out=None):
+                mask=None, packed_out=None, pooled_hw=None, de_out=None):
     """Backward of  e = relu(bn2(c) * s + r)  incl. the SE FCs.
     -> dc, dr, dgamma, dbeta, dw1, db1, dw2, db2
     tile_stats: per-patch sums [2][tiles][C] of de * (e > 0) and de * (e > 0) * xhat(c) from the convolution epilogue
     that produced ``de`` (``conv3x3(..., stat_bn=(c, mean, invstd), stat_mask=e)``): the reduction pass is skipped.
-    mask: the bits ``se_tail_fwd(..., want_mask=True)`` returned; both passes then read them instead of e."""
-    _chk(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1, w2)
+    mask: the bits ``se_tail_fwd(..., want_mask=True)`` returned; both passes then read them instead of e.
+    pooled_hw = (H, W): the block's output was avgpool2(e) (``se_tail_fwd(pool_hw=)``) and ``de`` is the gradient of THAT,
+    [N][H/2][W/2][C]; needs ``mask``.  de_out (optional, [N][H][W][C]) receives the gradient of e itself (avgpool2's backward),
+    which no pass here reads."""
+    _chk(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1, w2, de_out)
+    if pooled_hw is not None and mask is None:
+        raise _lib.AdyoloHipError("se_tail_bwd(pooled_hw=) needs the ReLU-mask bits")
     n, ch = c_t.shape[0], c_t.shape[-1]
     hw = c_t.numel() // (n * ch)
     cr = w1.shape[0]
@@ -677,8 +682,12 @@ def se_tail_bwd(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1,
         _c("adyolo_se_tail_bwd_tiles", _p(tile_stats), _p(sg), _p(sgx), n, tile_stats.shape[1] // n, ch, _stream())
     else:
         partial = _new(c_t, 2 * 1024 * ch)
-        _c("adyolo_se_tail_bwd_reduce", _p(de), _p(e), _p(mask), _p(c_t), _p(mean), _p(invstd), _p(sg), _p(sgx), _p(partial),
-           n, hw, ch, _stream())
+        if pooled_hw is not None:
+            _c("adyolo_se_tail_bwd_reduce_pooled", _p(de), _p(mask), _p(c_t), _p(mean), _p(invstd), _p(sg), _p(sgx), _p(partial),
+               n, pooled_hw[0], pooled_hw[1], ch, _stream())
+        else:
+            _c("adyolo_se_tail_bwd_reduce", _p(de), _p(e), _p(mask), _p(c_t), _p(mean), _p(invstd), _p(sg), _p(sgx), _p(partial),
+               n, hw, ch, _stream())
     pw = 2 * ch * cr + cr + 3 * ch
     part, cws = _new(c_t, n, pw), _new(c_t, 1024, pw)
     packed = packed_out if packed_out is not None else _new(c_t, pw)    # packed_out: the six gradients' slice of the flat buffer
@@ -699,8 +708,12 @@ def se_tail_bwd(de, e, c_t, gamma, beta, mean, invstd, ssum, pooled, hid, s, w1,
     if EXACT.on:                # BN2's batch sums over all ranks for the dc formula; the packed parameter gradients stay local
         glob = EXACT.all_reduce(torch.stack([sdd, sddx]))
         a_sdd, a_sddx, cs = glob[0], glob[1], float(EXACT.world)
-    _c("adyolo_se_tail_bwd_apply", _p(de), _p(e), _p(mask), _p(c_t), _p(gamma), _p(mean), _p(invstd), _p(s), _p(dpool),
-       _p(a_sdd), _p(a_sddx), _p(dc), _p(dr), n, hw, ch, cs, _stream())
+    if pooled_hw is not None:
+        _c("adyolo_se_tail_bwd_apply_pooled", _p(de), _p(mask), _p(c_t), _p(gamma), _p(mean), _p(invstd), _p(s), _p(dpool),
+           _p(a_sdd), _p(a_sddx), _p(dc), _p(dr), _p(de_out), n, pooled_hw[0], pooled_hw[1], ch, cs, _stream())
+    else:
+        _c("adyolo_se_tail_bwd_apply", _p(de), _p(e), _p(mask), _p(c_t), _p(gamma), _p(mean), _p(invstd), _p(s), _p(dpool),
+           _p(a_sdd), _p(a_sddx), _p(dc), _p(dr), n, hw, ch, cs, _stream())
     return dc, dr, dgamma, dbeta, dw1, db1, dw2, db2
 
 

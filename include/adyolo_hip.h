@@ -289,6 +289,17 @@ int adyolo_se_fc_bwd(const float *sg, const float *sgx, const float *ssum, const
                      const float *hid, const float *s, const float *w1, const float *w2, float *dpool,
                      float *part /*[N][P]*/, float *packed /*[P]*/, float *colsum_ws /*[1024][P]*/, int N,
                      int HW, int C, int Cr, void *stream);
+/* The two passes for a block whose output was the pooled tensor (adyolo_se_tail_fwd_pool): dpooled [N][H/2][W/2][C] is the
+ * gradient of avgpool2(e); de = 0.25 * dpooled spread over 2 x 2 pixels is formed on the fly (torch.nn.AvgPool2d's backward,
+ * resnet.py:29) and written to de_out when given -- the identity shortcut's share of the gradient, read by conv1's
+ * data-gradient epilogue -- so no adyolo_avgpool2_bwd launch and no full-size de is read by either pass.  Same values. */
+int adyolo_se_tail_bwd_reduce_pooled(const float *dpooled, const uint64_t *mask, const float *c, const float *mean,
+                                     const float *invstd, float *sg, float *sgx, float *partial, int N, int H, int W, int C,
+                                     void *stream);
+int adyolo_se_tail_bwd_apply_pooled(const float *dpooled, const uint64_t *mask, const float *c, const float *gamma,
+                                    const float *mean, const float *invstd, const float *s, const float *dpool,
+                                    const float *sdd, const float *sddx, float *dc, float *dr /*or NULL*/,
+                                    float *de_out /*or NULL*/, int N, int H, int W, int C, float count_scale, void *stream);
 int adyolo_se_tail_bwd_apply(const float *de, const float *e, const uint64_t *mask /*or NULL*/, const float *c,
                              const float *gamma, const float *mean, const float *invstd, const float *s,
                              const float *dpool, const float *sdd, const float *sddx, float *dc,

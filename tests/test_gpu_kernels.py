@@ -339,6 +339,37 @@ def test_se_tail_fwd_pooled_equals_tail_then_avgpool(ops, n, h, w, c, r_affine, 
     assert not ops.se_tail_pool_ok(7, 64, 32) and not ops.se_tail_pool_ok(8, 6, 32) and not ops.se_tail_pool_ok(8, 64, 256)
 
 
+@pytest.mark.parametrize("n,h,w,c,want_dr", [(2, 8, 64, 32, False), (3, 6, 32, 64, True), (2, 64, 16, 32, False)])
+def test_se_tail_bwd_from_the_pooled_gradient_equals_avgpool_bwd_then_tail_bwd(ops, n, h, w, c, want_dr):
+    """Backward of a block whose output was avgpool2(e) (reference resnet.py:29: AvgPool2d's backward in front of the tail's):
+    the reduction and the apply pass take the POOLED gradient and the apply pass writes the gradient of e -- every output
+    bit-identical to avgpool2_bwd followed by the ordinary passes."""
+    import torch
+    torch.manual_seed(7)
+    cr = max(c // 8, 4)
+    cc, r = dev(torch.randn(n, h, w, c)), dev(torch.randn(n, h, w, c))
+    gamma, beta = dev(torch.rand(c) + 0.5), dev(torch.randn(c))
+    mean, invstd = dev(torch.randn(c) * 0.1), dev(torch.rand(c) + 0.5)
+    scale, shift = ops.bn_scale_shift(gamma, beta, mean, invstd)
+    fw1, fb1, fw2, fb2 = dev(torch.randn(cr, c) * 0.1), dev(torch.randn(cr) * 0.1), dev(torch.randn(c, cr) * 0.1), dev(torch.randn(c) * 0.1)
+    ssum = cc.sum(dim=(1, 2)).contiguous()
+    pooled, hid, s = ops.se_fc_fwd(ssum, scale, shift, fw1, fb1, fw2, fb2, h * w)
+    _, bits = ops.se_tail_fwd(cc, r, scale, shift, s, want_mask=True)
+    dpo = dev(torch.randn(n, h // 2, w // 2, c))
+    de = ops.avgpool2_bwd(dpo, h, w)
+    ref = ops.se_tail_bwd(de, None, cc, gamma, beta, mean, invstd, ssum, pooled, hid, s, fw1, fw2, want_dr=want_dr, mask=bits)
+    de_out = torch.empty_like(cc)
+    got = ops.se_tail_bwd(dpo, None, cc, gamma, beta, mean, invstd, ssum, pooled, hid, s, fw1, fw2, want_dr=want_dr, mask=bits,
+                          pooled_hw=(h, w), de_out=de_out)
+    torch.cuda.synchronize()
+    assert torch.equal(de_out, de)
+    for a, b, what in zip(got, ref, ("dc", "dr", "dgamma", "dbeta", "dw1", "db1", "dw2", "db2")):
+        if a is None or b is None:
+            assert a is None and b is None, what
+        else:
+            assert torch.equal(a, b), what
+
+
 def test_avgpool(ops):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 32, 12, 16, generator=g, requires_grad=True)
