@@ -37,7 +37,9 @@
 #define W4P_X_AUX 0       // ... of the staged input's loads (A/B switch)
 #endif
 #ifndef W4P_OP_AUX
-#define W4P_OP_AUX 0      // ... of the fused operands' loads (addend, statistics input: each read once; 2 measured no gain)
+#define W4P_OP_AUX 2      // ... of the fused operands' loads (addend, statistics input: each read once): non-temporal since round 6 --
+                          // they no longer push the staged input's half-read lines out of L2 (-5.5 % reads at stage 1, data-gradient
+                          // launches -1.3 to -2.5 % at stages 1-3; profiles/r06_w4p_opaux_ab.txt; no gain when round 5 tried it)
 #endif
 #ifndef W4P_STAGGER
 #define W4P_STAGGER 0     // experiment (round 6): workgroups with an odd slot start this many cycles late, so that the epilogues of the
