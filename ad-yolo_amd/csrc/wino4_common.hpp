@@ -13,6 +13,7 @@ constexpr float A2 = PA * PA, B2 = PB * PB, S2 = A2 + B2, P2 = A2 * B2;
 constexpr float A3 = PA * PA * PA, B3 = PB * PB * PB;
 
 typedef unsigned int u32x4_t __attribute__((__vector_size__(16)));
+typedef unsigned int u32x2_t __attribute__((__vector_size__(8)));
 
 template <int TC>
 struct Cfg {

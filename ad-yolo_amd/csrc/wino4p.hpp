@@ -52,6 +52,12 @@
 #ifndef W4P_BRES
 #define W4P_BRES 1        // 1: 32 -> 32 layers take the resident-U form of the kernel (BRES below), 0: the B ring as everywhere else
 #endif
+#ifndef W4P_MKDEDUP
+#define W4P_MKDEDUP 1     // 1: the epilogue's ReLU-mask bit loads shared between the pixels of a row segment where Cout allows (32 / 64 / 128)
+#endif
+#ifndef W4P_FULL
+#define W4P_FULL 1        // 1: 32 -> 32 layers with operand sets 15 / 27 / 31 request both halves of the next patch's input lines together
+#endif
 #ifndef W4P_BRES_ACC
 #define W4P_BRES_ACC 3    // channel groups (of the four) of the resident U kept in AccVGPRs
 #endif
@@ -118,7 +124,16 @@ struct PairConst<std::integral_constant<int, V>> { static constexpr int value = 
 // 144 registers, the half of the accumulator file an NB = 1 kernel leaves unused -- is loaded ONCE per workgroup and stays resident:
 // no B fragment loads in the pair loop (a buffer load costs the issuing wave ~19 cycles next to the fp32 MFMA, 72 of them per patch),
 // and the two pairs are two copies of the body (pair index, image-buffer parity and register indices are compile-time constants)
-template <int TC, bool AFF, int EPI, int NB, bool BRES = false>
+// FULL (32 -> 32 layers whose epilogue leaves no room for BRES -- operand sets 15 / 27 / 31 -- but 48 registers): a 32-channel
+// pixel is ONE 128-byte line and its two 64-byte halves belong to the patch's two pairs.  Requested microseconds apart the
+// second half misses L2 again at this stage's traffic (profiles/r06_w4p_fetch_excess.txt), and these launches ARE bound by their
+// bytes.  Here both halves of the next patch are requested back to back (during the current patch's pair 0; the pair-1 half
+// waits in a second register set across pair 1 and the epilogue), nothing is requested twice, and the pair body is
+// instantiated per pair as in BRES.
+// MKM (operand sets with ReLU-mask bits; compile-time, like every operand combination of this kernel: run-time variants of the
+// mask arrays went through scratch memory): how the 4 pixels of an epilogue row segment share their mask words -- 0 each pixel
+// loads its own dword per component (any Cout, any W), 1 / 2 / 3: Cout = 32 / 64 / 128 and W % 4 == 0, see `keep` in the epilogue
+template <int TC, bool AFF, int EPI, int NB, bool BRES = false, bool FULL = false, int MKM = 0>
 __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
     const float *__restrict__ x, const float *__restrict__ u, const float *__restrict__ bias,
     const float *__restrict__ addend, const float *__restrict__ addend_mask, const float *__restrict__ in_scale,
@@ -282,7 +297,8 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
     };
 
     static_assert(!BRES || NB == 1, "resident U: 32-channel output blocks only");
-    const int nkg = BRES ? 4 : Cin / 8, npairs = BRES ? 2 : Cin / 16;     // (npairs is even: Cin % 32 == 0)
+    static_assert(!(BRES && FULL), "BRES and FULL exclude each other");
+    const int nkg = (BRES || FULL) ? 4 : Cin / 8, npairs = (BRES || FULL) ? 2 : Cin / 16;     // (npairs is even: Cin % 32 == 0)
     const size_t ustride_pos = (size_t)(Cout / 32) * nkg * 256;
     const int urec = (int)(36 * ustride_pos * 4);
     const int ulane = lane * 16;
@@ -323,6 +339,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
 
     f32x16 acc[9][NB];
     f32x4 pvA[6], pvB[6];
+    f32x4 pvC[6], pvD[6];                                 // FULL: the pair-1 halves (rounds 0 / 1) of the next patch (else unused)
     __syncthreads();                                      // affine table visible
     // pair 0 of the first patch: all staging rounds in flight together (the accumulators are zeroed while they are)
     st_load(pvA, 0, 0, true);
@@ -337,8 +354,13 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
     st_load(pvA, 2, 0, wave == 0);                        // leftover rows
     st_store(pvB, 1, lds, 0);
     if (wave == 0) st_store(pvA, 2, lds, 0);
-    st_load(pvA, 0, 1, true);                             // rounds 0 and 1 of pair 1 (npairs >= 2)
-    st_load(pvB, 1, 1, true);
+    if constexpr (FULL) {
+        st_load(pvC, 0, 1, true);
+        st_load(pvD, 1, 1, true);
+    } else {
+        st_load(pvA, 0, 1, true);                         // rounds 0 and 1 of pair 1 (npairs >= 2)
+        st_load(pvB, 1, 1, true);
+    }
     __syncthreads();
 
     // (ext-vector values throughout: with one wave per SIMD a v_pk_fma_f32 issues in the time of a v_fma_f32 --
@@ -393,7 +415,10 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
     // No run-time condition around a load or an LDS read (the compiler's vmcnt / lgkmcnt bookkeeping stays exact), and nothing
     // of them is live across the epilogue.
     auto pair_body = [&](auto PR_) {
-        const int pr = PR_;                                                    // (BRES: an integral constant)
+        const int pr = PR_;                                                    // (BRES, FULL: an integral constant)
+        constexpr bool second = FULL && PairConst<decltype(PR_)>::value == 0;   // FULL, pair 0: pair 1 of THIS patch is staged, from C / D
+        f32x4(&SA)[6] = second ? pvC : pvA;
+        f32x4(&SB)[6] = second ? pvD : pvB;
         float *Cn = lds + ((pr + 1) & 1) * (2 * CBUF);
         const int prn = pr + 1 < npairs ? pr + 1 : 0;                          // pair being staged
         const int prn2 = pr + 2 < npairs ? pr + 2 : pr + 2 - npairs;           // pair being requested
@@ -420,11 +445,11 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                     if (step == 12) a_xform_full();
                     if (step == 18) a_xform_half();
                     if (step == 30) a_xform_full();                            // the next pair's first group
-                    if (step == 4) st_xform(pvA, 0, prn);
-                    if (step == 12) st_xform(pvB, 1, prn);
-                    if (step == 6) st_write(pvA, 0, Cn);
-                    if (step == 14) st_write(pvB, 1, Cn);
-                    if (step == 22 && lwave) st_store(pvA, 2, Cn, prn);
+                    if (step == 4) st_xform(SA, 0, prn);
+                    if (step == 12) st_xform(SB, 1, prn);
+                    if (step == 6) st_write(SA, 0, Cn);
+                    if (step == 14) st_write(SB, 1, Cn);
+                    if (step == 22 && lwave) st_store(SA, 2, Cn, prn);
                     // full-round requests from step 16 on and leftover-row requests from the next pair's step 8 on belong to the
                     // next patch (every transform of this patch's data that needs the old offsets is done by then)
                     if (step == 13 && turn) {
@@ -478,9 +503,23 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                     if (step == 28) a_reads_full(0);                           // (bases: the next pair's already)
                     if (step == 32) a_reads_half(0);
                     if (!(W4P_WHATIF & 128)) {
-                        if (step == 25) st_load(pvA, 0, prn2, true, pr == npairs - 1);
-                        if (step == 16) st_load(pvB, 1, prn2, true, pr == npairs - 1);
-                        if (step == 8) st_load(pvA, 2, prn, lwave);
+                        if constexpr (FULL) {
+                            // both halves of the next patch's lines, back to back, from the current patch's pair 0; nothing from pair 1
+                            if constexpr (second) {
+                                if (step == 16) {
+                                    st_load(pvB, 1, 0, true);
+                                    st_load(pvD, 1, 1, true);
+                                }
+                                if (step == 25) {
+                                    st_load(pvA, 0, 0, true);
+                                    st_load(pvC, 0, 1, true);
+                                }
+                            }
+                        } else {
+                            if (step == 25) st_load(pvA, 0, prn2, true, pr == npairs - 1);
+                            if (step == 16) st_load(pvB, 1, prn2, true, pr == npairs - 1);
+                        }
+                        if (step == 8) st_load(SA, 2, prn, lwave);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -514,7 +553,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
             Wn = W;
         }
         tstamp(0);
-        if constexpr (BRES) {
+        if constexpr (BRES || FULL) {
             pair_body(std::integral_constant<int, 0>{});
             pair_body(std::integral_constant<int, 1>{});
         } else {
@@ -571,30 +610,63 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
             // offsets turns a bit into an and-mask where it is applied.
             f32x4 ad[2][4], ax[2][4];
             unsigned amk_raw[2][4][4], smk_raw[2][4][4], amk = 0, smk = 0;
+            // (round 6: a buffer load costs the issuing wave ~19 cycles here, and the 4 pixels of a row segment are 4 x Cout/4 float4
+            //  apart -- with 32 output channels all of them share ONE dword per component, with 64 one 8-byte word, with 128 two:
+            //  4 / 4 / 8 loads per row segment and mask instead of 16.  The shared word is fetched for the segment's first pixel; if
+            //  that one is in the image and a later one is not, the later one reads bits of some other pixel -- its addend is 0, its
+            //  store is dropped and its statistics are skipped, so they are never used)
+            // (needs W % 4 == 0: a row segment then starts at a float4 index that is a multiple of 4 x Cout/4; the launcher checks)
+            constexpr int mkmode = MKM;
+            static_assert(MKM == 0 || (MKM == 1 && NB == 1) || ((MKM == 2 || MKM == 3) && NB == 2), "mask sharing mode vs block width");
             auto keep = [&](const float *mptr, unsigned (&mk)[2][4][4]) {
                 const __amdgpu_buffer_rsrc_t rs = rsrc_of(mptr + (sbase >> 8) * 8, sbytes >> 5);
 #pragma unroll
-                for (int e = 0; e < 2; ++e)
+                for (int e = 0; e < 2; ++e) {
+                    const int q0 = off[e][0] >> 4;
+                    if (mkmode == 1) {
+                        const int wo = off[e][0] >= 0 ? (q0 >> 6) * 32 + ((q0 >> 5) & 1) * 4 : (int)0x80000000;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const int q = off[e][b] >> 4;
-                        const int wo = off[e][b] >= 0 ? (q >> 6) * 32 + ((q >> 5) & 1) * 4 : (int)0x80000000;
+                        for (int k = 0; k < 4; ++k) mk[e][0][k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, wo, k * 8, 0);
+                    } else if (mkmode >= 2) {
+                        const int wo = off[e][0] >= 0 ? (q0 >> 6) * 32 : (int)0x80000000;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            mk[e][b][k] = (W4P_WHATIF & 256) ? 0xffffffffu + (unsigned)wo * 0u
-                                                             : (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, wo, k * 8, 0);
+                        for (int k = 0; k < 4; ++k) {
+                            const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, wo, k * 8, 0);
+                            mk[e][0][k] = v[0];
+                            mk[e][1][k] = v[1];
+                            if (mkmode == 3) {
+                                const u32x2_t v2 = __builtin_amdgcn_raw_buffer_load_b64(rs, wo, 32 + k * 8, 0);
+                                mk[e][2][k] = v2[0];
+                                mk[e][3][k] = v2[1];
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const int q = off[e][b] >> 4;
+                            const int wo = off[e][b] >= 0 ? (q >> 6) * 32 + ((q >> 5) & 1) * 4 : (int)0x80000000;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                mk[e][b][k] = (W4P_WHATIF & 256) ? 0xffffffffu + (unsigned)wo * 0u
+                                                                 : (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, wo, k * 8, 0);
+                        }
                     }
+                }
             };
             auto squeeze = [&](const unsigned (&mk)[2][4][4]) {
                 unsigned r = 0;
 #pragma unroll
-                for (int e = 0; e < 2; ++e)
+                for (int e = 0; e < 2; ++e) {
+                    const unsigned s0 = (unsigned)(off[e][0] >> 4) & 31u;
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        const unsigned sh = (unsigned)(off[e][b] >> 4) & 31u;
+                        const unsigned sh = mkmode == 1 ? s0 + 8u * b : mkmode == 2 ? s0 + 16u * (b & 1) : mkmode == 3 ? s0
+                                                                                                          : (unsigned)(off[e][b] >> 4) & 31u;
+                        const int rb = mkmode == 1 ? 0 : mkmode == 2 ? (b >> 1) : b;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) r |= __builtin_amdgcn_ubfe(mk[e][b][k], sh, 1u) << (16 * e + 4 * b + k);
+                        for (int k = 0; k < 4; ++k) r |= __builtin_amdgcn_ubfe(mk[e][rb][k], sh, 1u) << (16 * e + 4 * b + k);
                     }
+                }
                 return r;
             };
             if (AD) {
@@ -619,8 +691,10 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                 //  ~10 B / clock / CU; those two keep the late form, the 48 registers are not there: profiles/r05_w4p_hoisted_requests_ab.txt)
                 set_off(offF, false, nty, ntx, Wn);
                 xbF = x + (size_t)nn * xsample;
-                st_load(pvA, 0, 1, true);
-                st_load(pvB, 1, 1, true);
+                if constexpr (!FULL) {                    // (FULL: that half is in pvC / pvD already)
+                    st_load(pvA, 0, 1, true);
+                    st_load(pvB, 1, 1, true);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- writer: raw accumulators (rows rh * 8 .. + 7 of the 32 x 32 tile) of the wave's nine positions, straight from
@@ -707,8 +781,10 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                 set_off(offF, false, nty, ntx, Wn);
                 xbF = x + (size_t)nn * xsample;
                 if (W4P_TIMING) tstamp(12);
-                st_load(pvA, 0, 1, true);
-                st_load(pvB, 1, 1, true);
+                if constexpr (!FULL) {
+                    st_load(pvA, 0, 1, true);
+                    st_load(pvB, 1, 1, true);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (W4P_TIMING) tstamp(13);
             }
@@ -874,11 +950,36 @@ void launch_wino4p(const W4Launch &a) {
             return;
         }
     }
+    // shared ReLU-mask words (MKM): the three shapes the SE-ResNet's data gradients have, bits for every mask that is given
+    const bool mkshare = W4P_MKDEDUP && (EPI == 15 || EPI == 27 || EPI == 31) && (a.W & 3) == 0 && !a.in_scale &&
+                         (a.mask_bits & (((EPI & 4) ? 1 : 0) | ((EPI & 16) ? 2 : 0))) == (((EPI & 4) ? 1 : 0) | ((EPI & 16) ? 2 : 0));
+    if constexpr (EPI == 15 || EPI == 27 || EPI == 31) {
+        if (mkshare && a.nb == 2 && a.tc == 8 && a.Cout == 64) {
+            ADYOLO_WINO4P_FWD(8, false, 2, false, false, 2);
+            return;
+        }
+        // (Cout = 128, two 8-byte words per component and row segment -- MKM 3 -- measured 0.5-2.9 % SLOWER than the dwords and is
+        //  not instantiated: profiles/r06_w4p_mkdedup_ab.txt)
+        if (mkshare && a.nb == 1 && a.tc == 8 && a.Cout == 32 && a.Cin == 32 && W4P_FULL) {
+            ADYOLO_WINO4P_FWD(8, false, 1, false, true, 1);
+            return;
+        }
+    }
     if (a.nb == 2) {
         ADYOLO_WINO4P_NB(2)
     } else {
         // 32 -> 32 layers: the resident-U form where the epilogue leaves it the registers (operand sets 15 / 27 / 31 do not: 20-46
         // spilled registers and 6-14 % slower, profiles/r06_w4p_bres_ab.txt)
+        if constexpr (W4P_FULL && (EPI == 15 || EPI == 27 || EPI == 31)) {
+            if (a.Cin == 32) {                            // the same layers where resident U does not fit: whole input lines at once
+                if (a.tc == 8) {
+                    if (a.in_scale) ADYOLO_WINO4P_FWD(8, true, 1, false, true); else ADYOLO_WINO4P_FWD(8, false, 1, false, true);
+                } else {
+                    if (a.in_scale) ADYOLO_WINO4P_FWD(4, true, 1, false, true); else ADYOLO_WINO4P_FWD(4, false, 1, false, true);
+                }
+                return;
+            }
+        }
         if constexpr (W4P_BRES && (EPI == 0 || EPI == 1 || EPI == 2 || EPI == 9)) {
             if (a.Cin == 32) {
                 if (a.tc == 8) {
