@@ -971,12 +971,10 @@ void launch_wino4p(const W4Launch &a) {
         // 32 -> 32 layers: the resident-U form where the epilogue leaves it the registers (operand sets 15 / 27 / 31 do not: 20-46
         // spilled registers and 6-14 % slower, profiles/r06_w4p_bres_ab.txt)
         if constexpr (W4P_FULL && (EPI == 15 || EPI == 27 || EPI == 31)) {
-            if (a.Cin == 32) {                            // the same layers where resident U does not fit: whole input lines at once
-                if (a.tc == 8) {
-                    if (a.in_scale) ADYOLO_WINO4P_FWD(8, true, 1, false, true); else ADYOLO_WINO4P_FWD(8, false, 1, false, true);
-                } else {
-                    if (a.in_scale) ADYOLO_WINO4P_FWD(4, true, 1, false, true); else ADYOLO_WINO4P_FWD(4, false, 1, false, true);
-                }
+            // the same layers where resident U does not fit: whole input lines at once.  (Data gradients carry no producer affine;
+            //  a launch that does takes the B-ring form below, which is the one the affine variants are checked in.)
+            if (a.Cin == 32 && !a.in_scale) {
+                if (a.tc == 8) ADYOLO_WINO4P_FWD(8, false, 1, false, true); else ADYOLO_WINO4P_FWD(4, false, 1, false, true);
                 return;
             }
         }

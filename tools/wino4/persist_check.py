@@ -135,7 +135,10 @@ def main():
         # heights / widths, both tile shapes (W = 16: 4 tile columns), 1 / 2 / 4 channel blocks, 2 ... 32 pairs
         for shp in [(1, 16, 16, 32, 64), (2, 32, 16, 64, 64), (64, 160, 16, 64, 64), (64, 90, 16, 64, 128), (40, 70, 32, 64, 64),
                     (24, 67, 16, 128, 256), (3, 37, 40, 32, 64), (70, 33, 50, 32, 128), (9, 100, 64, 64, 64), (2, 600, 16, 256, 256),
-                    (5, 8, 16, 512, 64), (48, 64, 32, 32, 64), (3, 40, 64, 32, 32), (40, 64, 64, 32, 32), (20, 72, 32, 64, 32)]:
+                    (5, 8, 16, 512, 64), (48, 64, 32, 32, 64), (3, 40, 64, 32, 32), (40, 64, 64, 32, 32), (20, 72, 32, 64, 32),
+                    # round 6 (resident U, whole-line staging, shared mask words): 32 -> 32 with a width that is not a multiple of 4 (no
+                    # mask sharing) and with ragged patches in both directions; 64 -> 64 the same
+                    (40, 52, 70, 32, 32), (70, 36, 52, 32, 32), (48, 44, 36, 64, 64)]:
             print("shape N=%d H=%d W=%d %d->%d" % shp, flush=True)
             worst = max(worst, check(*shp))
         print("WORST relative error %.3e %s" % (worst, "OK" if worst < 2e-5 else "FAIL"), flush=True)
