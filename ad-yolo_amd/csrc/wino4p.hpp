@@ -55,6 +55,9 @@
 #ifndef W4P_MKDEDUP
 #define W4P_MKDEDUP 1     // 1: the epilogue's ReLU-mask bit loads shared between the pixels of a row segment where Cout allows (32 / 64 / 128)
 #endif
+#ifndef W4P_LEFT_PIN
+#define W4P_LEFT_PIN 1    // 1: the leftover-row data get an (empty) unconditional use in front of `if (lwave)`: see pair_body, step 22
+#endif
 #ifndef W4P_FULL
 #define W4P_FULL 1        // 1: 32 -> 32 layers with operand sets 15 / 27 / 31 request both halves of the next patch's input lines together
 #endif
@@ -449,6 +452,13 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                     if (step == 12) st_xform(SB, 1, prn);
                     if (step == 6) st_write(SA, 0, Cn);
                     if (step == 14) st_write(SB, 1, Cn);
+                    // (the leftover rows are requested at step 8 and used by ONE wave here.  In the per-pair copies of the body (BRES,
+                    //  FULL) the compiler sank the six loads into this branch, right in front of their use: the staging wave waited out
+                    //  a whole memory latency, the other three at the barrier behind it -- ~2 000 cycles per pair in the stamps of
+                    //  profiles/r06_w4p_timing.txt.  An empty asm that READS the six values in every wave keeps the requests where they
+                    //  are issued; the other waves' requests were out of range and came back at once.)
+                    if (step == 22 && W4P_LEFT_PIN && (BRES || FULL))       // (the one-body kernels keep the requests in place by themselves)
+                        asm volatile("" :: "v"(SA[0]), "v"(SA[1]), "v"(SA[2]), "v"(SA[3]), "v"(SA[4]), "v"(SA[5]));
                     if (step == 22 && lwave) st_store(SA, 2, Cn, prn);
                     // full-round requests from step 16 on and leftover-row requests from the next pair's step 8 on belong to the
                     // next patch (every transform of this patch's data that needs the old offsets is done by then)
