@@ -55,6 +55,9 @@
 #ifndef W4P_MKDEDUP
 #define W4P_MKDEDUP 1     // 1: the epilogue's ReLU-mask bit loads shared between the pixels of a row segment where Cout allows (32 / 64 / 128)
 #endif
+#ifndef W4P_SWAP1
+#define W4P_SWAP1 1       // 1: BRES stages round 1 before round 0 in a patch's second pair (see pair_body)
+#endif
 #ifndef W4P_LEFT_PIN
 #define W4P_LEFT_PIN 1    // 1: the leftover-row data get an (empty) unconditional use in front of `if (lwave)`: see pair_body, step 22
 #endif
@@ -422,6 +425,16 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
         constexpr bool second = FULL && PairConst<decltype(PR_)>::value == 0;   // FULL, pair 0: pair 1 of THIS patch is staged, from C / D
         f32x4(&SA)[6] = second ? pvC : pvA;
         f32x4(&SB)[6] = second ? pvD : pvB;
+        // BRES, pair 1: the image staged here is pair 0 of the NEXT patch, requested during pair 0 of this one -- round 1 at
+        // step 16, round 0 at step 25.  With 32-channel blocks a step is half as long (only every other step carries MFMAs): from
+        // step 25 to step 4 of this pair are ~2 500 cycles, less than a memory latency under load.  So this pair takes round 1 FIRST
+        // (steps 4 / 6; 24 steps after its request) and round 0 second (12 / 14; 23 steps), and the leftover rows ride in the round-1
+        // registers, which nothing requests into during this pair.
+        // (measured: resident-U kernels -1.7 to -3.3 % per launch, whole-line kernels +-1 %: BRES only; profiles/r06_w4p_leftpin_ab.txt)
+        constexpr bool swapped = W4P_SWAP1 && BRES && PairConst<decltype(PR_)>::value == 1;
+        f32x4(&S1)[6] = swapped ? SB : SA;                                     // staged at steps 4 / 6, then host of the leftover rows
+        f32x4(&S2)[6] = swapped ? SA : SB;                                     // staged at steps 12 / 14
+        constexpr int R1 = swapped ? 1 : 0, R2 = swapped ? 0 : 1;
         float *Cn = lds + ((pr + 1) & 1) * (2 * CBUF);
         const int prn = pr + 1 < npairs ? pr + 1 : 0;                          // pair being staged
         const int prn2 = pr + 2 < npairs ? pr + 2 : pr + 2 - npairs;           // pair being requested
@@ -448,18 +461,18 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                     if (step == 12) a_xform_full();
                     if (step == 18) a_xform_half();
                     if (step == 30) a_xform_full();                            // the next pair's first group
-                    if (step == 4) st_xform(SA, 0, prn);
-                    if (step == 12) st_xform(SB, 1, prn);
-                    if (step == 6) st_write(SA, 0, Cn);
-                    if (step == 14) st_write(SB, 1, Cn);
+                    if (step == 4) st_xform(S1, R1, prn);
+                    if (step == 12) st_xform(S2, R2, prn);
+                    if (step == 6) st_write(S1, R1, Cn);
+                    if (step == 14) st_write(S2, R2, Cn);
                     // (the leftover rows are requested at step 8 and used by ONE wave here.  In the per-pair copies of the body (BRES,
                     //  FULL) the compiler sank the six loads into this branch, right in front of their use: the staging wave waited out
                     //  a whole memory latency, the other three at the barrier behind it -- ~2 000 cycles per pair in the stamps of
                     //  profiles/r06_w4p_timing.txt.  An empty asm that READS the six values in every wave keeps the requests where they
                     //  are issued; the other waves' requests were out of range and came back at once.)
                     if (step == 22 && W4P_LEFT_PIN && (BRES || FULL))       // (the one-body kernels keep the requests in place by themselves)
-                        asm volatile("" :: "v"(SA[0]), "v"(SA[1]), "v"(SA[2]), "v"(SA[3]), "v"(SA[4]), "v"(SA[5]));
-                    if (step == 22 && lwave) st_store(SA, 2, Cn, prn);
+                        asm volatile("" :: "v"(S1[0]), "v"(S1[1]), "v"(S1[2]), "v"(S1[3]), "v"(S1[4]), "v"(S1[5]));
+                    if (step == 22 && lwave) st_store(S1, 2, Cn, prn);
                     // full-round requests from step 16 on and leftover-row requests from the next pair's step 8 on belong to the
                     // next patch (every transform of this patch's data that needs the old offsets is done by then)
                     if (step == 13 && turn) {
@@ -529,7 +542,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                             if (step == 25) st_load(pvA, 0, prn2, true, pr == npairs - 1);
                             if (step == 16) st_load(pvB, 1, prn2, true, pr == npairs - 1);
                         }
-                        if (step == 8) st_load(SA, 2, prn, lwave);
+                        if (step == 8) st_load(S1, 2, prn, lwave);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
