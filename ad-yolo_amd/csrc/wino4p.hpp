@@ -538,6 +538,13 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                                     st_load(pvC, 0, 1, true);
                                 }
                             }
+                        } else if constexpr (BRES) {
+                            // (the pair index is a compile-time value: the second pair's requests -- never used, see KILLDUP -- are
+                            //  simply not there; they would also land in the registers that host its leftover rows, see `swapped`)
+                            if constexpr (PairConst<decltype(PR_)>::value == 0) {
+                                if (step == 25) st_load(pvA, 0, prn2, true);
+                                if (step == 16) st_load(pvB, 1, prn2, true);
+                            }
                         } else {
                             if (step == 25) st_load(pvA, 0, prn2, true, pr == npairs - 1);
                             if (step == 16) st_load(pvB, 1, prn2, true, pr == npairs - 1);
