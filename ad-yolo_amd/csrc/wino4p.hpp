@@ -55,6 +55,10 @@
 #ifndef W4P_MKDEDUP
 #define W4P_MKDEDUP 1     // 1: the epilogue's ReLU-mask bit loads shared between the pixels of a row segment where Cout allows (32 / 64 / 128)
 #endif
+#ifndef W4P_REQ_FENCE
+#define W4P_REQ_FENCE 0   // 1: a compiler barrier behind the step-16 requests of the per-pair bodies (BRES, FULL), which otherwise drift down
+                          // to ~step 23 -- measured neutral (+-0.5 %, profiles/r06_w4p_leftpin_ab.txt): off
+#endif
 #ifndef W4P_SWAP1
 #define W4P_SWAP1 1       // 1: BRES stages round 1 before round 0 in a patch's second pair (see pair_body)
 #endif
@@ -532,6 +536,7 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                                 if (step == 16) {
                                     st_load(pvB, 1, 0, true);
                                     st_load(pvD, 1, 1, true);
+                                    if (W4P_REQ_FENCE) asm volatile("" ::: "memory");      // (as in the BRES branch below)
                                 }
                                 if (step == 25) {
                                     st_load(pvA, 0, 0, true);
@@ -543,7 +548,13 @@ __global__ __launch_bounds__(256, 1) void wino4p_fwd_kernel(
                             //  simply not there; they would also land in the registers that host its leftover rows, see `swapped`)
                             if constexpr (PairConst<decltype(PR_)>::value == 0) {
                                 if (step == 25) st_load(pvA, 0, prn2, true);
-                                if (step == 16) st_load(pvB, 1, prn2, true);
+                                if (step == 16) {
+                                    st_load(pvB, 1, prn2, true);
+                                    // (a compiler barrier for memory operations: without it these six requests drifted down past the
+                                    //  `if (lwave)` block of step 22 -- a basic-block boundary the scheduling barriers do not reach
+                                    //  across -- and the second pair needs their data FIRST, see `swapped`)
+                                    if (W4P_REQ_FENCE) asm volatile("" ::: "memory");
+                                }
                             }
                         } else {
                             if (step == 25) st_load(pvA, 0, prn2, true, pr == npairs - 1);
