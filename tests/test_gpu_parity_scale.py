@@ -692,6 +692,59 @@ def test_grad_sink_equals_autograd_accumulation(ops):
     assert nonzero >= 0.95 * len(flat.offsets), (nonzero, len(flat.offsets))
 
 
+@pytest.mark.parametrize("training", [True, False])
+def test_pooled_stage_boundaries_equal_the_separate_calls(ops, monkeypatch, training):
+    """functional.FUSE_POOL / FUSE_POOL_BWD (round 6): in front of a pooled stage boundary (reference resnet.py:29,40,158-164:
+    the next SEBasicBlock starts with AvgPool2d(2, 2)) the tail writes avgpool2(e) and the mask bits instead of e, and its backward
+    works from the pooled gradient.  Output, loss and EVERY parameter gradient of the whole model must equal the unfused route
+    bit for bit, in training mode (with and without the backward half) and in evaluation mode."""
+    import bench
+    from adyolo_amd import functional as Fn
+    from adyolo_amd.wrapper import WrapperModel, WrapperCriterion
+    from adyolo_amd.dist import FlatParameters
+    from adyolo_amd.datasets import synthetic_targets
+    torch.manual_seed(100)
+    prm = bench.params("cuda:0")
+    model = WrapperModel((1, 7, 160, 64), (), prm).to("cuda:0")
+    model.train(training)
+    model.encoder.lstm.dropout = 0.0
+    flat = FlatParameters(model)
+    crit = WrapperCriterion(prm)
+    x = torch.randn(3, 7, 160, 64, generator=torch.Generator().manual_seed(4)).to("cuda:0")
+    target = synthetic_targets(3, 40, 12, seed=4)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    seen = []
+    real = ops.se_tail_fwd
+
+    def spy(*a, **kw):
+        seen.append(kw.get("pool_hw"))
+        return real(*a, **kw)
+    monkeypatch.setattr(ops, "se_tail_fwd", spy)
+    runs = []
+    for fuse, fuse_bwd in ((False, False), (True, False), (True, True)):
+        monkeypatch.setattr(Fn, "FUSE_POOL", fuse)
+        monkeypatch.setattr(Fn, "FUSE_POOL_BWD", fuse_bwd)
+        model.load_state_dict(sd0)                       # (training mode moves the running statistics)
+        del seen[:]
+        if training:
+            flat.zero_grad()
+            out = model(x)
+            loss = crit(out, target)
+            loss.backward()
+            torch.cuda.synchronize()
+            runs.append((out.detach().clone(), loss.detach().clone(), flat.flat_grad.clone()))
+        else:
+            with torch.no_grad():
+                out = model(x)
+            torch.cuda.synchronize()
+            runs.append((out.clone(),))
+        pooled = [hw for hw in seen if hw is not None]
+        assert len(seen) == 16 and len(pooled) == (2 if fuse else 0), (fuse, seen)
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------------------ BASELINE configs 3 and 5 on the real model
 def test_config3_dcase2022_c13_train_step_matches_oracle(ops):
     """BASELINE config 3's model on one device: DCASE2022 = 13 classes (src/configs/hyp_data_DCASE2022.yaml:3) -> head
